@@ -1,0 +1,303 @@
+/*
+ * gsx.h — C ABI of the MI355X-native sparse nonlinear-least-squares backend.
+ *
+ * One shared library (libgsx.so, built by hipcc for gfx950) exports exactly the
+ * entry points below.  Plain pointers and sizes only: no C++ types, no torch
+ * types, no exceptions across the boundary.  Every function returns a
+ * gsx_status (0 = OK).  All floating point is FP64, keys are uint64_t
+ * (gtsam::Key, gtsam/base/types.h:97), indices are int32_t.
+ *
+ * What each entry point replaces in the reference (paths relative to
+ * /root/reference/):
+ *
+ *   gsx_create / gsx_destroy     lowering of NonlinearFactorGraph + Values
+ *                                (gtsam/nonlinear/NonlinearFactorGraph.h,
+ *                                 gtsam/nonlinear/Values.h:74-79)
+ *   gsx_set_ordering             params.ordering / Ordering::Create
+ *                                (gtsam/nonlinear/LevenbergMarquardtParams.h:112-117),
+ *                                symbolic analysis = EliminationTree ctor
+ *                                (gtsam/inference/EliminationTree-inst.h:78-156) +
+ *                                JunctionTree ctor (gtsam/inference/JunctionTree-inst.h:51-153)
+ *   gsx_compute_ordering         Ordering::Create for the stand-alone harness
+ *                                (gtsam/inference/Ordering.h:217-236); NOT ccolamd — own
+ *                                minimum-degree / nested-dissection / Schur orderings
+ *   gsx_set_values/get_values    Values insert/at (gtsam/nonlinear/Values.h)
+ *   gsx_error                    NonlinearFactorGraph::error
+ *                                (gtsam/nonlinear/NonlinearFactorGraph.cpp:170-179)
+ *   gsx_linearize                NonlinearFactorGraph::linearize
+ *                                (gtsam/nonlinear/NonlinearFactorGraph.cpp:239-278)
+ *   gsx_get_jacobians            the JacobianFactor [A b] blocks
+ *                                (gtsam/linear/JacobianFactor-inl.h:62-100)
+ *   gsx_hessian_diagonal         GaussianFactorGraph::hessianDiagonal
+ *                                (gtsam/linear/GaussianFactorGraph.cpp:279-287)
+ *   gsx_solve                    buildDampedSystem + NonlinearOptimizer::solve
+ *                                (gtsam/nonlinear/internal/LevenbergMarquardtState.h:125-156,
+ *                                 gtsam/nonlinear/NonlinearOptimizer.cpp:132-179) =
+ *                                eliminateMultifrontal(EliminatePreferCholesky) +
+ *                                GaussianBayesTree::optimize
+ *                                (gtsam/inference/EliminateableFactorGraph-inst.h:123-146,
+ *                                 gtsam/linear/HessianFactor.cpp:515-551,
+ *                                 gtsam/base/cholesky.cpp:108-159,
+ *                                 gtsam/linear/linearAlgorithms-inst.h:49-117)
+ *   gsx_linear_error             GaussianFactorGraph::error
+ *                                (gtsam/linear/GaussianFactorGraph.cpp:71-78)
+ *   gsx_retract                  Values::retract (gtsam/nonlinear/Values.cpp:53-64,99-101)
+ *   gsx_lm_optimize / _iterate   LevenbergMarquardtOptimizer::optimize / iterate
+ *                                (gtsam/nonlinear/LevenbergMarquardtOptimizer.cpp:121-308,
+ *                                 gtsam/nonlinear/NonlinearOptimizer.cpp:62-117,182-231)
+ *   gsx_gn_optimize              GaussNewtonOptimizer::iterate
+ *                                (gtsam/nonlinear/GaussNewtonOptimizer.cpp:44-66)
+ *   gsx_solve_gfg                GaussianFactorGraph::optimize(ordering, EliminatePreferCholesky)
+ *                                (gtsam/linear/GaussianFactorGraph.cpp:316-319) — the
+ *                                NonlinearOptimizer::solve seam
+ *                                (gtsam/nonlinear/NonlinearOptimizer.h:129-130)
+ *
+ * Threading: a handle is NOT thread-safe; distinct handles are independent.
+ * One handle = one device + one HIP stream.  The library fails with
+ * GSX_E_NO_DEVICE when no gfx950 device is usable: there is no CPU fallback.
+ */
+#ifndef GSX_H_
+#define GSX_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gsx_context* gsx_handle;
+
+/* ---- status codes ------------------------------------------------------- */
+typedef enum gsx_status {
+  GSX_OK = 0,
+  GSX_E_INVALID = 1,        /* bad argument / malformed description            */
+  GSX_E_NO_DEVICE = 2,      /* no usable gfx950 device / HIP error             */
+  GSX_E_BAD_ORDERING = 3,   /* ordering is not a permutation of the variables  */
+                            /* (EliminationTree-inst.h:137-141)                */
+  GSX_E_INDETERMINATE = 4,  /* IndeterminantLinearSystemException              */
+                            /* (gtsam/linear/linearExceptions.h:94-97)         */
+  GSX_E_STATE = 5,          /* call sequence error (e.g. solve before linearize)*/
+  GSX_E_NOMEM = 6
+} gsx_status;
+
+/* ---- variable types (state layout / tangent dim) ------------------------ */
+enum {
+  GSX_VAR_VECTOR = 0, /* R^d: state d, tangent d (Point2/Point3/generic)       */
+  GSX_VAR_POSE2 = 1,  /* state (x,y,theta), tangent (x,y,theta)                */
+  GSX_VAR_POSE3 = 2,  /* state R row-major 9 + t 3, tangent (omega3, v3)       */
+  GSX_VAR_CAMERA = 3  /* PinholeCamera<Cal3Bundler>: Pose3 state 12 +          */
+                      /* (f,k1,k2,u0,v0); tangent (pose 6, f, k1, k2)          */
+};
+
+/* ---- factor types -------------------------------------------------------- */
+enum {
+  GSX_F_LINEAR = 0,         /* JacobianFactor given directly: meas = [A b] col-major,
+                               rows = f_rows[i]; keys: any number                 */
+  GSX_F_PRIOR = 1,          /* PriorFactor<T> (gtsam/nonlinear/PriorFactor.h:98-102);
+                               meas = prior value in the variable's state layout  */
+  GSX_F_BETWEEN = 2,        /* BetweenFactor<T> (gtsam/slam/BetweenFactor.h:111-124);
+                               meas = measured T in state layout; T in
+                               {VECTOR, POSE2, POSE3}                              */
+  GSX_F_SFM = 3             /* GeneralSFMFactor<PinholeCamera<Cal3Bundler>,Point3>
+                               (gtsam/slam/GeneralSFMFactor.h:141-177); keys
+                               (camera, point); meas = (u,v)                       */
+};
+
+/* ---- noise model kinds (gtsam/linear/NoiseModel.cpp) --------------------- */
+enum {
+  GSX_NOISE_UNIT = 0,       /* no parameters                                     */
+  GSX_NOISE_ISOTROPIC = 1,  /* 1 parameter: sigma                                */
+  GSX_NOISE_DIAGONAL = 2,   /* m parameters: sigmas                              */
+  GSX_NOISE_GAUSSIAN = 3    /* m*m parameters: upper-triangular sqrt information R,
+                               row-major (whitened = R * unwhitened)             */
+};
+
+/* ---- ordering kinds for gsx_compute_ordering ----------------------------- */
+enum {
+  GSX_ORDER_NATURAL = 0,    /* ascending key                                      */
+  GSX_ORDER_MINDEGREE = 1,  /* own approximate-minimum-degree (host)              */
+  GSX_ORDER_ND = 2,         /* own nested dissection (BFS level-set separators)   */
+  GSX_ORDER_SCHUR = 3       /* VECTOR(3) landmarks first, then the rest by
+                               minimum degree on the reduced graph                */
+};
+
+/*
+ * Immutable problem structure.  Variables are listed in ASCENDING KEY ORDER
+ * (the iteration order of gtsam::Values); everything else refers to variables
+ * by their index in this list.  Factors are listed in graph order.
+ */
+typedef struct gsx_problem_desc {
+  int32_t n_vars;
+  const uint64_t* var_keys;   /* [n_vars] strictly ascending                     */
+  const int32_t* var_types;   /* [n_vars] GSX_VAR_*                              */
+  const int32_t* var_dims;    /* [n_vars] tangent dim (checked for typed vars)   */
+
+  int32_t n_factors;
+  const int32_t* f_type;      /* [n_factors] GSX_F_*                             */
+  const int32_t* f_rows;      /* [n_factors] residual dim m                      */
+  const int32_t* f_key_ptr;   /* [n_factors+1] CSR into f_vars                   */
+  const int32_t* f_vars;      /* variable indices                                */
+  const int64_t* f_meas_ptr;  /* [n_factors+1] CSR into meas                     */
+  const double* meas;
+  const int32_t* f_noise_kind;/* [n_factors] GSX_NOISE_*                         */
+  const int64_t* f_noise_ptr; /* [n_factors+1] CSR into noise                    */
+  const double* noise;
+} gsx_problem_desc;
+
+/* LevenbergMarquardtParams (gtsam/nonlinear/LevenbergMarquardtParams.h:61-98) +
+ * NonlinearOptimizerParams (gtsam/nonlinear/NonlinearOptimizerParams.h:42-108). */
+typedef struct gsx_lm_params {
+  int32_t max_iterations;        /* 100 (legacy) / 50 (ceres)                  */
+  double relative_error_tol;     /* 1e-5 / 1e-6                                */
+  double absolute_error_tol;     /* 1e-5 / 0                                   */
+  double error_tol;              /* 0                                          */
+  double lambda_initial;         /* 1e-5 / 1e-4                                */
+  double lambda_factor;          /* 10 / 2                                     */
+  double lambda_upper_bound;     /* 1e5 / 1e32                                 */
+  double lambda_lower_bound;     /* 0 / 1e-16                                  */
+  double min_model_fidelity;     /* 1e-3                                       */
+  int32_t diagonal_damping;      /* 0 / 1                                      */
+  int32_t use_fixed_lambda_factor; /* 1 / 0                                    */
+  double min_diagonal;           /* 1e-6                                       */
+  double max_diagonal;           /* 1e32                                       */
+  int32_t verbosity;             /* 0 silent, 1 SUMMARY lines to stdout        */
+} gsx_lm_params;
+
+/* Result + per-inner-iteration trace (the CSV the reference's logFile holds:
+ * LevenbergMarquardtOptimizer.cpp:104-118). */
+typedef struct gsx_lm_result {
+  double initial_error;
+  double final_error;
+  double final_lambda;
+  int32_t iterations;            /* outer (accepted) iterations                */
+  int32_t inner_iterations;      /* tryLambda calls                            */
+  int32_t n_solve_failures;      /* indeterminate systems met on the way       */
+  int32_t trace_len;             /* entries written to the trace arrays        */
+  /* caller-owned, each [trace_cap] or NULL */
+  int32_t trace_cap;
+  double* trace_error;           /* error after the inner iteration            */
+  double* trace_lambda;          /* lambda tried                               */
+  int32_t* trace_accepted;       /* 1 accepted, 0 rejected, -1 solve failed    */
+} gsx_lm_result;
+
+/* Symbolic-analysis and timing counters (gsx_get_stats). */
+typedef struct gsx_stats {
+  int64_t n_fronts;              /* Bayes-tree cliques                         */
+  int64_t n_levels;              /* height of the assembly tree                */
+  int64_t max_front_dim;         /* max frontal scalar dim                     */
+  int64_t max_front_rows;        /* max frontal + separator scalar dim         */
+  int64_t n_small_fronts;        /* fronts eliminated in LDS                   */
+  int64_t n_big_fronts;          /* fronts eliminated by the blocked path      */
+  double factor_flops;           /* sum f^3/3 + f^2 (s+1) + f (s+1)^2          */
+  double front_bytes;            /* sum 8 (f+s+1)^2                            */
+  double lpanel_bytes;           /* sum 8 f (f+s+1)  (back-substitution reads) */
+  double jacobian_bytes;         /* bytes of all [A b] blocks                  */
+  double hessian_bytes;          /* bytes of the block-sparse H panels         */
+  double total_dim;              /* scalar dimension of the system             */
+  /* accumulated device times (ms, HIP events on the handle's stream) and call
+   * counts since the last gsx_reset_stats, named like the reference's gttic
+   * labels (gtsam/base/timing.h) */
+  double ms_linearize, ms_assemble_hessian, ms_factorize, ms_backsolve,
+      ms_linear_error, ms_retract, ms_error;
+  int64_t n_linearize, n_factorize, n_backsolve, n_error;
+  int64_t n_cheirality;          /* SFM factors zeroed by cheirality in the last linearize */
+} gsx_stats;
+
+/* ---- lifecycle ------------------------------------------------------------ */
+gsx_status gsx_create(const gsx_problem_desc* desc, int32_t device, gsx_handle* out);
+gsx_status gsx_destroy(gsx_handle h);
+const char* gsx_last_error(gsx_handle h);          /* human-readable, may be "" */
+const char* gsx_version(void);
+int32_t gsx_device_count(void);                    /* 0 when no GPU is visible  */
+
+/* ---- ordering / symbolic analysis (host only; works without a GPU) -------- */
+gsx_status gsx_set_ordering(gsx_handle h, const uint64_t* keys, int32_t n);
+gsx_status gsx_compute_ordering(gsx_handle h, int32_t kind, uint64_t* keys_out);
+gsx_status gsx_get_ordering(gsx_handle h, uint64_t* keys_out);
+/* Bayes-tree structure for parity checks: per front the frontal / separator
+ * variable indices (CSR) and the parent front (-1 = root).  Pass NULL arrays to
+ * query sizes (*n_fronts, *n_sep_total = length of sep_vars). */
+gsx_status gsx_get_tree(gsx_handle h, int32_t* n_fronts, int64_t* n_sep_total, int32_t* parent,
+                        int32_t* frontal_ptr, int32_t* frontal_vars,
+                        int32_t* sep_ptr, int32_t* sep_vars);
+
+/* ---- state ----------------------------------------------------------------- */
+int64_t gsx_state_size(gsx_handle h);              /* doubles in packed Values  */
+int64_t gsx_tangent_size(gsx_handle h);            /* doubles in packed delta   */
+int64_t gsx_jacobian_size(gsx_handle h);           /* doubles in all [A b]      */
+gsx_status gsx_set_values(gsx_handle h, const double* packed, int64_t n);
+gsx_status gsx_get_values(gsx_handle h, double* packed, int64_t n);
+
+/* ---- the hot path, step by step -------------------------------------------- */
+gsx_status gsx_error(gsx_handle h, double* out);
+gsx_status gsx_linearize(gsx_handle h);
+/* [A b] of every factor, graph order, each dense column-major m x (sum d + 1) */
+gsx_status gsx_get_jacobians(gsx_handle h, double* out, int64_t n);
+gsx_status gsx_hessian_diagonal(gsx_handle h, double* out, int64_t n);
+/* Damped solve (J'J + lambda D) delta = J'b with D = I or clamp(diag J'J).
+ * delta_out may be NULL (delta stays on the device for gsx_retract).
+ * On GSX_E_INDETERMINATE *bad_key holds a frontal key of a failing clique. */
+gsx_status gsx_solve(gsx_handle h, double lambda, int32_t diagonal_damping,
+                     double min_diagonal, double max_diagonal, double* delta_out,
+                     int64_t n, uint64_t* bad_key);
+/* 0.5 * sum |A_i delta - b_i|^2 on the UNDAMPED linear graph, at 0 and at the
+ * delta of the last gsx_solve. */
+gsx_status gsx_linear_error(gsx_handle h, double* err_at_zero, double* err_at_delta);
+/* trial = values (+) delta (device delta of the last solve when delta==NULL);
+ * *trial_error (may be NULL) = graph error at trial; commit != 0 makes trial
+ * the current values. */
+gsx_status gsx_retract(gsx_handle h, const double* delta, int64_t n, int32_t commit,
+                       double* trial_error);
+
+/* ---- optimizers ------------------------------------------------------------- */
+void gsx_lm_params_legacy(gsx_lm_params* p);       /* SetLegacyDefaults          */
+void gsx_lm_params_ceres(gsx_lm_params* p);        /* SetCeresDefaults           */
+gsx_status gsx_lm_optimize(gsx_handle h, const gsx_lm_params* p, gsx_lm_result* r);
+/* one outer iteration (LevenbergMarquardtOptimizer::iterate); the LM state
+ * (lambda, factor, error) lives in the handle; reset by gsx_lm_reset. */
+gsx_status gsx_lm_reset(gsx_handle h, const gsx_lm_params* p);
+gsx_status gsx_lm_iterate(gsx_handle h, const gsx_lm_params* p, double* error,
+                          double* lambda);
+gsx_status gsx_gn_optimize(gsx_handle h, int32_t max_iterations, double relative_error_tol,
+                           double absolute_error_tol, double error_tol, gsx_lm_result* r);
+
+/* ---- the linear seam (NonlinearOptimizer::solve override) ------------------- */
+/* desc must contain only GSX_F_LINEAR factors and GSX_VAR_VECTOR variables;
+ * ordering may be NULL (own minimum degree).  delta_out in variable-index order. */
+gsx_status gsx_solve_gfg(const gsx_problem_desc* desc, const uint64_t* ordering,
+                         int32_t device, double* delta_out, int64_t n, uint64_t* bad_key);
+
+/* ---- dense kernel exposed for unit parity (gtsam/base/cholesky.cpp:108-159) -- */
+/* In-place partial Cholesky of an n x n column-major symmetric matrix (upper
+ * triangle significant, like the reference): on return the first nfrontal rows
+ * hold [R S], the trailing block holds C - S'S (upper).  *ok = 0 when the
+ * reference would have reported failure. */
+gsx_status gsx_cholesky_partial(double* abc, int32_t n, int32_t nfrontal, int32_t device,
+                                int32_t* ok);
+
+/* ---- multi-GPU (one process per GPU; the caller owns the collective) -------- */
+/* Restrict the handle to the factors owned by `rank` of `world` (factors are
+ * dealt by their first-eliminated variable's subtree).  Separator fronts are
+ * exposed as one contiguous FP64 device buffer that the caller all-reduces
+ * (RCCL via torch.distributed) between gsx_factorize_local and
+ * gsx_factorize_finish.  See DESIGN.md §multi-GPU. */
+gsx_status gsx_set_partition(gsx_handle h, int32_t rank, int32_t world);
+gsx_status gsx_partition_buffer(gsx_handle h, void** device_ptr, int64_t* n_doubles);
+gsx_status gsx_factorize_local(gsx_handle h, double lambda, int32_t diagonal_damping,
+                               double min_diagonal, double max_diagonal);
+gsx_status gsx_factorize_finish(gsx_handle h, double* delta_out, int64_t n, uint64_t* bad_key);
+
+/* ---- stats / stream ---------------------------------------------------------- */
+gsx_status gsx_get_stats(gsx_handle h, gsx_stats* out);
+gsx_status gsx_reset_stats(gsx_handle h);
+gsx_status gsx_synchronize(gsx_handle h);
+/* average duration (ms) of the named kernel class over launches since the last
+ * gsx_reset_stats, measured with HIP events on the handle's stream; names:
+ * "linearize", "assemble_hessian", "factor_small", "factor_big", "backsolve",
+ * "linear_error", "retract", "error". *launches (may be NULL) = count. */
+gsx_status gsx_kernel_time(gsx_handle h, const char* name, double* avg_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSX_H_ */

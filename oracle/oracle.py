@@ -1,0 +1,112 @@
+"""ctypes binding of oracle/liboracle.so (TEST INFRASTRUCTURE — see oracle/oracle.cpp).
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from gtsam_petercdev_amd import _abi as A
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+REF_COLAMD_PATH = os.path.join(_HERE, "_ref", "libccolamd_ref.so")
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = C.CDLL(LIB_PATH)
+    return _lib
+
+
+class OracleBackend(A.Backend):
+    def __init__(self, arrays: A.ProblemArrays, device: int = 0):
+        super().__init__(load(), "orc_", arrays, device)
+
+    def compute_ordering(self, kind):  # the oracle has no ordering code of its own
+        raise NotImplementedError("the oracle takes the ordering as an input")
+
+    def timing(self):
+        t = np.zeros(8)
+        tree = np.zeros(6)
+        self._fn("get_timing")(self._h, t.ctypes.data_as(C.POINTER(C.c_double)),
+                               tree.ctypes.data_as(C.POINTER(C.c_double)))
+        names = ["linearize", "damp", "eliminate", "backsub", "linear_error", "retract", "error", "symbolic"]
+        tn = ["flops", "bytes", "cliques", "depth", "max_f", "max_s"]
+        return dict(zip(names, t.tolist())), dict(zip(tn, tree.tolist()))
+
+    def reset_timing(self):
+        self._fn("reset_timing")(self._h)
+
+    def conditional(self, c):
+        nf, nc = C.c_int32(), C.c_int32()
+        self._check(self._fn("get_conditional")(self._h, C.c_int32(c), C.byref(nf), C.byref(nc), None), "get_conditional")
+        out = np.zeros(nf.value * nc.value)
+        self._fn("get_conditional")(self._h, C.c_int32(c), C.byref(nf), C.byref(nc),
+                                    out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out.reshape(nc.value, nf.value).T  # nf x ncols
+
+
+def oracle_backend(arrays: A.ProblemArrays, device: int = 0) -> OracleBackend:
+    return OracleBackend(arrays, device)
+
+
+def cholesky_partial(abc: np.ndarray, nfrontal: int):
+    """gtsam::choleskyPartial restatement on a (n,n) array (upper triangle significant)."""
+    n = abc.shape[0]
+    m = np.asfortranarray(abc, dtype=np.float64).copy(order="F")
+    ok = C.c_int32()
+    load().orc_cholesky_partial(m.ctypes.data_as(C.POINTER(C.c_double)), C.c_int32(n), C.c_int32(nfrontal),
+                                C.byref(ok))
+    return m, bool(ok.value)
+
+
+# ---- the reference's own CCOLAMD, compiled from its C sources (oracle/Makefile) ----------------
+def have_ref_colamd() -> bool:
+    return os.path.exists(REF_COLAMD_PATH)
+
+
+def colamd_ordering(arrays: A.ProblemArrays, cmember=None) -> np.ndarray:
+    """Ordering::Colamd / ColamdConstrained restated (gtsam/inference/Ordering.cpp:43-125):
+    columns = variables in ascending key order, rows = factor indices in graph order,
+    knobs dense_row = dense_col = -1, cmember all 0 unless given.  Calls the reference's
+    ccolamd() from oracle/_ref/libccolamd_ref.so.  Returns keys in elimination order."""
+    lib = C.CDLL(REF_COLAMD_PATH)
+    nvars, nfac = arrays.n_vars, arrays.n_factors
+    if nvars == 0:
+        return np.zeros(0, np.uint64)
+    if nvars == 1:
+        return arrays.var_keys.copy()
+    # VariableIndex: per variable the factor indices in graph order
+    fidx = np.repeat(np.arange(nfac, dtype=np.int32), np.diff(arrays.f_key_ptr))
+    order = np.lexsort((fidx, arrays.f_vars))  # stable by variable, then factor index
+    col_rows = fidx[order]
+    counts = np.bincount(arrays.f_vars, minlength=nvars)
+    p = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    nentries = int(col_rows.size)
+    lib.ccolamd_recommended.restype = C.c_size_t
+    alen = int(lib.ccolamd_recommended(C.c_int(nentries), C.c_int(nfac), C.c_int(nvars)))
+    Aarr = np.zeros(alen, np.int32)
+    Aarr[:nentries] = col_rows
+    knobs = (C.c_double * 20)()
+    lib.ccolamd_set_defaults(knobs)
+    knobs[0] = -1.0  # CCOLAMD_DENSE_ROW
+    knobs[1] = -1.0  # CCOLAMD_DENSE_COL
+    stats = (C.c_int * 20)()
+    cm = np.zeros(nvars, np.int32) if cmember is None else np.ascontiguousarray(cmember, dtype=np.int32)
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    rv = lib.ccolamd(C.c_int(nfac), C.c_int(nvars), C.c_int(alen), ip(Aarr), ip(p), knobs, stats, ip(cm))
+    if rv != 1:
+        raise RuntimeError(f"ccolamd failed with return value {rv}")
+    return arrays.var_keys[p[:nvars]]
