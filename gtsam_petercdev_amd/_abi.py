@@ -187,7 +187,7 @@ def _dptr(a):
 class Backend:
     """One solver handle.  `lib` is a ctypes CDLL, `prefix` is "gsx_" or "orc_"."""
 
-    def __init__(self, lib, prefix: str, arrays: ProblemArrays, device: int = 0):
+    def __init__(self, lib, prefix: str, arrays: ProblemArrays, device: int = 0, set_initial: bool = True):
         self._lib = lib
         self._pfx = prefix
         self.arrays = arrays
@@ -202,7 +202,7 @@ class Backend:
         self.state_size = int(self._fn("state_size", C.c_int64)(self._h))
         self.tangent_size = int(self._fn("tangent_size", C.c_int64)(self._h))
         self.jacobian_size = int(self._fn("jacobian_size", C.c_int64)(self._h))
-        if arrays.values is not None:
+        if set_initial and arrays.values is not None:
             self.set_values(arrays.values)
 
     def _fn(self, name, restype=C.c_int):

@@ -36,8 +36,10 @@ def version() -> str:
 
 
 class ProductBackend(A.Backend):
-    def __init__(self, arrays: A.ProblemArrays, device: int = 0):
-        super().__init__(load(), "gsx_", arrays, device)
+    def __init__(self, arrays: A.ProblemArrays, device: int = 0, host_only: bool = False):
+        """host_only=True skips the upload of the initial values: only the host-side entry points
+        (orderings, symbolic analysis, get_tree, stats) are usable — for tests without a GPU."""
+        super().__init__(load(), "gsx_", arrays, device, set_initial=not host_only)
 
     def stats(self) -> dict:
         s = A.Stats()

@@ -1,0 +1,48 @@
+"""Build csrc/libgsx.so with hipcc for gfx950 (in-tree, so the .so travels to the GPU box)."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(CSRC, "libgsx.so")
+SOURCES = ["problem.cpp", "ordering.cpp", "symbolic.cpp", "kernels.hip", "solver.hip"]
+HEADERS = ["gsx_internal.h", "kernels.h", "device_geometry.h", os.path.join("..", "..", "include", "gsx.h")]
+
+
+def _stale() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in SOURCES + HEADERS)
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    for s in SOURCES:
+        o = os.path.join(CSRC, os.path.splitext(s)[0] + ".o")
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+               "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value", "-c", os.path.join(CSRC, s), "-o", o]
+        if s.endswith(".cpp"):
+            cmd.insert(1, "-x")
+            cmd.insert(2, "c++")
+            cmd.remove("--offload-arch=gfx950")
+            cmd.remove("-munsafe-fp-atomics")
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        objs.append(o)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,72 @@
+// gsx_internal.h — host-side data structures of libgsx (product; never includes oracle/).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/gsx.h"
+
+namespace gsx {
+
+// Size classes of fronts: S* are eliminated inside LDS by one workgroup, BIG by the blocked
+// global-memory path.  n = frontal + separator + 1 (rhs) scalar rows.
+constexpr int kSmallMaxN = 140;     // 140^2 * 8 B = 156.8 KB <= 160 KB LDS
+constexpr int kTile = 32;           // tile edge of the blocked big-front path
+
+struct HostProblem {
+  int n_vars = 0, n_factors = 0;
+  std::vector<uint64_t> keys;
+  std::vector<int> types, dims, state_off, tan_off;
+  int64_t state_size = 0, tan_size = 0, jac_size = 0;
+  // factors (graph order)
+  std::vector<int> f_type, f_rows, f_key_ptr, f_vars, f_noise_kind;
+  std::vector<int64_t> f_meas_ptr, f_noise_ptr, f_jac_off;
+  std::vector<double> meas, noise;
+  std::vector<int> f_cols;           // sum d + 1
+};
+
+// Symbolic factorization for one ordering.
+struct Symbolic {
+  int n_fronts = 0;
+  std::vector<int> order;            // position -> var
+  std::vector<int> pos;              // var -> position
+  std::vector<int> front_of_var;     // var -> front in which it is frontal
+  std::vector<int> parent;           // front -> parent front (-1 root)
+  std::vector<int> fvar_ptr, fvars;  // CSR: front -> local variable list (frontals first, then separator by position)
+  std::vector<int> nfrontal_vars;    // front -> number of frontal variables
+  std::vector<int> F, S, N;          // frontal dim, separator dim, n = F+S+1
+  std::vector<int64_t> off;          // arena offset (doubles) of the n x n column-major front
+  std::vector<int> level;            // 0 = leaves
+  std::vector<int> child_ptr, children;  // CSR front -> children (in the reference's child order)
+  // scalar row maps
+  std::vector<int64_t> cmap_ptr;     // front -> offset in cmap of its (S+1) update-row -> parent-row map
+  std::vector<int> cmap;
+  std::vector<int64_t> gidx_ptr;     // front -> offset in gidx of its (F+S) row -> global tangent index map
+  std::vector<int> gidx;
+  // H panels (per variable, in elimination order of rows)
+  std::vector<int64_t> h_off;        // var -> offset of its panel in the H pool
+  std::vector<int> h_rows;           // var -> panel rows (d_A + sum later-neighbour dims + 1)
+  std::vector<int64_t> hmap_ptr;     // var -> offset in hmap of panel-row -> front-row map
+  std::vector<int> hmap;
+  std::vector<int> h_loc;            // var -> local scalar column offset of the variable in its front
+  int64_t h_size = 0, arena_size = 0;
+  // H assembly term lists: per variable, terms (one per (factor, destination block))
+  std::vector<int64_t> term_ptr;     // var -> range in the term arrays
+  std::vector<int64_t> t_jac;        // offset of the factor's [A b]
+  std::vector<int> t_m, t_colA, t_colB, t_dB, t_dst;
+  // schedule: fronts sorted by (level, class); per level the ranges of each class
+  std::vector<int> sched;            // front ids
+  std::vector<int> lvl_ptr;          // level -> range in sched (size n_levels+1)
+  std::vector<int> lvl_small_end;    // level -> end of the small (LDS) fronts inside the level range
+  int n_levels = 0;
+  // stats
+  double flops = 0, front_bytes = 0, lpanel_bytes = 0;
+  int64_t max_F = 0, max_rows = 0, n_small = 0, n_big = 0;
+};
+
+// host algorithms
+gsx_status lower_problem(const gsx_problem_desc* d, HostProblem& P, std::string& err);
+void compute_ordering(const HostProblem& P, int kind, std::vector<int>& order);
+gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order, Symbolic& S, std::string& err);
+
+}  // namespace gsx

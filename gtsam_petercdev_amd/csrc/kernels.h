@@ -1,0 +1,85 @@
+// kernels.h — device-side tables and the launch functions of kernels.hip (product; gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace gsx {
+
+typedef long long i64;
+
+// Immutable problem tables on the device (graph order).
+struct DevProblem {
+  int n_vars, n_factors;
+  const int *var_type, *var_dim, *var_state_off, *var_tan_off;
+  const int *f_type, *f_rows, *f_key_ptr, *f_vars, *f_noise_kind, *f_cols;
+  const i64 *f_meas_off, *f_noise_off, *f_jac_off;
+  const double *meas, *noise;
+};
+
+// Symbolic tables on the device.
+struct DevSymbolic {
+  int n_fronts;
+  // fronts
+  const i64* fr_off;            // arena offset
+  const int *fr_N, *fr_F, *fr_nfv, *fr_fvar_ptr, *fvars, *fr_parent, *fr_child_ptr, *children;
+  const i64 *cmap_ptr, *gidx_ptr;
+  const int *cmap, *gidx;
+  // H panels
+  const i64 *h_off, *hmap_ptr;
+  const int *h_rows, *hmap, *h_loc;
+  // H assembly terms
+  const i64 *term_ptr, *t_jac;
+  const int *t_m, *t_colA, *t_colB, *t_dB, *t_dst;
+};
+
+// status words written by the factorization / back-substitution kernels
+struct DevStatus {
+  int n_fail;        // fronts whose partial Cholesky failed (non-positive pivot or exponent-gap test)
+  int first_front;   // smallest failing front id (INT_MAX when none)
+  int n_nonfinite;   // non-finite entries met in back-substitution
+  int n_cheirality;  // SFM factors zeroed in the last linearize
+};
+
+// scalar slots in the device scalar buffer
+enum { SC_LAMBDA = 0, SC_ERR = 1, SC_LIN0 = 2, SC_LIND = 3, SC_TRIAL_ERR = 4, SC_COUNT = 8 };
+
+struct BigDesc {   // one big front of a level
+  i64 off;
+  int N, F, front, parent;   // parent front id (-1 root)
+};
+
+// ---- launches (all asynchronous on `st`) ---------------------------------------------------------
+void launch_linearize(const DevProblem& P, const int* const type_lists[6], const int type_counts[6],
+                      const double* values, double* jac, DevStatus* status, hipStream_t st);
+void launch_error(const DevProblem& P, const double* values, double* partials, int n_partials_cap,
+                  double* scalars, int slot, hipStream_t st);
+void launch_linear_error(const DevProblem& P, const double* jac, const double* delta, double* partials,
+                         int n_partials_cap, double* scalars, hipStream_t st);
+void launch_retract(const DevProblem& P, const double* values, const double* delta, double* out, hipStream_t st);
+void launch_assemble_h_group(const DevProblem& P, const DevSymbolic& S, const int* vars, int count, int threads,
+                             int lds_bytes, bool global, const double* jac, double* H, hipStream_t st);
+void launch_hessian_diag(const DevProblem& P, const DevSymbolic& S, const double* H, double* diag, hipStream_t st);
+void launch_make_damping(int n, const double* hdiag, int diagonal, double mind, double maxd, double* damp,
+                         hipStream_t st);
+// small fronts of one size class: ids[0..count), each eliminated by one workgroup of `threads`
+// threads with (max_n^2) doubles of LDS
+void launch_front_small(const DevProblem& P, const DevSymbolic& S, const int* ids, int count, int max_n,
+                        int threads, const double* H, const double* damp, const double* scalars, double* arena,
+                        DevStatus* status, hipStream_t st);
+void launch_big_init(const DevProblem& P, const DevSymbolic& S, const BigDesc* descs, int count, int max_n,
+                     int max_nfv, const double* H, const double* damp, const double* scalars, double* arena,
+                     hipStream_t st);
+void launch_big_step(const DevSymbolic& S, const BigDesc* descs, int count, int kb, int max_row_tiles,
+                     int max_pairs, double* arena, DevStatus* status, hipStream_t st);
+void launch_big_scatter(const DevSymbolic& S, const BigDesc* descs, int count, int max_s1, double* arena,
+                        hipStream_t st);
+void launch_backsolve(const DevSymbolic& S, const int* ids, int count, int threads, int max_n, const double* arena,
+                      double* delta, DevStatus* status, hipStream_t st);
+void launch_set_scalar(double* scalars, int slot, double v, hipStream_t st);
+// dense unit kernel for gsx_cholesky_partial: in-place lower partial Cholesky of an n x n
+// column-major matrix (lower triangle significant)
+void launch_dense_partial(double* a, int n, int nf, DevStatus* status, hipStream_t st);
+int max_dynamic_lds();
+
+}  // namespace gsx

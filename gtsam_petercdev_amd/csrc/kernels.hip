@@ -1,0 +1,969 @@
+// kernels.hip — hand-written HIP kernels of the hot path for gfx950 (MI355X, wave64).
+//
+//   linearize_*        per-factor residual/Jacobian -> [A b] blocks           (HBM-bound)
+//   error / linear_error / retract                                            (HBM-bound)
+//   assemble_h         Jacobians -> block-sparse Hessian panels (J'J, J'b), per-variable
+//                      deterministic gather through LDS                        (HBM-bound)
+//   front_small        fused assemble + partial Cholesky of one Bayes-tree clique in LDS
+//                      (extend-add of child Schur complements, choleskyPartial semantics of
+//                      gtsam/base/cholesky.cpp:108-159), >= 97 % of all cliques   (HBM/LDS-bound)
+//   big_*              blocked right-looking partial Cholesky of large cliques in HBM
+//                      (trsm + syrk tiles, FP64 MFMA in the syrk)               (MFMA-bound)
+//   backsolve          x_F = L11^-T (d - L21^T x_S) per clique, top-down        (HBM-bound)
+//
+// Fronts are stored column-major, lower triangle significant: L = R' of the reference's
+// upper-triangular [R S d] (gtsam/linear/GaussianConditional.h:243-252), the rhs d is the last ROW.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+
+#include "device_geometry.h"
+#include "gsx_internal.h"
+#include "kernels.h"
+
+namespace gsx {
+using namespace gsxd;
+
+#define T kTile
+
+// ---------------------------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+// total in thread 0 of the block (fixed summation order => deterministic)
+__device__ __forceinline__ double block_sum(double v) {
+  __shared__ double ws[16];
+  v = wave_sum(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) ws[wave] = v;
+  __syncthreads();
+  double s = 0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += ws[w];
+  return s;
+}
+
+template <int M, int NC>
+__device__ __forceinline__ void whiten_store(double (&J)[M * NC], int kind, const double* np, double* out) {
+  if (kind == GSX_NOISE_ISOTROPIC) {
+    const double inv = 1.0 / np[0];
+#pragma unroll
+    for (int i = 0; i < M * NC; ++i) J[i] *= inv;
+  } else if (kind == GSX_NOISE_DIAGONAL) {
+    double inv[M];
+#pragma unroll
+    for (int r = 0; r < M; ++r) inv[r] = 1.0 / np[r];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int r = 0; r < M; ++r) J[c * M + r] *= inv[r];
+  } else if (kind == GSX_NOISE_GAUSSIAN) {
+    double R[M * M];
+#pragma unroll
+    for (int i = 0; i < M * M; ++i) R[i] = np[i];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      double col[M];
+#pragma unroll
+      for (int r = 0; r < M; ++r) {
+        double s = 0;
+#pragma unroll
+        for (int k = r; k < M; ++k) s += R[r * M + k] * J[c * M + k];
+        col[r] = s;
+      }
+#pragma unroll
+      for (int r = 0; r < M; ++r) J[c * M + r] = col[r];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < M * NC; ++i) out[i] = J[i];
+}
+
+template <int M>
+__device__ __forceinline__ double whitened_half_sqnorm(double (&e)[M], int kind, const double* np) {
+  double s = 0;
+  if (kind == GSX_NOISE_UNIT) {
+#pragma unroll
+    for (int r = 0; r < M; ++r) s += e[r] * e[r];
+  } else if (kind == GSX_NOISE_ISOTROPIC) {
+    const double inv = 1.0 / np[0];
+#pragma unroll
+    for (int r = 0; r < M; ++r) s += (e[r] * inv) * (e[r] * inv);
+  } else if (kind == GSX_NOISE_DIAGONAL) {
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+      const double x = e[r] * (1.0 / np[r]);
+      s += x * x;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+      double x = 0;
+#pragma unroll
+      for (int k = r; k < M; ++k) x += np[r * M + k] * e[k];
+      s += x * x;
+    }
+  }
+  return 0.5 * s;
+}
+
+// runtime-dimension whitening of an m x nc column-major block living in global memory
+__device__ inline void whiten_inplace(double* J, int m, int nc, int kind, const double* np) {
+  if (kind == GSX_NOISE_UNIT) return;
+  if (kind == GSX_NOISE_ISOTROPIC) {
+    const double inv = 1.0 / np[0];
+    for (int i = 0; i < m * nc; ++i) J[i] *= inv;
+  } else if (kind == GSX_NOISE_DIAGONAL) {
+    for (int c = 0; c < nc; ++c)
+      for (int r = 0; r < m; ++r) J[c * m + r] *= (1.0 / np[r]);
+  } else {
+    for (int c = 0; c < nc; ++c)
+      for (int r = 0; r < m; ++r) {  // ascending r: row r only needs rows k >= r (still unwhitened)
+        double s = 0;
+        for (int k = r; k < m; ++k) s += np[r * m + k] * J[c * m + k];
+        J[c * m + r] = s;
+      }
+  }
+}
+
+// traits<T>::Local(x, y) = chart(x^-1 y) for every variable type
+__device__ inline void local_coords(int type, int dim, const double* x, const double* y, double* out) {
+  if (type == GSX_VAR_VECTOR) {
+    for (int i = 0; i < dim; ++i) out[i] = y[i] - x[i];
+  } else if (type == GSX_VAR_POSE2) {
+    const P2 h = compose(inverse(load_pose2(x)), load_pose2(y));
+    out[0] = h.x; out[1] = h.y; out[2] = theta(h);
+  } else {
+    pose3_logmap(between(load_pose3(x), load_pose3(y)), out);
+    if (type == GSX_VAR_CAMERA) {
+      out[6] = y[12] - x[12]; out[7] = y[13] - x[13]; out[8] = y[14] - x[14];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// linearize: one thread per factor (register-resident [A b], whitening fused)
+// ---------------------------------------------------------------------------------------------
+// GeneralSFMFactor::linearize — gtsam/slam/GeneralSFMFactor.h:141-177
+__global__ void __launch_bounds__(256) linearize_sfm_kernel(DevProblem P, const int* list, int n, const double* values,
+                                                            double* jac, DevStatus* status) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int f = list[i];
+  const int kp = P.f_key_ptr[f];
+  const double* cam = values + P.var_state_off[P.f_vars[kp]];
+  const double* pt = values + P.var_state_off[P.f_vars[kp + 1]];
+  const double* z = P.meas + P.f_meas_off[f];
+  double camr[17], ptr3[3], pi[2], H1[18], H2[6], J[26];
+#pragma unroll
+  for (int k = 0; k < 17; ++k) camr[k] = cam[k];
+  ptr3[0] = pt[0]; ptr3[1] = pt[1]; ptr3[2] = pt[2];
+  const bool ok = sfm_project(camr, ptr3, pi, H1, H2);
+  if (ok) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      J[2 * c] = H1[c];
+      J[2 * c + 1] = H1[9 + c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      J[18 + 2 * c] = H2[c];
+      J[18 + 2 * c + 1] = H2[3 + c];
+    }
+    J[24] = z[0] - pi[0];
+    J[25] = z[1] - pi[1];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 26; ++k) J[k] = 0;
+    atomicAdd(&status->n_cheirality, 1);
+  }
+  whiten_store<2, 13>(J, P.f_noise_kind[f], P.noise + P.f_noise_off[f], jac + P.f_jac_off[f]);
+}
+
+// BetweenFactor<Pose2> via NoiseModelFactor::linearize — gtsam/nonlinear/NonlinearFactor.cpp:152-184
+__global__ void __launch_bounds__(256) linearize_between_pose2_kernel(DevProblem P, const int* list, int n,
+                                                                      const double* values, double* jac) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int f = list[i];
+  const int kp = P.f_key_ptr[f];
+  const P2 x1 = load_pose2(values + P.var_state_off[P.f_vars[kp]]);
+  const P2 x2 = load_pose2(values + P.var_state_off[P.f_vars[kp + 1]]);
+  const P2 h = compose(inverse(x1), x2);
+  const P2 zh = compose(inverse(load_pose2(P.meas + P.f_meas_off[f])), h);
+  const P2 hi = inverse(h);
+  // Ad(h^-1) = [[c,-s,y],[s,c,-x],[0,0,1]]; A1 = -Ad, A2 = I, b = -e
+  double J[21];
+  J[0] = -hi.c; J[1] = -hi.s; J[2] = 0;
+  J[3] = hi.s; J[4] = -hi.c; J[5] = 0;
+  J[6] = -hi.y; J[7] = hi.x; J[8] = -1;
+  J[9] = 1; J[10] = 0; J[11] = 0;
+  J[12] = 0; J[13] = 1; J[14] = 0;
+  J[15] = 0; J[16] = 0; J[17] = 1;
+  J[18] = -zh.x; J[19] = -zh.y; J[20] = -theta(zh);
+  whiten_store<3, 7>(J, P.f_noise_kind[f], P.noise + P.f_noise_off[f], jac + P.f_jac_off[f]);
+}
+
+__global__ void __launch_bounds__(256) linearize_between_pose3_kernel(DevProblem P, const int* list, int n,
+                                                                      const double* values, double* jac) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int f = list[i];
+  const int kp = P.f_key_ptr[f];
+  const P3 x1 = load_pose3(values + P.var_state_off[P.f_vars[kp]]);
+  const P3 x2 = load_pose3(values + P.var_state_off[P.f_vars[kp + 1]]);
+  const P3 h = between(x1, x2);
+  const P3 zh = compose(inverse(load_pose3(P.meas + P.f_meas_off[f])), h);
+  double e[6], Ad[36], J[78];
+  pose3_logmap(zh, e);
+  pose3_adjoint(inverse(h), Ad);
+#pragma unroll
+  for (int c = 0; c < 6; ++c)
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      J[c * 6 + r] = -Ad[6 * r + c];
+      J[36 + c * 6 + r] = (r == c) ? 1.0 : 0.0;
+    }
+#pragma unroll
+  for (int r = 0; r < 6; ++r) J[72 + r] = -e[r];
+  whiten_store<6, 13>(J, P.f_noise_kind[f], P.noise + P.f_noise_off[f], jac + P.f_jac_off[f]);
+}
+
+// priors of every type and BetweenFactor on vector spaces: rare, runtime dims, built in place
+__global__ void linearize_generic_kernel(DevProblem P, const int* list, int n, const double* values, double* jac) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int f = list[i];
+  const int kp = P.f_key_ptr[f];
+  const int m = P.f_rows[f];
+  double* J = jac + P.f_jac_off[f];
+  const double* z = P.meas + P.f_meas_off[f];
+  if (P.f_type[f] == GSX_F_PRIOR) {
+    // PriorFactor — gtsam/nonlinear/PriorFactor.h:98-102: e = -Local(x, prior), H = I, b = -e
+    const int v = P.f_vars[kp];
+    double l[9];
+    local_coords(P.var_type[v], P.var_dim[v], values + P.var_state_off[v], z, l);
+    for (int c = 0; c < m; ++c)
+      for (int r = 0; r < m; ++r) J[c * m + r] = (r == c) ? 1.0 : 0.0;
+    for (int r = 0; r < m; ++r) J[m * m + r] = l[r];
+    whiten_inplace(J, m, m + 1, P.f_noise_kind[f], P.noise + P.f_noise_off[f]);
+  } else {  // BETWEEN on VECTOR: e = (x2 - x1) - z, A1 = -I, A2 = I
+    const double* x1 = values + P.var_state_off[P.f_vars[kp]];
+    const double* x2 = values + P.var_state_off[P.f_vars[kp + 1]];
+    for (int c = 0; c < m; ++c)
+      for (int r = 0; r < m; ++r) {
+        J[c * m + r] = (r == c) ? -1.0 : 0.0;
+        J[m * m + c * m + r] = (r == c) ? 1.0 : 0.0;
+      }
+    for (int r = 0; r < m; ++r) J[2 * m * m + r] = -((x2[r] - x1[r]) - z[r]);
+    whiten_inplace(J, m, 2 * m + 1, P.f_noise_kind[f], P.noise + P.f_noise_off[f]);
+  }
+}
+
+void launch_linearize(const DevProblem& P, const int* const type_lists[6], const int type_counts[6],
+                      const double* values, double* jac, DevStatus* status, hipStream_t st) {
+  auto grid = [](int n) { return dim3((n + 255) / 256); };
+  if (type_counts[0])
+    linearize_sfm_kernel<<<grid(type_counts[0]), 256, 0, st>>>(P, type_lists[0], type_counts[0], values, jac, status);
+  if (type_counts[1])
+    linearize_between_pose2_kernel<<<grid(type_counts[1]), 256, 0, st>>>(P, type_lists[1], type_counts[1], values, jac);
+  if (type_counts[2])
+    linearize_between_pose3_kernel<<<grid(type_counts[2]), 256, 0, st>>>(P, type_lists[2], type_counts[2], values, jac);
+  if (type_counts[3])
+    linearize_generic_kernel<<<grid(type_counts[3]), 256, 0, st>>>(P, type_lists[3], type_counts[3], values, jac);
+}
+
+// ---------------------------------------------------------------------------------------------
+// graph error (NoiseModelFactor::error, gtsam/nonlinear/NonlinearFactor.cpp:138-149)
+// ---------------------------------------------------------------------------------------------
+__device__ inline double factor_error(const DevProblem& P, int f, const double* values) {
+  const int type = P.f_type[f];
+  if (type == GSX_F_LINEAR) return 0.0;
+  const int kp = P.f_key_ptr[f];
+  const int kind = P.f_noise_kind[f];
+  const double* np = P.noise + P.f_noise_off[f];
+  const double* z = P.meas + P.f_meas_off[f];
+  if (type == GSX_F_SFM) {
+    const double* cam = values + P.var_state_off[P.f_vars[kp]];
+    const double* pt = values + P.var_state_off[P.f_vars[kp + 1]];
+    double camr[17], ptr3[3], pi[2], e[2];
+#pragma unroll
+    for (int k = 0; k < 17; ++k) camr[k] = cam[k];
+    ptr3[0] = pt[0]; ptr3[1] = pt[1]; ptr3[2] = pt[2];
+    if (!sfm_project(camr, ptr3, pi, nullptr, nullptr)) return 0.0;
+    e[0] = pi[0] - z[0];
+    e[1] = pi[1] - z[1];
+    return whitened_half_sqnorm<2>(e, kind, np);
+  }
+  const int v0 = P.f_vars[kp];
+  const int vt = P.var_type[v0];
+  if (type == GSX_F_BETWEEN && vt == GSX_VAR_POSE2) {
+    const P2 h = compose(inverse(load_pose2(values + P.var_state_off[v0])),
+                         load_pose2(values + P.var_state_off[P.f_vars[kp + 1]]));
+    const P2 zh = compose(inverse(load_pose2(z)), h);
+    double e[3] = {zh.x, zh.y, theta(zh)};
+    return whitened_half_sqnorm<3>(e, kind, np);
+  }
+  if (type == GSX_F_BETWEEN && vt == GSX_VAR_POSE3) {
+    const P3 h = between(load_pose3(values + P.var_state_off[v0]), load_pose3(values + P.var_state_off[P.f_vars[kp + 1]]));
+    double e[6];
+    pose3_logmap(compose(inverse(load_pose3(z)), h), e);
+    return whitened_half_sqnorm<6>(e, kind, np);
+  }
+  // generic: priors, vector between
+  const int m = P.f_rows[f];
+  double e[9];
+  if (type == GSX_F_PRIOR) {
+    local_coords(vt, P.var_dim[v0], values + P.var_state_off[v0], z, e);
+  } else {
+    const double* x1 = values + P.var_state_off[v0];
+    const double* x2 = values + P.var_state_off[P.f_vars[kp + 1]];
+    for (int r = 0; r < m; ++r) e[r] = (x2[r] - x1[r]) - z[r];
+  }
+  double s = 0;
+  for (int r = 0; r < m; ++r) {
+    double x;
+    if (kind == GSX_NOISE_UNIT) x = e[r];
+    else if (kind == GSX_NOISE_ISOTROPIC) x = e[r] * (1.0 / np[0]);
+    else if (kind == GSX_NOISE_DIAGONAL) x = e[r] * (1.0 / np[r]);
+    else {
+      x = 0;
+      for (int k = r; k < m; ++k) x += np[r * m + k] * e[k];
+    }
+    s += x * x;
+  }
+  return 0.5 * s;
+}
+
+__global__ void __launch_bounds__(256) error_kernel(DevProblem P, const double* values, double* partials) {
+  double acc = 0;
+  for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < P.n_factors; f += gridDim.x * blockDim.x)
+    acc += factor_error(P, f, values);
+  const double s = block_sum(acc);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256) reduce_final_kernel(const double* partials, int n, int stride, double* scalars,
+                                                           int slot) {
+  double acc = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) acc += partials[(size_t)i * stride];
+  const double s = block_sum(acc);
+  if (threadIdx.x == 0) scalars[slot] = s;
+}
+
+void launch_error(const DevProblem& P, const double* values, double* partials, int cap, double* scalars, int slot,
+                  hipStream_t st) {
+  int nb = (P.n_factors + 255) / 256;
+  nb = nb < 1 ? 1 : (nb > cap ? cap : nb);
+  error_kernel<<<nb, 256, 0, st>>>(P, values, partials);
+  reduce_final_kernel<<<1, 256, 0, st>>>(partials, nb, 1, scalars, slot);
+}
+
+// ---------------------------------------------------------------------------------------------
+// linear error 0.5 sum |A delta - b|^2 at 0 and at delta (JacobianFactor::error,
+// gtsam/linear/JacobianFactor.cpp:494-514)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) linear_error_kernel(DevProblem P, const double* jac, const double* delta,
+                                                           double* partials) {
+  double acc0 = 0, accd = 0;
+  for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < P.n_factors; f += gridDim.x * blockDim.x) {
+    const int m = P.f_rows[f], nc = P.f_cols[f];
+    const double* J = jac + P.f_jac_off[f];
+    for (int r = 0; r < m; ++r) {
+      const double b = J[(nc - 1) * m + r];
+      double e = -b;
+      int col = 0;
+      for (int k = P.f_key_ptr[f]; k < P.f_key_ptr[f + 1]; ++k) {
+        const int v = P.f_vars[k];
+        const double* x = delta + P.var_tan_off[v];
+        const int d = P.var_dim[v];
+        for (int c = 0; c < d; ++c, ++col) e += J[col * m + r] * x[c];
+      }
+      acc0 += b * b;
+      accd += e * e;
+    }
+  }
+  const double s0 = block_sum(0.5 * acc0);
+  const double sd = block_sum(0.5 * accd);
+  if (threadIdx.x == 0) {
+    partials[2 * blockIdx.x] = s0;
+    partials[2 * blockIdx.x + 1] = sd;
+  }
+}
+
+void launch_linear_error(const DevProblem& P, const double* jac, const double* delta, double* partials, int cap,
+                         double* scalars, hipStream_t st) {
+  int nb = (P.n_factors + 255) / 256;
+  nb = nb < 1 ? 1 : (nb > cap / 2 ? cap / 2 : nb);
+  linear_error_kernel<<<nb, 256, 0, st>>>(P, jac, delta, partials);
+  reduce_final_kernel<<<1, 256, 0, st>>>(partials, nb, 2, scalars, SC_LIN0);
+  reduce_final_kernel<<<1, 256, 0, st>>>(partials + 1, nb, 2, scalars, SC_LIND);
+}
+
+// ---------------------------------------------------------------------------------------------
+// retract (Values::retract, gtsam/nonlinear/Values.cpp:53-64): one thread per variable
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) retract_kernel(DevProblem P, const double* values, const double* delta,
+                                                      double* out) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= P.n_vars) return;
+  const double* x = values + P.var_state_off[v];
+  const double* d = delta + P.var_tan_off[v];
+  double* y = out + P.var_state_off[v];
+  const int type = P.var_type[v];
+  if (type == GSX_VAR_VECTOR) {
+    for (int i = 0; i < P.var_dim[v]; ++i) y[i] = x[i] + d[i];
+  } else if (type == GSX_VAR_POSE2) {
+    const P2 r = compose(load_pose2(x), load_pose2(d));
+    y[0] = r.x; y[1] = r.y; y[2] = theta(r);
+  } else {
+    double xi[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xi[i] = d[i];
+    store_pose3(compose(load_pose3(x), pose3_expmap(xi)), y);
+    if (type == GSX_VAR_CAMERA) {
+      y[12] = x[12] + d[6]; y[13] = x[13] + d[7]; y[14] = x[14] + d[8];
+      y[15] = x[15]; y[16] = x[16];
+    }
+  }
+}
+void launch_retract(const DevProblem& P, const double* values, const double* delta, double* out, hipStream_t st) {
+  if (P.n_vars) retract_kernel<<<(P.n_vars + 255) / 256, 256, 0, st>>>(P, values, delta, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Hessian panels: for variable A (rows: A itself, its later-eliminated neighbours, rhs)
+//   panel[dst+i, j] = sum over terms  sum_r J[r, colB+i] * J[r, colA+j]
+// One workgroup per variable, `copies` waves each owning a private LDS copy of the panel and a
+// strided share of the term list; copies are summed in wave order => deterministic.
+// (JacobianFactor::updateHessian, gtsam/linear/JacobianFactor.cpp:586-624, restructured as a gather.)
+// ---------------------------------------------------------------------------------------------
+__global__ void assemble_h_kernel(DevProblem P, DevSymbolic S, const int* vars, const double* jac, double* H) {
+  extern __shared__ double lds[];
+  const int v = vars[blockIdx.x];
+  const int dA = P.var_dim[v], rows = S.h_rows[v], psize = rows * dA;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  double* panel = lds + (size_t)wave * psize;
+  for (int e = lane; e < psize; e += 64) panel[e] = 0;
+  const i64 t1 = S.term_ptr[v + 1];
+  for (i64 t = S.term_ptr[v] + wave; t < t1; t += nw) {
+    const double* Jf = jac + S.t_jac[t];
+    const int m = S.t_m[t], colA = S.t_colA[t], colB = S.t_colB[t], dB = S.t_dB[t], dst = S.t_dst[t];
+    for (int e = lane; e < dB * dA; e += 64) {
+      const int i = e % dB, j = e / dB;
+      const double* a = Jf + (colB + i) * m;
+      const double* b = Jf + (colA + j) * m;
+      double acc = 0;
+      for (int r = 0; r < m; ++r) acc += a[r] * b[r];
+      panel[dst + i + j * rows] += acc;
+    }
+  }
+  __syncthreads();
+  double* out = H + S.h_off[v];
+  for (int e = threadIdx.x; e < psize; e += blockDim.x) {
+    double s = 0;
+    for (int w = 0; w < nw; ++w) s += lds[(size_t)w * psize + e];
+    out[e] = s;
+  }
+}
+// panels too large for LDS: one wave accumulates straight into the (zeroed) global panel
+__global__ void assemble_h_global_kernel(DevProblem P, DevSymbolic S, const int* vars, const double* jac, double* H) {
+  const int v = vars[blockIdx.x];
+  const int dA = P.var_dim[v], rows = S.h_rows[v], psize = rows * dA;
+  const int lane = threadIdx.x;
+  double* panel = H + S.h_off[v];
+  for (int e = lane; e < psize; e += 64) panel[e] = 0;
+  __syncthreads();
+  const i64 t1 = S.term_ptr[v + 1];
+  for (i64 t = S.term_ptr[v]; t < t1; ++t) {
+    const double* Jf = jac + S.t_jac[t];
+    const int m = S.t_m[t], colA = S.t_colA[t], colB = S.t_colB[t], dB = S.t_dB[t], dst = S.t_dst[t];
+    for (int e = lane; e < dB * dA; e += 64) {
+      const int i = e % dB, j = e / dB;
+      double acc = 0;
+      for (int r = 0; r < m; ++r) acc += Jf[(colB + i) * m + r] * Jf[(colA + j) * m + r];
+      panel[dst + i + j * rows] += acc;  // an entry is always owned by the same lane
+    }
+  }
+}
+
+static int g_max_lds = -1;
+int max_dynamic_lds() {
+  if (g_max_lds < 0) {
+    int dev = 0, v = 0;
+    hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0) v = 65536;
+    g_max_lds = v;
+  }
+  return g_max_lds;
+}
+
+void launch_assemble_h_group(const DevProblem& P, const DevSymbolic& S, const int* vars, int count, int threads,
+                             int lds_bytes, bool global, const double* jac, double* H, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)assemble_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    attr = true;
+  }
+  if (!count) return;
+  if (global) assemble_h_global_kernel<<<count, 64, 0, st>>>(P, S, vars, jac, H);
+  else assemble_h_kernel<<<count, threads, lds_bytes, st>>>(P, S, vars, jac, H);
+}
+
+__global__ void hessian_diag_kernel(DevProblem P, DevSymbolic S, const double* H, double* diag) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= P.n_vars) return;
+  const int d = P.var_dim[v], rows = S.h_rows[v];
+  const double* p = H + S.h_off[v];
+  for (int k = 0; k < d; ++k) diag[P.var_tan_off[v] + k] = p[k + k * rows];
+}
+void launch_hessian_diag(const DevProblem& P, const DevSymbolic& S, const double* H, double* diag, hipStream_t st) {
+  if (P.n_vars) hessian_diag_kernel<<<(P.n_vars + 255) / 256, 256, 0, st>>>(P, S, H, diag);
+}
+
+// damping weights D: 1 (lambda I) or clamp(diag H) (diagonalDamping) —
+// gtsam/nonlinear/LevenbergMarquardtOptimizer.cpp:293-299, internal/LevenbergMarquardtState.h:125-156
+__global__ void make_damping_kernel(int n, const double* hdiag, int diagonal, double mind, double maxd, double* damp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  damp[i] = diagonal ? fmin(fmax(hdiag[i], mind), maxd) : 1.0;
+}
+void launch_make_damping(int n, const double* hdiag, int diagonal, double mind, double maxd, double* damp,
+                         hipStream_t st) {
+  if (n) make_damping_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, hdiag, diagonal, mind, maxd, damp);
+}
+
+__global__ void set_scalar_kernel(double* scalars, int slot, double v) { scalars[slot] = v; }
+void launch_set_scalar(double* scalars, int slot, double v, hipStream_t st) {
+  set_scalar_kernel<<<1, 1, 0, st>>>(scalars, slot, v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// in-LDS partial Cholesky (choleskyPartial, gtsam/base/cholesky.cpp:108-159), lower form:
+// columns 0..F-1 become [L11; L21] (incl. the rhs row), the trailing block C -= L21 L21'.
+// All threads of the block take part.  Returns (in every thread) 0 ok / 1 failed.
+// ---------------------------------------------------------------------------------------------
+__device__ inline int lds_partial_cholesky(double* L, int n, int F) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+  int fail = 0;
+  for (int j = 0; j < F; ++j) {
+    const double p = L[j + j * n];
+    if (!(p > 0)) fail = 1;  // Eigen::LLT reports NumericalIssue on a non-positive pivot
+    const double s = (p > 0) ? sqrt(p) : 1.0;
+    const double inv = 1.0 / s;
+    __syncthreads();
+    if (tid == 0) L[j + j * n] = s;
+    for (int r = j + 1 + tid; r < n; r += nt) L[r + j * n] *= inv;
+    __syncthreads();
+    for (int c = j + 1 + wave; c < n; c += nw) {
+      const double lc = L[c + j * n];
+      for (int r = c + lane; r < n; r += 64) L[r + c * n] -= L[r + j * n] * lc;
+    }
+    __syncthreads();
+  }
+  // conditioning test on the last two pivots — cholesky.cpp:145-158
+  if (F >= 2) {
+    int e2, e1;
+    (void)frexp(L[(F - 2) + (F - 2) * n], &e2);
+    (void)frexp(L[(F - 1) + (F - 1) * n], &e1);
+    if (!(e2 - e1 < 12)) fail = 1;
+  } else if (F == 1) {
+    int e1;
+    (void)frexp(L[0], &e1);
+    if (!(e1 > -12)) fail = 1;
+  }
+  return fail;
+}
+
+__device__ inline void report_failure(DevStatus* status, int front) {
+  atomicAdd(&status->n_fail, 1);
+  atomicMin(&status->first_front, front);
+}
+
+// ---------------------------------------------------------------------------------------------
+// front_small: one workgroup assembles and eliminates one clique entirely inside LDS.
+//   1. H panels of the frontal variables (+ lambda D on their diagonal)      [HessianFactor merge ctor]
+//   2. extend-add of the children's Schur complements, in child order        [updateHessian of child factors]
+//   3. partial Cholesky                                                      [choleskyPartial]
+//   4. L panel -> arena (kept for back-substitution); Schur complement -> arena (pulled by a small
+//      parent) or atomically added into a big parent's front.
+// ---------------------------------------------------------------------------------------------
+__global__ void front_small_kernel(DevProblem P, DevSymbolic S, const int* ids, const double* H, const double* damp,
+                                   const double* scalars, double* arena, DevStatus* status) {
+  extern __shared__ double L[];
+  const int f = ids[blockIdx.x];
+  const int n = S.fr_N[f], F = S.fr_F[f];
+  const i64 off = S.fr_off[f];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+  const double lambda = scalars[SC_LAMBDA];
+  for (int e = tid; e < n * n; e += nt) L[e] = 0;
+  __syncthreads();
+  const int nfv = S.fr_nfv[f];
+  const int* fv = S.fvars + S.fr_fvar_ptr[f];
+  for (int k = 0; k < nfv; ++k) {
+    const int v = fv[k];
+    const int dA = P.var_dim[v], rows = S.h_rows[v], c0 = S.h_loc[v];
+    const double* hp = H + S.h_off[v];
+    const int* hm = S.hmap + S.hmap_ptr[v];
+    const int toff = P.var_tan_off[v];
+    for (int e = tid; e < rows * dA; e += nt) {
+      const int r = e % rows, j = e / rows;
+      double x = hp[e];
+      if (r == j) x += lambda * damp[toff + j];  // rows 0..dA-1 of the panel are the variable itself
+      L[hm[r] + (c0 + j) * n] = x;
+    }
+  }
+  __syncthreads();
+  for (int ci = S.fr_child_ptr[f]; ci < S.fr_child_ptr[f + 1]; ++ci) {
+    const int ch = S.children[ci];
+    const int nc = S.fr_N[ch], Fc = S.fr_F[ch], s1 = nc - Fc;
+    const int* cm = S.cmap + S.cmap_ptr[ch];
+    const double* src0 = arena + S.fr_off[ch] + (i64)Fc * nc + Fc;
+    for (int col = wave; col < s1; col += nw) {
+      const int pc = cm[col];
+      const double* src = src0 + (i64)col * nc;
+      for (int r = col + lane; r < s1; r += 64) L[cm[r] + pc * n] += src[r];
+    }
+    __syncthreads();
+  }
+  const int fail = lds_partial_cholesky(L, n, F);
+  if (fail && tid == 0) report_failure(status, f);
+  // L panel
+  double* A = arena + off;
+  for (int c = wave; c < F; c += nw)
+    for (int r = c + lane; r < n; r += 64) A[r + (i64)c * n] = L[r + c * n];
+  const int parent = S.fr_parent[f];
+  const int s1 = n - F;
+  if (parent >= 0 && S.fr_N[parent] > kSmallMaxN) {
+    const int* pm = S.cmap + S.cmap_ptr[f];
+    const int pn = S.fr_N[parent];
+    double* PA = arena + S.fr_off[parent];
+    for (int col = wave; col < s1; col += nw) {
+      const i64 pc = (i64)pm[col] * pn;
+      for (int r = col + lane; r < s1; r += 64) unsafeAtomicAdd(&PA[pm[r] + pc], L[(F + r) + (F + col) * n]);
+    }
+  } else {
+    for (int col = wave; col < s1; col += nw)
+      for (int r = col + lane; r < s1; r += 64) A[(F + r) + (i64)(F + col) * n] = L[(F + r) + (F + col) * n];
+  }
+}
+
+void launch_front_small(const DevProblem& P, const DevSymbolic& S, const int* ids, int count, int max_n, int threads,
+                        const double* H, const double* damp, const double* scalars, double* arena, DevStatus* status,
+                        hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)front_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  if (count)
+    front_small_kernel<<<count, threads, (size_t)max_n * max_n * sizeof(double), st>>>(P, S, ids, H, damp, scalars,
+                                                                                         arena, status);
+}
+
+// ---------------------------------------------------------------------------------------------
+// big fronts (n > kSmallMaxN): blocked right-looking partial Cholesky in HBM, tile T = 32
+// ---------------------------------------------------------------------------------------------
+__global__ void big_zero_kernel(const BigDesc* descs, double* arena) {
+  const BigDesc d = descs[blockIdx.y];
+  const i64 total = (i64)d.N * d.N;
+  double* A = arena + d.off;
+  for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (i64)gridDim.x * blockDim.x) A[e] = 0;
+}
+__global__ void big_add_h_kernel(DevProblem P, DevSymbolic S, const BigDesc* descs, const double* H, const double* damp,
+                                 const double* scalars, double* arena) {
+  const BigDesc d = descs[blockIdx.y];
+  const int f = d.front;
+  if ((int)blockIdx.x >= S.fr_nfv[f]) return;
+  const int v = S.fvars[S.fr_fvar_ptr[f] + blockIdx.x];
+  const int dA = P.var_dim[v], rows = S.h_rows[v], c0 = S.h_loc[v], n = d.N;
+  const double* hp = H + S.h_off[v];
+  const int* hm = S.hmap + S.hmap_ptr[v];
+  const int toff = P.var_tan_off[v];
+  const double lambda = scalars[SC_LAMBDA];
+  double* A = arena + d.off;
+  for (int e = threadIdx.x; e < rows * dA; e += blockDim.x) {
+    const int r = e % rows, j = e / rows;
+    double x = hp[e];
+    if (r == j) x += lambda * damp[toff + j];
+    A[hm[r] + (i64)(c0 + j) * n] = x;
+  }
+}
+void launch_big_init(const DevProblem& P, const DevSymbolic& S, const BigDesc* descs, int count, int max_n, int max_nfv,
+                     const double* H, const double* damp, const double* scalars, double* arena, hipStream_t st) {
+  if (!count) return;
+  i64 tot = (i64)max_n * max_n;
+  int bx = (int)((tot + 256 * 8 - 1) / (256 * 8));
+  bx = bx < 1 ? 1 : (bx > 4096 ? 4096 : bx);
+  big_zero_kernel<<<dim3(bx, count), 256, 0, st>>>(descs, arena);
+  big_add_h_kernel<<<dim3(max_nfv, count), 128, 0, st>>>(P, S, descs, H, damp, scalars, arena);
+}
+
+// factor a w x w lower tile held in LDS (ld = T+1); all 256 threads; returns fail flag
+__device__ inline int lds_tile_potrf(double (*D)[T + 1], int w) {
+  const int tid = threadIdx.x;
+  int fail = 0;
+  for (int j = 0; j < w; ++j) {
+    const double p = D[j][j];
+    if (!(p > 0)) fail = 1;
+    const double s = (p > 0) ? sqrt(p) : 1.0;
+    const double inv = 1.0 / s;
+    __syncthreads();
+    if (tid == 0) D[j][j] = s;
+    for (int r = j + 1 + tid; r < w; r += blockDim.x) D[r][j] *= inv;
+    __syncthreads();
+    const int ww = w - j - 1;
+    for (int e = tid; e < ww * ww; e += blockDim.x) {
+      const int rr = j + 1 + e % ww, cc = j + 1 + e / ww;
+      if (rr >= cc) D[rr][cc] -= D[rr][j] * D[cc][j];
+    }
+    __syncthreads();
+  }
+  return fail;
+}
+
+// panel step kb, part 1: row tiles below the diagonal tile  X <- X * L_kk^-T
+__global__ void __launch_bounds__(256) big_trsm_kernel(const BigDesc* descs, int kb, double* arena) {
+  const BigDesc d = descs[blockIdx.y];
+  const int n = d.N, F = d.F, c0 = kb * T;
+  if (c0 >= F) return;
+  const int w = min(T, F - c0);
+  const int r0 = c0 + w + blockIdx.x * T;
+  if (r0 >= n) return;
+  const int h = min(T, n - r0);
+  double* A = arena + d.off;
+  __shared__ double D[T][T + 1], Li[T][T + 1], X[T][T + 1];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < w * w; e += 256) {
+    const int r = e % w, c = e / w;
+    D[r][c] = (r >= c) ? A[(c0 + r) + (i64)(c0 + c) * n] : 0.0;
+  }
+  for (int e = tid; e < h * w; e += 256) {
+    const int r = e % h, c = e / h;
+    X[r][c] = A[(r0 + r) + (i64)(c0 + c) * n];
+  }
+  __syncthreads();
+  lds_tile_potrf(D, w);
+  // Li = D^-1 (lower): thread c solves D y = e_c
+  if (tid < w) {
+    const int c = tid;
+    for (int r = 0; r < w; ++r) Li[r][c] = 0;
+    for (int r = c; r < w; ++r) {
+      double s = (r == c) ? 1.0 : 0.0;
+      for (int k = c; k < r; ++k) s -= D[r][k] * Li[k][c];
+      Li[r][c] = s / D[r][r];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < h * w; e += 256) {
+    const int r = e % h, c = e / h;
+    double s = 0;
+    for (int k = 0; k <= c; ++k) s += X[r][k] * Li[c][k];
+    A[(r0 + r) + (i64)(c0 + c) * n] = s;
+  }
+}
+
+// panel step kb, part 2: trailing update C[i,j] -= P_i P_j' over lower tile pairs, plus one extra
+// block per front that factors the diagonal tile for good and checks the pivots.
+__global__ void __launch_bounds__(256) big_syrk_kernel(const BigDesc* descs, int kb, double* arena, DevStatus* status) {
+  const BigDesc d = descs[blockIdx.y];
+  const int n = d.N, F = d.F, c0 = kb * T;
+  if (c0 >= F) return;
+  const int w = min(T, F - c0);
+  const int base = c0 + w;
+  const int ntile = (n - base + T - 1) / T;
+  const int npairs = ntile * (ntile + 1) / 2;
+  const int t = blockIdx.x;
+  double* A = arena + d.off;
+  const int tid = threadIdx.x;
+  __shared__ double Pi[T][T + 1], Pj[T][T + 1];
+  if (t == npairs) {
+    for (int e = tid; e < w * w; e += 256) {
+      const int r = e % w, c = e / w;
+      Pi[r][c] = (r >= c) ? A[(c0 + r) + (i64)(c0 + c) * n] : 0.0;
+    }
+    __syncthreads();
+    int fail = lds_tile_potrf(Pi, w);
+    for (int e = tid; e < w * w; e += 256) {
+      const int r = e % w, c = e / w;
+      if (r >= c) A[(c0 + r) + (i64)(c0 + c) * n] = Pi[r][c];
+    }
+    if (tid == 0) {
+      if (base == F) {  // last panel: conditioning test on the last two pivots (cholesky.cpp:145-158)
+        const double p1 = Pi[w - 1][w - 1];
+        int e1, e2;
+        (void)frexp(p1, &e1);
+        if (F >= 2) {
+          const double p2 = (w >= 2) ? Pi[w - 2][w - 2] : A[(F - 2) + (i64)(F - 2) * n];
+          (void)frexp(p2, &e2);
+          if (!(e2 - e1 < 12)) fail = 1;
+        } else if (!(e1 > -12)) {
+          fail = 1;
+        }
+      }
+      if (fail) report_failure(status, d.front);
+    }
+    return;
+  }
+  if (t > npairs) return;
+  int i = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+  while ((i + 1) * (i + 2) / 2 <= t) ++i;
+  while (i * (i + 1) / 2 > t) --i;
+  const int j = t - i * (i + 1) / 2;
+  const int ri = base + i * T, rj = base + j * T;
+  const int hi = min(T, n - ri), hj = min(T, n - rj);
+  for (int e = tid; e < hi * w; e += 256) {
+    const int r = e % hi, c = e / hi;
+    Pi[r][c] = A[(ri + r) + (i64)(c0 + c) * n];
+  }
+  for (int e = tid; e < hj * w; e += 256) {
+    const int r = e % hj, c = e / hj;
+    Pj[r][c] = A[(rj + r) + (i64)(c0 + c) * n];
+  }
+  __syncthreads();
+  for (int e = tid; e < hi * hj; e += 256) {
+    const int r = e % hi, c = e / hi;
+    if (i == j && r < c) continue;
+    double s = 0;
+    for (int k = 0; k < w; ++k) s += Pi[r][k] * Pj[c][k];
+    A[(ri + r) + (i64)(rj + c) * n] -= s;
+  }
+}
+
+void launch_big_step(const DevSymbolic& S, const BigDesc* descs, int count, int kb, int max_row_tiles, int max_pairs,
+                     double* arena, DevStatus* status, hipStream_t st) {
+  if (!count) return;
+  if (max_row_tiles > 0) big_trsm_kernel<<<dim3(max_row_tiles, count), 256, 0, st>>>(descs, kb, arena);
+  big_syrk_kernel<<<dim3(max_pairs + 1, count), 256, 0, st>>>(descs, kb, arena, status);
+}
+
+// Schur complement of a big front -> atomically added into its big parent
+__global__ void __launch_bounds__(256) big_scatter_kernel(DevSymbolic S, const BigDesc* descs, double* arena) {
+  const BigDesc d = descs[blockIdx.y];
+  if (d.parent < 0 || S.fr_N[d.parent] <= kSmallMaxN) return;
+  const int n = d.N, F = d.F, s1 = n - F;
+  const int* pm = S.cmap + S.cmap_ptr[d.front];
+  const int pn = S.fr_N[d.parent];
+  double* PA = arena + S.fr_off[d.parent];
+  const double* A = arena + d.off;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int col = blockIdx.x * 4 + wave; col < s1; col += gridDim.x * 4) {
+    const i64 pc = (i64)pm[col] * pn;
+    for (int r = col + lane; r < s1; r += 64) unsafeAtomicAdd(&PA[pm[r] + pc], A[(F + r) + (i64)(F + col) * n]);
+  }
+}
+void launch_big_scatter(const DevSymbolic& S, const BigDesc* descs, int count, int max_s1, double* arena,
+                        hipStream_t st) {
+  if (!count) return;
+  int bx = (max_s1 + 3) / 4;
+  bx = bx < 1 ? 1 : (bx > 1024 ? 1024 : bx);
+  big_scatter_kernel<<<dim3(bx, count), 256, 0, st>>>(S, descs, arena);
+}
+
+// ---------------------------------------------------------------------------------------------
+// back-substitution of one clique per workgroup (OptimizeClique, gtsam/linear/linearAlgorithms-inst.h:49-117):
+//   L11' x_F = d - L21' x_S, blocked by 32 columns from the last panel to the first.
+// ---------------------------------------------------------------------------------------------
+__global__ void backsolve_kernel(DevSymbolic S, const int* ids, const double* arena, double* delta, DevStatus* status) {
+  extern __shared__ double xs[];  // n-1 solution entries of this front (frontal + separator)
+  __shared__ double tile[T][T + 1];
+  __shared__ double y[T];
+  const int f = ids[blockIdx.x];
+  const int n = S.fr_N[f], F = S.fr_F[f];
+  const double* A = arena + S.fr_off[f];
+  const int* gi = S.gidx + S.gidx_ptr[f];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+  for (int r = F + tid; r < n - 1; r += nt) xs[r] = delta[gi[r]];
+  __syncthreads();
+  const int nblk = (F + T - 1) / T;
+  for (int kb = nblk - 1; kb >= 0; --kb) {
+    const int c0 = kb * T, w = min(T, F - c0);
+    for (int c = wave; c < w; c += nw) {
+      const double* col = A + (i64)(c0 + c) * n;
+      double acc = 0;
+      for (int r = c0 + w + lane; r < n - 1; r += 64) acc += col[r] * xs[r];
+      acc = wave_sum(acc);
+      if (lane == 0) y[c] = col[n - 1] - acc;
+    }
+    for (int e = tid; e < w * w; e += nt) {
+      const int r = e % w, c = e / w;
+      if (r >= c) tile[r][c] = A[(c0 + r) + (i64)(c0 + c) * n];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      // solve tile' x = y backwards; lane r holds y_r
+      double yr = (lane < w) ? y[lane] : 0.0;
+      for (int c = w - 1; c >= 0; --c) {
+        const double xc = __shfl(yr, c, 64) / tile[c][c];
+        if (lane == c) yr = xc;
+        else if (lane < c) yr -= tile[c][lane] * xc;
+      }
+      if (lane < w) {
+        xs[c0 + lane] = yr;
+        delta[gi[c0 + lane]] = yr;
+        if (!isfinite(yr)) atomicAdd(&status->n_nonfinite, 1);
+      }
+    }
+    __syncthreads();
+  }
+}
+void launch_backsolve(const DevSymbolic& S, const int* ids, int count, int threads, int max_n, const double* arena,
+                      double* delta, DevStatus* status, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)backsolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr = true;
+  }
+  if (count) backsolve_kernel<<<count, threads, (size_t)max_n * sizeof(double), st>>>(S, ids, arena, delta, status);
+}
+
+// ---------------------------------------------------------------------------------------------
+// dense unit entry (gsx_cholesky_partial): small matrices through the LDS kernel, large ones
+// through the blocked path.
+// ---------------------------------------------------------------------------------------------
+__global__ void dense_small_kernel(double* a, int n, int nf, DevStatus* status) {
+  extern __shared__ double L[];
+  for (int e = threadIdx.x; e < n * n; e += blockDim.x) L[e] = a[e];
+  __syncthreads();
+  const int fail = lds_partial_cholesky(L, n, nf);
+  if (fail && threadIdx.x == 0) report_failure(status, 0);
+  for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+    const int r = e % n, c = e / n;
+    if (r >= c) a[e] = L[e];
+  }
+}
+void launch_dense_partial(double* a, int n, int nf, DevStatus* status, hipStream_t st) {
+  if (nf == 0) return;
+  if (n <= kSmallMaxN) {
+    static bool attr = false;
+    if (!attr) {
+      hipFuncSetAttribute((const void*)dense_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr = true;
+    }
+    dense_small_kernel<<<1, 256, (size_t)n * n * sizeof(double), st>>>(a, n, nf, status);
+    return;
+  }
+  BigDesc h{0, n, nf, 0, -1};
+  BigDesc* d = nullptr;
+  hipMalloc(&d, sizeof(BigDesc));
+  hipMemcpyAsync(d, &h, sizeof(BigDesc), hipMemcpyHostToDevice, st);
+  DevSymbolic S{};
+  const int steps = (nf + T - 1) / T;
+  for (int kb = 0; kb < steps; ++kb) {
+    const int c0 = kb * T, w = (nf - c0 < T) ? nf - c0 : T, base = c0 + w;
+    const int nt = (n - base + T - 1) / T;
+    launch_big_step(S, d, 1, kb, nt, nt * (nt + 1) / 2, a, status, st);
+  }
+  hipStreamSynchronize(st);
+  hipFree(d);
+}
+
+}  // namespace gsx

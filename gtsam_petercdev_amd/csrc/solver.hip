@@ -1,0 +1,1176 @@
+// solver.hip — handle, device memory, level-scheduled multifrontal driver, LM/GN policy and the
+// C-ABI of include/gsx.h.  Product code: no oracle, no CPU fallback — every numeric entry point
+// returns GSX_E_NO_DEVICE when there is no usable GPU.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "gsx_internal.h"
+#include "kernels.h"
+
+using namespace gsx;
+
+namespace {
+
+#define HIPCHK(ctx, expr)                                                                  \
+  do {                                                                                     \
+    hipError_t e__ = (expr);                                                               \
+    if (e__ != hipSuccess) {                                                               \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                     \
+      return GSX_E_NO_DEVICE;                                                              \
+    }                                                                                      \
+  } while (0)
+
+template <class Tp>
+struct DevBuf {
+  Tp* p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count) {
+    release();
+    n = count;
+    if (count == 0) return hipSuccess;
+    return hipMalloc((void**)&p, count * sizeof(Tp));
+  }
+  hipError_t upload(const std::vector<Tp>& v, hipStream_t st) {
+    hipError_t e = alloc(v.size() ? v.size() : 1);
+    if (e != hipSuccess) return e;
+    if (v.empty()) return hipSuccess;
+    return hipMemcpyAsync(p, v.data(), v.size() * sizeof(Tp), hipMemcpyHostToDevice, st);
+  }
+  void release() {
+    if (p) hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  ~DevBuf() { release(); }
+};
+
+struct SmallLaunch {
+  int begin, count, max_n, threads;
+};
+struct BigLevel {
+  int begin = 0, count = 0, steps = 0, max_s1 = 0;
+  std::vector<int> row_tiles, pairs;  // per kb
+};
+
+enum Phase { PH_LINEARIZE, PH_ASSEMBLE_H, PH_FACTORIZE, PH_BACKSOLVE, PH_LINERR, PH_RETRACT, PH_ERROR,
+             PH_FACTOR_SMALL, PH_FACTOR_BIG, PH_COUNT };
+const char* kPhaseNames[PH_COUNT] = {"linearize", "assemble_hessian", "factorize", "backsolve", "linear_error",
+                                     "retract", "error", "factor_small", "factor_big"};
+
+struct Timer {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, pool;
+  double ms = 0;
+  int64_t count = 0;
+};
+
+}  // namespace
+
+struct gsx_context {
+  std::string err;
+  int device = 0;
+  bool has_device = false;
+  hipStream_t stream = nullptr;
+  HostProblem P;
+  Symbolic S;
+  bool has_symbolic = false;
+  std::vector<int> order;
+
+  // device problem
+  DevBuf<int> d_var_type, d_var_dim, d_var_state_off, d_var_tan_off, d_f_type, d_f_rows, d_f_key_ptr, d_f_vars,
+      d_f_noise_kind, d_f_cols;
+  DevBuf<i64> d_f_meas_off, d_f_noise_off, d_f_jac_off;
+  DevBuf<double> d_meas, d_noise;
+  DevBuf<int> d_type_list[4];
+  int type_count[6] = {0, 0, 0, 0, 0, 0};
+  DevProblem DP{};
+  // device symbolic
+  DevBuf<i64> d_fr_off, d_cmap_ptr, d_gidx_ptr, d_h_off, d_hmap_ptr, d_term_ptr, d_t_jac;
+  DevBuf<int> d_fr_N, d_fr_F, d_fr_nfv, d_fr_fvar_ptr, d_fvars, d_fr_parent, d_fr_child_ptr, d_children, d_cmap,
+      d_gidx, d_h_rows, d_hmap, d_h_loc, d_t_m, d_t_colA, d_t_colB, d_t_dB, d_t_dst, d_sched, d_hvars;
+  DevBuf<BigDesc> d_big;
+  DevSymbolic DS{};
+  // schedule
+  std::vector<std::vector<SmallLaunch>> small_launch;  // per level
+  std::vector<BigLevel> big_level;
+  std::vector<BigDesc> big_descs;
+  int big_max_n = 0, big_max_nfv = 0;
+  struct HGroup {
+    int begin, count, threads, lds;
+    bool global;
+  };
+  std::vector<HGroup> hgroups;
+  // numeric buffers
+  DevBuf<double> d_values, d_trial, d_delta, d_udelta, d_jac, d_H, d_arena, d_hdiag, d_damp, d_partials, d_scalars;
+  DevBuf<DevStatus> d_status;
+  double* h_scalars = nullptr;  // pinned
+  DevStatus* h_status = nullptr;
+  static constexpr int kPartials = 4096;
+  bool values_set = false, linearized = false, h_ready = false, solved = false, damp_ready = false;
+  int damp_kind = -1;
+  double damp_min = 0, damp_max = 0;
+  // LM state
+  double lm_lambda = 0, lm_factor = 0, lm_error = 0;
+  int lm_iterations = 0, lm_inner = 0;
+  // stats
+  Timer timers[PH_COUNT];
+  int profiling = 0;
+  int64_t n_cheirality = 0;
+};
+
+namespace {
+
+void timer_begin(gsx_context* c, int ph) {
+  Timer& t = c->timers[ph];
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  if (!t.pool.empty()) {
+    ev = t.pool.back();
+    t.pool.pop_back();
+  } else {
+    hipEventCreate(&ev.first);
+    hipEventCreate(&ev.second);
+  }
+  hipEventRecord(ev.first, c->stream);
+  t.pending.push_back(ev);
+}
+void timer_end(gsx_context* c, int ph) { hipEventRecord(c->timers[ph].pending.back().second, c->stream); }
+void timers_resolve(gsx_context* c) {
+  hipStreamSynchronize(c->stream);
+  for (int ph = 0; ph < PH_COUNT; ++ph) {
+    Timer& t = c->timers[ph];
+    for (auto& ev : t.pending) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+        t.ms += ms;
+        t.count++;
+      }
+      t.pool.push_back(ev);
+    }
+    t.pending.clear();
+  }
+}
+
+gsx_status upload_problem(gsx_context* c) {
+  const HostProblem& P = c->P;
+  hipStream_t st = c->stream;
+  HIPCHK(c, c->d_var_type.upload(P.types, st));
+  HIPCHK(c, c->d_var_dim.upload(P.dims, st));
+  HIPCHK(c, c->d_var_state_off.upload(P.state_off, st));
+  HIPCHK(c, c->d_var_tan_off.upload(P.tan_off, st));
+  HIPCHK(c, c->d_f_type.upload(P.f_type, st));
+  HIPCHK(c, c->d_f_rows.upload(P.f_rows, st));
+  HIPCHK(c, c->d_f_key_ptr.upload(P.f_key_ptr, st));
+  HIPCHK(c, c->d_f_vars.upload(P.f_vars, st));
+  HIPCHK(c, c->d_f_noise_kind.upload(P.f_noise_kind, st));
+  HIPCHK(c, c->d_f_cols.upload(P.f_cols, st));
+  std::vector<i64> mo(P.f_meas_ptr.begin(), P.f_meas_ptr.end()), no(P.f_noise_ptr.begin(), P.f_noise_ptr.end()),
+      jo(P.f_jac_off.begin(), P.f_jac_off.end());
+  HIPCHK(c, c->d_f_meas_off.upload(mo, st));
+  HIPCHK(c, c->d_f_noise_off.upload(no, st));
+  HIPCHK(c, c->d_f_jac_off.upload(jo, st));
+  HIPCHK(c, c->d_meas.upload(P.meas, st));
+  HIPCHK(c, c->d_noise.upload(P.noise, st));
+  // factor type lists for the linearize kernels
+  std::vector<int> lists[4];
+  for (int f = 0; f < P.n_factors; ++f) {
+    const int t = P.f_type[f];
+    const int vt = P.types[P.f_vars[P.f_key_ptr[f]]];
+    if (t == GSX_F_SFM) lists[0].push_back(f);
+    else if (t == GSX_F_BETWEEN && vt == GSX_VAR_POSE2) lists[1].push_back(f);
+    else if (t == GSX_F_BETWEEN && vt == GSX_VAR_POSE3) lists[2].push_back(f);
+    else if (t != GSX_F_LINEAR) lists[3].push_back(f);
+  }
+  for (int k = 0; k < 4; ++k) {
+    c->type_count[k] = (int)lists[k].size();
+    HIPCHK(c, c->d_type_list[k].upload(lists[k], st));
+  }
+  HIPCHK(c, c->d_values.alloc(std::max<int64_t>(P.state_size, 1)));
+  HIPCHK(c, c->d_trial.alloc(std::max<int64_t>(P.state_size, 1)));
+  HIPCHK(c, c->d_delta.alloc(std::max<int64_t>(P.tan_size, 1)));
+  HIPCHK(c, c->d_udelta.alloc(std::max<int64_t>(P.tan_size, 1)));
+  HIPCHK(c, c->d_hdiag.alloc(std::max<int64_t>(P.tan_size, 1)));
+  HIPCHK(c, c->d_damp.alloc(std::max<int64_t>(P.tan_size, 1)));
+  HIPCHK(c, c->d_jac.alloc(std::max<int64_t>(P.jac_size, 1)));
+  HIPCHK(c, c->d_partials.alloc(gsx_context::kPartials));
+  HIPCHK(c, c->d_scalars.alloc(SC_COUNT));
+  HIPCHK(c, c->d_status.alloc(1));
+  HIPCHK(c, hipHostMalloc((void**)&c->h_scalars, SC_COUNT * sizeof(double)));
+  HIPCHK(c, hipHostMalloc((void**)&c->h_status, sizeof(DevStatus)));
+  HIPCHK(c, hipMemsetAsync(c->d_scalars.p, 0, SC_COUNT * sizeof(double), st));
+  HIPCHK(c, hipMemsetAsync(c->d_delta.p, 0, std::max<int64_t>(P.tan_size, 1) * sizeof(double), st));
+  // LINEAR factors: their (whitened) [A b] is static — written once
+  {
+    std::vector<double> jac;
+    bool any = false;
+    for (int f = 0; f < P.n_factors; ++f) any = any || P.f_type[f] == GSX_F_LINEAR;
+    if (any) {
+      jac.assign(P.jac_size, 0.0);
+      for (int f = 0; f < P.n_factors; ++f) {
+        if (P.f_type[f] != GSX_F_LINEAR) continue;
+        const int m = P.f_rows[f], nc = P.f_cols[f];
+        double* J = jac.data() + P.f_jac_off[f];
+        std::copy(P.meas.begin() + P.f_meas_ptr[f], P.meas.begin() + P.f_meas_ptr[f + 1], J);
+        const double* np = P.noise.data() + P.f_noise_ptr[f];
+        const int kind = P.f_noise_kind[f];
+        // folding a noise model into a GIVEN linear factor is data preparation (JacobianFactor::whiten,
+        // gtsam/linear/JacobianFactor.cpp), done once at creation
+        for (int cidx = 0; cidx < nc; ++cidx) {
+          if (kind == GSX_NOISE_ISOTROPIC)
+            for (int r = 0; r < m; ++r) J[cidx * m + r] *= 1.0 / np[0];
+          else if (kind == GSX_NOISE_DIAGONAL)
+            for (int r = 0; r < m; ++r) J[cidx * m + r] *= 1.0 / np[r];
+          else if (kind == GSX_NOISE_GAUSSIAN)
+            for (int r = 0; r < m; ++r) {
+              double s = 0;
+              for (int k = r; k < m; ++k) s += np[r * m + k] * J[cidx * m + k];
+              J[cidx * m + r] = s;
+            }
+        }
+      }
+      HIPCHK(c, hipMemcpyAsync(c->d_jac.p, jac.data(), jac.size() * sizeof(double), hipMemcpyHostToDevice, st));
+      HIPCHK(c, hipStreamSynchronize(st));
+    }
+  }
+  DevProblem& D = c->DP;
+  D.n_vars = P.n_vars;
+  D.n_factors = P.n_factors;
+  D.var_type = c->d_var_type.p; D.var_dim = c->d_var_dim.p;
+  D.var_state_off = c->d_var_state_off.p; D.var_tan_off = c->d_var_tan_off.p;
+  D.f_type = c->d_f_type.p; D.f_rows = c->d_f_rows.p; D.f_key_ptr = c->d_f_key_ptr.p; D.f_vars = c->d_f_vars.p;
+  D.f_noise_kind = c->d_f_noise_kind.p; D.f_cols = c->d_f_cols.p;
+  D.f_meas_off = c->d_f_meas_off.p; D.f_noise_off = c->d_f_noise_off.p; D.f_jac_off = c->d_f_jac_off.p;
+  D.meas = c->d_meas.p; D.noise = c->d_noise.p;
+  HIPCHK(c, hipStreamSynchronize(st));
+  return GSX_OK;
+}
+
+int small_threads_for(int n) {
+  if (n <= 48) return 64;
+  if (n <= 72) return 128;
+  if (n <= 100) return 256;
+  return 512;
+}
+
+// Build the launch plan (host) and upload the symbolic tables.
+gsx_status upload_symbolic(gsx_context* c) {
+  const Symbolic& S = c->S;
+  const HostProblem& P = c->P;
+  hipStream_t st = c->stream;
+  HIPCHK(c, c->d_fr_off.upload(std::vector<i64>(S.off.begin(), S.off.end()), st));
+  HIPCHK(c, c->d_fr_N.upload(S.N, st));
+  HIPCHK(c, c->d_fr_F.upload(S.F, st));
+  HIPCHK(c, c->d_fr_nfv.upload(S.nfrontal_vars, st));
+  HIPCHK(c, c->d_fr_fvar_ptr.upload(S.fvar_ptr, st));
+  HIPCHK(c, c->d_fvars.upload(S.fvars, st));
+  HIPCHK(c, c->d_fr_parent.upload(S.parent, st));
+  HIPCHK(c, c->d_fr_child_ptr.upload(S.child_ptr, st));
+  HIPCHK(c, c->d_children.upload(S.children, st));
+  HIPCHK(c, c->d_cmap_ptr.upload(std::vector<i64>(S.cmap_ptr.begin(), S.cmap_ptr.end()), st));
+  HIPCHK(c, c->d_gidx_ptr.upload(std::vector<i64>(S.gidx_ptr.begin(), S.gidx_ptr.end()), st));
+  HIPCHK(c, c->d_cmap.upload(S.cmap, st));
+  HIPCHK(c, c->d_gidx.upload(S.gidx, st));
+  HIPCHK(c, c->d_h_off.upload(std::vector<i64>(S.h_off.begin(), S.h_off.end()), st));
+  HIPCHK(c, c->d_hmap_ptr.upload(std::vector<i64>(S.hmap_ptr.begin(), S.hmap_ptr.end()), st));
+  HIPCHK(c, c->d_h_rows.upload(S.h_rows, st));
+  HIPCHK(c, c->d_hmap.upload(S.hmap, st));
+  HIPCHK(c, c->d_h_loc.upload(S.h_loc, st));
+  HIPCHK(c, c->d_term_ptr.upload(std::vector<i64>(S.term_ptr.begin(), S.term_ptr.end()), st));
+  HIPCHK(c, c->d_t_jac.upload(std::vector<i64>(S.t_jac.begin(), S.t_jac.end()), st));
+  HIPCHK(c, c->d_t_m.upload(S.t_m, st));
+  HIPCHK(c, c->d_t_colA.upload(S.t_colA, st));
+  HIPCHK(c, c->d_t_colB.upload(S.t_colB, st));
+  HIPCHK(c, c->d_t_dB.upload(S.t_dB, st));
+  HIPCHK(c, c->d_t_dst.upload(S.t_dst, st));
+  HIPCHK(c, c->d_sched.upload(S.sched, st));
+  HIPCHK(c, c->d_H.alloc(std::max<int64_t>(S.h_size, 1)));
+  HIPCHK(c, c->d_arena.alloc(std::max<int64_t>(S.arena_size, 1)));
+  // ---- H assembly groups: variables bucketed by panel size (LDS) and term count -----------------
+  {
+    struct VI {
+      int v, psize;
+      int64_t terms;
+    };
+    std::vector<VI> light, heavy, huge;
+    for (int v = 0; v < P.n_vars; ++v) {
+      const int psize = S.h_rows[v] * P.dims[v];
+      const int64_t terms = S.term_ptr[v + 1] - S.term_ptr[v];
+      if (terms >= 96 && (int64_t)psize * 4 * 8 <= 48 * 1024) heavy.push_back({v, psize, terms});
+      else if ((int64_t)psize * 8 <= 48 * 1024) light.push_back({v, psize, terms});
+      else huge.push_back({v, psize, terms});
+    }
+    auto by_psize = [](const VI& a, const VI& b) { return a.psize < b.psize; };
+    std::stable_sort(light.begin(), light.end(), by_psize);
+    std::stable_sort(heavy.begin(), heavy.end(), by_psize);
+    std::vector<int> hv;
+    c->hgroups.clear();
+    auto emit = [&](std::vector<VI>& L, int threads, int copies, bool global) {
+      size_t i = 0;
+      while (i < L.size()) {
+        // group = run whose largest panel is at most 2x (and at least 1 KB) of its smallest
+        size_t j = i;
+        const int lo = std::max(L[i].psize, 128);
+        while (j < L.size() && L[j].psize <= 2 * lo) ++j;
+        const int maxp = L[j - 1].psize;
+        c->hgroups.push_back({(int)hv.size(), (int)(j - i), threads, global ? 0 : maxp * copies * 8, global});
+        for (size_t k = i; k < j; ++k) hv.push_back(L[k].v);
+        i = j;
+      }
+    };
+    emit(light, 64, 1, false);
+    emit(heavy, 256, 4, false);
+    emit(huge, 64, 1, true);
+    HIPCHK(c, c->d_hvars.upload(hv, st));
+  }
+  // ---- factorization launch plan ---------------------------------------------------------------------
+  c->small_launch.assign(S.n_levels, {});
+  c->big_level.assign(S.n_levels, BigLevel());
+  c->big_descs.clear();
+  c->big_max_n = c->big_max_nfv = 0;
+  for (int l = 0; l < S.n_levels; ++l) {
+    int i = S.lvl_ptr[l];
+    const int se = S.lvl_small_end[l];
+    while (i < se) {
+      const int thr = small_threads_for(S.N[S.sched[i]]);
+      int j = i, maxn = 0;
+      // same thread class, and LDS footprint within 1.6x of the smallest member
+      const int n0 = std::max(S.N[S.sched[i]], 12);
+      while (j < se && small_threads_for(S.N[S.sched[j]]) == thr && S.N[S.sched[j]] * 10 <= n0 * 13) {
+        maxn = std::max(maxn, S.N[S.sched[j]]);
+        ++j;
+      }
+      c->small_launch[l].push_back({i, j - i, maxn, thr});
+      i = j;
+    }
+    BigLevel& B = c->big_level[l];
+    B.begin = (int)c->big_descs.size();
+    for (int k = se; k < S.lvl_ptr[l + 1]; ++k) {
+      const int f = S.sched[k];
+      c->big_descs.push_back(BigDesc{(i64)S.off[f], S.N[f], S.F[f], f, S.parent[f]});
+      B.steps = std::max(B.steps, (S.F[f] + kTile - 1) / kTile);
+      B.max_s1 = std::max(B.max_s1, S.N[f] - S.F[f]);
+      c->big_max_n = std::max(c->big_max_n, S.N[f]);
+      c->big_max_nfv = std::max(c->big_max_nfv, S.nfrontal_vars[f]);
+    }
+    B.count = (int)c->big_descs.size() - B.begin;
+    B.row_tiles.assign(B.steps, 0);
+    B.pairs.assign(B.steps, 0);
+    for (int k = B.begin; k < B.begin + B.count; ++k) {
+      const BigDesc& d = c->big_descs[k];
+      for (int kb = 0; kb * kTile < d.F; ++kb) {
+        const int c0 = kb * kTile, w = std::min(kTile, d.F - c0), base = c0 + w;
+        const int nt = (d.N - base + kTile - 1) / kTile;
+        B.row_tiles[kb] = std::max(B.row_tiles[kb], nt);
+        B.pairs[kb] = std::max(B.pairs[kb], nt * (nt + 1) / 2);
+      }
+    }
+  }
+  HIPCHK(c, c->d_big.upload(c->big_descs, st));
+  DevSymbolic& D = c->DS;
+  D.n_fronts = S.n_fronts;
+  D.fr_off = c->d_fr_off.p; D.fr_N = c->d_fr_N.p; D.fr_F = c->d_fr_F.p; D.fr_nfv = c->d_fr_nfv.p;
+  D.fr_fvar_ptr = c->d_fr_fvar_ptr.p; D.fvars = c->d_fvars.p; D.fr_parent = c->d_fr_parent.p;
+  D.fr_child_ptr = c->d_fr_child_ptr.p; D.children = c->d_children.p;
+  D.cmap_ptr = c->d_cmap_ptr.p; D.gidx_ptr = c->d_gidx_ptr.p; D.cmap = c->d_cmap.p; D.gidx = c->d_gidx.p;
+  D.h_off = c->d_h_off.p; D.hmap_ptr = c->d_hmap_ptr.p; D.h_rows = c->d_h_rows.p; D.hmap = c->d_hmap.p;
+  D.h_loc = c->d_h_loc.p;
+  D.term_ptr = c->d_term_ptr.p; D.t_jac = c->d_t_jac.p; D.t_m = c->d_t_m.p; D.t_colA = c->d_t_colA.p;
+  D.t_colB = c->d_t_colB.p; D.t_dB = c->d_t_dB.p; D.t_dst = c->d_t_dst.p;
+  HIPCHK(c, hipStreamSynchronize(st));
+  c->h_ready = false;
+  c->solved = false;
+  return GSX_OK;
+}
+
+// ---- device pipeline pieces (all asynchronous) -------------------------------------------------------
+void dev_linearize(gsx_context* c) {
+  timer_begin(c, PH_LINEARIZE);
+  hipMemsetAsync(&c->d_status.p->n_cheirality, 0, sizeof(int), c->stream);
+  const int* lists[6] = {c->d_type_list[0].p, c->d_type_list[1].p, c->d_type_list[2].p, c->d_type_list[3].p, nullptr,
+                         nullptr};
+  launch_linearize(c->DP, lists, c->type_count, c->d_values.p, c->d_jac.p, c->d_status.p, c->stream);
+  timer_end(c, PH_LINEARIZE);
+  c->linearized = true;
+  c->h_ready = false;
+  c->damp_ready = false;
+  c->solved = false;
+}
+
+void dev_assemble_h(gsx_context* c) {
+  timer_begin(c, PH_ASSEMBLE_H);
+  for (const auto& g : c->hgroups)
+    launch_assemble_h_group(c->DP, c->DS, c->d_hvars.p + g.begin, g.count, g.threads, g.lds, g.global, c->d_jac.p,
+                            c->d_H.p, c->stream);
+  launch_hessian_diag(c->DP, c->DS, c->d_H.p, c->d_hdiag.p, c->stream);
+  timer_end(c, PH_ASSEMBLE_H);
+  c->h_ready = true;
+}
+
+void dev_damping(gsx_context* c, int diagonal, double mind, double maxd) {
+  if (c->damp_ready && c->damp_kind == diagonal && c->damp_min == mind && c->damp_max == maxd) return;
+  launch_make_damping((int)c->P.tan_size, c->d_hdiag.p, diagonal, mind, maxd, c->d_damp.p, c->stream);
+  c->damp_ready = true;
+  c->damp_kind = diagonal;
+  c->damp_min = mind;
+  c->damp_max = maxd;
+}
+
+void dev_factorize(gsx_context* c, double lambda) {
+  const Symbolic& S = c->S;
+  timer_begin(c, PH_FACTORIZE);
+  launch_set_scalar(c->d_scalars.p, SC_LAMBDA, lambda, c->stream);
+  DevStatus init{0, INT_MAX, 0, 0};
+  // keep the cheirality count of the last linearize
+  hipMemsetAsync(&c->d_status.p->n_fail, 0, sizeof(int), c->stream);
+  hipMemcpyAsync(&c->d_status.p->first_front, &init.first_front, sizeof(int), hipMemcpyHostToDevice, c->stream);
+  hipMemsetAsync(&c->d_status.p->n_nonfinite, 0, sizeof(int), c->stream);
+  if (!c->big_descs.empty())
+    launch_big_init(c->DP, c->DS, c->d_big.p, (int)c->big_descs.size(), c->big_max_n, c->big_max_nfv, c->d_H.p,
+                    c->d_damp.p, c->d_scalars.p, c->d_arena.p, c->stream);
+  for (int l = 0; l < S.n_levels; ++l) {
+    for (const SmallLaunch& sl : c->small_launch[l]) {
+      if (c->profiling) timer_begin(c, PH_FACTOR_SMALL);
+      launch_front_small(c->DP, c->DS, c->d_sched.p + sl.begin, sl.count, sl.max_n, sl.threads, c->d_H.p, c->d_damp.p,
+                         c->d_scalars.p, c->d_arena.p, c->d_status.p, c->stream);
+      if (c->profiling) timer_end(c, PH_FACTOR_SMALL);
+    }
+    const BigLevel& B = c->big_level[l];
+    if (B.count) {
+      if (c->profiling) timer_begin(c, PH_FACTOR_BIG);
+      for (int kb = 0; kb < B.steps; ++kb)
+        launch_big_step(c->DS, c->d_big.p + B.begin, B.count, kb, B.row_tiles[kb], B.pairs[kb], c->d_arena.p,
+                        c->d_status.p, c->stream);
+      launch_big_scatter(c->DS, c->d_big.p + B.begin, B.count, B.max_s1, c->d_arena.p, c->stream);
+      if (c->profiling) timer_end(c, PH_FACTOR_BIG);
+    }
+  }
+  timer_end(c, PH_FACTORIZE);
+}
+
+void dev_backsolve(gsx_context* c) {
+  const Symbolic& S = c->S;
+  timer_begin(c, PH_BACKSOLVE);
+  for (int l = S.n_levels - 1; l >= 0; --l) {
+    const BigLevel& B = c->big_level[l];
+    const int se = S.lvl_small_end[l];
+    if (B.count) {
+      int maxn = 0;
+      for (int k = se; k < S.lvl_ptr[l + 1]; ++k) maxn = std::max(maxn, S.N[S.sched[k]]);
+      launch_backsolve(c->DS, c->d_sched.p + se, S.lvl_ptr[l + 1] - se, 1024, maxn, c->d_arena.p, c->d_delta.p,
+                       c->d_status.p, c->stream);
+    }
+    for (const SmallLaunch& sl : c->small_launch[l])
+      launch_backsolve(c->DS, c->d_sched.p + sl.begin, sl.count, sl.max_n <= 48 ? 64 : 256, sl.max_n, c->d_arena.p,
+                       c->d_delta.p, c->d_status.p, c->stream);
+  }
+  timer_end(c, PH_BACKSOLVE);
+}
+
+void dev_linear_error(gsx_context* c) {
+  timer_begin(c, PH_LINERR);
+  launch_linear_error(c->DP, c->d_jac.p, c->d_delta.p, c->d_partials.p, gsx_context::kPartials, c->d_scalars.p,
+                      c->stream);
+  timer_end(c, PH_LINERR);
+}
+void dev_retract(gsx_context* c, const double* d_delta) {
+  timer_begin(c, PH_RETRACT);
+  launch_retract(c->DP, c->d_values.p, d_delta, c->d_trial.p, c->stream);
+  timer_end(c, PH_RETRACT);
+}
+void dev_error(gsx_context* c, const double* d_vals, int slot) {
+  timer_begin(c, PH_ERROR);
+  launch_error(c->DP, d_vals, c->d_partials.p, gsx_context::kPartials, c->d_scalars.p, slot, c->stream);
+  timer_end(c, PH_ERROR);
+}
+gsx_status readback(gsx_context* c) {
+  HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_status.p, sizeof(DevStatus), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  c->n_cheirality = c->h_status->n_cheirality;
+  return GSX_OK;
+}
+
+uint64_t failing_key(gsx_context* c) {
+  const DevStatus& s = *c->h_status;
+  if (s.n_fail > 0 && s.first_front >= 0 && s.first_front < c->S.n_fronts)
+    return c->P.keys[c->S.fvars[c->S.fvar_ptr[s.first_front]]];
+  return c->P.n_vars ? c->P.keys[c->S.order.empty() ? 0 : c->S.order[0]] : 0;
+}
+
+gsx_status need_device(gsx_context* c) {
+  if (!c->has_device) {
+    c->err = "no usable gfx950 device (the hot path has no CPU fallback)";
+    return GSX_E_NO_DEVICE;
+  }
+  return GSX_OK;
+}
+
+// ---- LM policy (host scalars only) — LevenbergMarquardtOptimizer.cpp:121-308 ---------------------------
+struct Trace {
+  gsx_lm_result* r;
+  void push(double err, double lambda, int acc) {
+    if (!r) return;
+    if (r->trace_len < r->trace_cap) {
+      if (r->trace_error) r->trace_error[r->trace_len] = err;
+      if (r->trace_lambda) r->trace_lambda[r->trace_len] = lambda;
+      if (r->trace_accepted) r->trace_accepted[r->trace_len] = acc;
+    }
+    r->trace_len++;
+  }
+};
+
+gsx_status lm_try_lambda(gsx_context* c, const gsx_lm_params& p, Trace& tr, gsx_lm_result* res, bool* done) {
+  dev_damping(c, p.diagonal_damping, p.min_diagonal, p.max_diagonal);
+  dev_factorize(c, c->lm_lambda);
+  dev_backsolve(c);
+  dev_linear_error(c);
+  dev_retract(c, c->d_delta.p);
+  dev_error(c, c->d_trial.p, SC_TRIAL_ERR);
+  gsx_status st = readback(c);
+  if (st != GSX_OK) return st;
+  const bool systemSolvedSuccessfully = (c->h_status->n_fail == 0 && c->h_status->n_nonfinite == 0);
+  if (!systemSolvedSuccessfully && res) res->n_solve_failures++;
+  double modelFidelity = 0.0;
+  bool step_is_successful = false, stopSearchingLambda = false;
+  double newError = std::numeric_limits<double>::infinity();
+  double costChange = 0.0;
+  const double lambda_tried = c->lm_lambda;
+  if (systemSolvedSuccessfully) {
+    const double oldLinearizedError = c->h_scalars[SC_LIN0];
+    const double newlinearizedError = c->h_scalars[SC_LIND];
+    const double linearizedCostChange = oldLinearizedError - newlinearizedError;
+    if (linearizedCostChange >= 0) {
+      newError = c->h_scalars[SC_TRIAL_ERR];
+      costChange = c->lm_error - newError;
+      if (linearizedCostChange > std::numeric_limits<double>::epsilon() * oldLinearizedError) {
+        modelFidelity = costChange / linearizedCostChange;
+        step_is_successful = modelFidelity > p.min_model_fidelity;
+      }
+      const double minAbsoluteTolerance = p.relative_error_tol * c->lm_error;
+      if (std::abs(costChange) < minAbsoluteTolerance) stopSearchingLambda = true;
+    }
+  }
+  if (p.verbosity >= 1)
+    std::printf("%4d %12.6g %12.2e %10.2e %6d\n", c->lm_iterations, newError, costChange, c->lm_lambda,
+                (int)systemSolvedSuccessfully);
+  if (step_is_successful) {
+    double newLambda = c->lm_lambda, newFactor = c->lm_factor;
+    if (p.use_fixed_lambda_factor) {
+      newLambda /= c->lm_factor;
+    } else {
+      newLambda *= std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * modelFidelity - 1.0, 3));
+      newFactor = 2.0 * c->lm_factor;
+    }
+    newLambda = std::max(p.lambda_lower_bound, newLambda);
+    std::swap(c->d_values.p, c->d_trial.p);  // accept the trial values
+    c->linearized = false;
+    c->h_ready = false;
+    c->solved = false;
+    c->lm_error = newError;
+    c->lm_lambda = newLambda;
+    c->lm_factor = newFactor;
+    c->lm_iterations += 1;
+    c->lm_inner += 1;
+    tr.push(newError, lambda_tried, 1);
+    *done = true;
+  } else if (!stopSearchingLambda) {
+    c->lm_lambda *= c->lm_factor;
+    c->lm_inner += 1;
+    if (!p.use_fixed_lambda_factor) c->lm_factor *= 2.0;
+    tr.push(newError, lambda_tried, systemSolvedSuccessfully ? 0 : -1);
+    *done = (c->lm_lambda >= p.lambda_upper_bound);
+  } else {
+    tr.push(newError, lambda_tried, 0);
+    *done = true;
+  }
+  return GSX_OK;
+}
+
+gsx_status lm_iterate(gsx_context* c, const gsx_lm_params& p, Trace& tr, gsx_lm_result* res) {
+  dev_linearize(c);
+  dev_assemble_h(c);
+  bool done = false;
+  while (!done) {
+    gsx_status st = lm_try_lambda(c, p, tr, res, &done);
+    if (st != GSX_OK) return st;
+  }
+  return GSX_OK;
+}
+
+bool check_convergence(double relTol, double absTol, double errTol, double currentError, double newError) {
+  if (newError <= errTol) return true;
+  const double absoluteDecrease = currentError - newError;
+  const double relativeDecrease = absoluteDecrease / currentError;
+  return (relTol && (relativeDecrease <= relTol)) || (absoluteDecrease <= absTol);
+}
+
+gsx_status compute_error_sync(gsx_context* c, double* out) {
+  dev_error(c, c->d_values.p, SC_ERR);
+  gsx_status st = readback(c);
+  if (st != GSX_OK) return st;
+  *out = c->h_scalars[SC_ERR];
+  return GSX_OK;
+}
+
+gsx_status ensure_ready(gsx_context* c, bool need_values, bool need_symbolic) {
+  gsx_status st = need_device(c);
+  if (st != GSX_OK) return st;
+  if (need_values && !c->values_set && c->P.state_size > 0) {
+    c->err = "values not set";
+    return GSX_E_STATE;
+  }
+  if (need_symbolic && !c->has_symbolic) {
+    c->err = "ordering not set";
+    return GSX_E_STATE;
+  }
+  return GSX_OK;
+}
+
+}  // namespace
+
+// ==================================================================================================
+// C ABI
+// ==================================================================================================
+extern "C" {
+
+const char* gsx_version(void) { return "gsx 0.1.0 (gfx950)"; }
+
+int32_t gsx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+gsx_status gsx_create(const gsx_problem_desc* desc, int32_t device, gsx_handle* out) {
+  if (!out) return GSX_E_INVALID;
+  *out = nullptr;
+  gsx_context* c = new gsx_context();
+  gsx_status st = lower_problem(desc, c->P, c->err);
+  if (st != GSX_OK) {
+    std::fprintf(stderr, "gsx_create: %s\n", c->err.c_str());
+    delete c;
+    return st;
+  }
+  c->device = device;
+  int n = 0;
+  if (hipGetDeviceCount(&n) == hipSuccess && n > 0 && device >= 0 && device < n && hipSetDevice(device) == hipSuccess &&
+      hipStreamCreate(&c->stream) == hipSuccess) {
+    c->has_device = true;
+    st = upload_problem(c);
+    if (st != GSX_OK) {
+      std::fprintf(stderr, "gsx_create: %s\n", c->err.c_str());
+      delete c;
+      return st;
+    }
+  }
+  *out = c;
+  return GSX_OK;
+}
+
+gsx_status gsx_destroy(gsx_handle h) {
+  if (!h) return GSX_OK;
+  if (h->has_device) {
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    for (auto& t : h->timers) {
+      for (auto& ev : t.pending) t.pool.push_back(ev);
+      for (auto& ev : t.pool) {
+        hipEventDestroy(ev.first);
+        hipEventDestroy(ev.second);
+      }
+    }
+    if (h->h_scalars) hipHostFree(h->h_scalars);
+    if (h->h_status) hipHostFree(h->h_status);
+  }
+  hipStream_t st = h->stream;
+  const bool dev = h->has_device;
+  delete h;
+  if (dev && st) hipStreamDestroy(st);
+  return GSX_OK;
+}
+
+const char* gsx_last_error(gsx_handle h) { return h ? h->err.c_str() : ""; }
+
+gsx_status gsx_set_ordering(gsx_handle h, const uint64_t* keys, int32_t n) {
+  if (!h || (!keys && n > 0)) return GSX_E_INVALID;
+  if (n != h->P.n_vars) {
+    h->err = "ordering size differs from the number of variables";
+    return GSX_E_BAD_ORDERING;
+  }
+  std::map<uint64_t, int> idx;
+  for (int v = 0; v < h->P.n_vars; ++v) idx[h->P.keys[v]] = v;
+  std::vector<int> ord(n);
+  for (int i = 0; i < n; ++i) {
+    auto it = idx.find(keys[i]);
+    if (it == idx.end()) {
+      h->err = "ordering contains a key that is not a variable of the graph";
+      return GSX_E_BAD_ORDERING;
+    }
+    ord[i] = it->second;
+  }
+  gsx_status st = symbolic_analysis(h->P, ord, h->S, h->err);
+  if (st != GSX_OK) return st;
+  h->order = ord;
+  h->has_symbolic = true;
+  if (h->has_device) {
+    hipSetDevice(h->device);
+    st = upload_symbolic(h);
+    if (st != GSX_OK) return st;
+  }
+  return GSX_OK;
+}
+
+gsx_status gsx_compute_ordering(gsx_handle h, int32_t kind, uint64_t* keys_out) {
+  if (!h || !keys_out || kind < 0 || kind > 3) return GSX_E_INVALID;
+  std::vector<int> ord;
+  compute_ordering(h->P, kind, ord);
+  for (int i = 0; i < h->P.n_vars; ++i) keys_out[i] = h->P.keys[ord[i]];
+  return GSX_OK;
+}
+
+gsx_status gsx_get_ordering(gsx_handle h, uint64_t* keys_out) {
+  if (!h || !h->has_symbolic) return GSX_E_STATE;
+  for (int i = 0; i < h->P.n_vars; ++i) keys_out[i] = h->P.keys[h->order[i]];
+  return GSX_OK;
+}
+
+gsx_status gsx_get_tree(gsx_handle h, int32_t* n_fronts, int64_t* n_sep_total, int32_t* parent, int32_t* frontal_ptr,
+                        int32_t* frontal_vars, int32_t* sep_ptr, int32_t* sep_vars) {
+  if (!h || !h->has_symbolic) return GSX_E_STATE;
+  const Symbolic& S = h->S;
+  if (n_fronts) *n_fronts = S.n_fronts;
+  if (n_sep_total) *n_sep_total = (int64_t)S.fvars.size() - h->P.n_vars;
+  if (!parent) return GSX_OK;
+  int fp = 0, sp = 0;
+  for (int f = 0; f < S.n_fronts; ++f) {
+    parent[f] = S.parent[f];
+    frontal_ptr[f] = fp;
+    sep_ptr[f] = sp;
+    for (int k = S.fvar_ptr[f]; k < S.fvar_ptr[f + 1]; ++k) {
+      if (k - S.fvar_ptr[f] < S.nfrontal_vars[f]) frontal_vars[fp++] = S.fvars[k];
+      else sep_vars[sp++] = S.fvars[k];
+    }
+  }
+  frontal_ptr[S.n_fronts] = fp;
+  sep_ptr[S.n_fronts] = sp;
+  return GSX_OK;
+}
+
+int64_t gsx_state_size(gsx_handle h) { return h ? h->P.state_size : 0; }
+int64_t gsx_tangent_size(gsx_handle h) { return h ? h->P.tan_size : 0; }
+int64_t gsx_jacobian_size(gsx_handle h) { return h ? h->P.jac_size : 0; }
+
+gsx_status gsx_set_values(gsx_handle h, const double* packed, int64_t n) {
+  if (!h || n != h->P.state_size || (!packed && n > 0)) return GSX_E_INVALID;
+  gsx_status st = need_device(h);
+  if (st != GSX_OK) return st;
+  hipSetDevice(h->device);
+  if (n > 0) {
+    HIPCHK(h, hipMemcpyAsync(h->d_values.p, packed, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  h->values_set = true;
+  h->linearized = h->h_ready = h->solved = false;
+  return GSX_OK;
+}
+
+gsx_status gsx_get_values(gsx_handle h, double* packed, int64_t n) {
+  if (!h || n != h->P.state_size || (!packed && n > 0)) return GSX_E_INVALID;
+  gsx_status st = ensure_ready(h, true, false);
+  if (st != GSX_OK) return st;
+  hipSetDevice(h->device);
+  if (n > 0) {
+    HIPCHK(h, hipMemcpyAsync(packed, h->d_values.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  return GSX_OK;
+}
+
+gsx_status gsx_error(gsx_handle h, double* out) {
+  if (!h || !out) return GSX_E_INVALID;
+  gsx_status st = ensure_ready(h, true, false);
+  if (st != GSX_OK) return st;
+  hipSetDevice(h->device);
+  return compute_error_sync(h, out);
+}
+
+gsx_status gsx_linearize(gsx_handle h) {
+  if (!h) return GSX_E_INVALID;
+  gsx_status st = ensure_ready(h, true, false);
+  if (st != GSX_OK) return st;
+  hipSetDevice(h->device);
+  dev_linearize(h);
+  return readback(h);
+}
+
+gsx_status gsx_get_jacobians(gsx_handle h, double* out, int64_t n) {
+  if (!h || n != h->P.jac_size || (!out && n > 0)) return GSX_E_INVALID;
+  gsx_status st = ensure_ready(h, true, false);
+  if (st != GSX_OK) return st;
+  if (!h->linearized) {
+    h->err = "linearize first";
+    return GSX_E_STATE;
+  }
+  hipSetDevice(h->device);
+  if (n > 0) {
+    HIPCHK(h, hipMemcpyAsync(out, h->d_jac.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  return GSX_OK;
+}
+
+gsx_status gsx_hessian_diagonal(gsx_handle h, double* out, int64_t n) {
+  if (!h || n != h->P.tan_size || (!out && n > 0)) return GSX_E_INVALID;
+  gsx_status st = ensure_ready(h, true, true);
+  if (st != GSX_OK) return st;
+  if (!h->linearized) {
+    h->err = "linearize first";
+    return GSX_E_STATE;
+  }
+  hipSetDevice(h->device);
+  if (!h->h_ready) dev_assemble_h(h);
+  if (n > 0) {
+    HIPCHK(h, hipMemcpyAsync(out, h->d_hdiag.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  return GSX_OK;
+}
+
+gsx_status gsx_solve(gsx_handle h, double lambda, int32_t diagonal_damping, double min_diagonal, double max_diagonal,
+                     double* delta_out, int64_t n, uint64_t* bad_key) {
+  if (!h || (delta_out && n != h->P.tan_size)) return GSX_E_INVALID;
+  gsx_status st = ensure_ready(h, true, true);
+  if (st != GSX_OK) return st;
+  if (!h->linearized) {
+    h->err = "linearize first";
+    return GSX_E_STATE;
+  }
+  hipSetDevice(h->device);
+  if (!h->h_ready) dev_assemble_h(h);
+  dev_damping(h, diagonal_damping, min_diagonal, max_diagonal);
+  dev_factorize(h, lambda);
+  dev_backsolve(h);
+  st = readback(h);
+  if (st != GSX_OK) return st;
+  if (h->h_status->n_fail > 0 || h->h_status->n_nonfinite > 0) {
+    if (bad_key) *bad_key = failing_key(h);
+    h->solved = false;
+    h->err = "indeterminate linear system";
+    return GSX_E_INDETERMINATE;
+  }
+  h->solved = true;
+  if (delta_out && n > 0) {
+    HIPCHK(h, hipMemcpyAsync(delta_out, h->d_delta.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  return GSX_OK;
+}
+
+gsx_status gsx_linear_error(gsx_handle h, double* e0, double* ed) {
+  if (!h) return GSX_E_INVALID;
+  gsx_status st = ensure_ready(h, true, false);
+  if (st != GSX_OK) return st;
+  if (!h->linearized || (ed && !h->solved)) {
+    h->err = "linearize (and solve) first";
+    return GSX_E_STATE;
+  }
+  hipSetDevice(h->device);
+  dev_linear_error(h);
+  st = readback(h);
+  if (st != GSX_OK) return st;
+  if (e0) *e0 = h->h_scalars[SC_LIN0];
+  if (ed) *ed = h->h_scalars[SC_LIND];
+  return GSX_OK;
+}
+
+gsx_status gsx_retract(gsx_handle h, const double* delta, int64_t n, int32_t commit, double* trial_error) {
+  if (!h) return GSX_E_INVALID;
+  gsx_status st = ensure_ready(h, true, false);
+  if (st != GSX_OK) return st;
+  hipSetDevice(h->device);
+  const double* dd = h->d_delta.p;
+  if (delta) {
+    if (n != h->P.tan_size) return GSX_E_INVALID;
+    if (n > 0) HIPCHK(h, hipMemcpyAsync(h->d_udelta.p, delta, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    dd = h->d_udelta.p;
+  } else if (!h->solved) {
+    h->err = "no delta: solve first";
+    return GSX_E_STATE;
+  }
+  dev_retract(h, dd);
+  if (trial_error) dev_error(h, h->d_trial.p, SC_TRIAL_ERR);
+  st = readback(h);
+  if (st != GSX_OK) return st;
+  if (trial_error) *trial_error = h->h_scalars[SC_TRIAL_ERR];
+  if (commit) {
+    std::swap(h->d_values.p, h->d_trial.p);
+    h->linearized = h->h_ready = h->solved = false;
+  }
+  return GSX_OK;
+}
+
+void gsx_lm_params_legacy(gsx_lm_params* p) {
+  // LevenbergMarquardtParams::SetLegacyDefaults — LevenbergMarquardtParams.h:69-82
+  *p = gsx_lm_params{100, 1e-5, 1e-5, 0.0, 1e-5, 10.0, 1e5, 0.0, 1e-3, 0, 1, 1e-6, 1e32, 0};
+}
+void gsx_lm_params_ceres(gsx_lm_params* p) {
+  // LevenbergMarquardtParams::SetCeresDefaults — LevenbergMarquardtParams.h:85-98
+  *p = gsx_lm_params{50, 1e-6, 0.0, 0.0, 1e-4, 2.0, 1e32, 1e-16, 1e-3, 1, 0, 1e-6, 1e32, 0};
+}
+
+gsx_status gsx_lm_reset(gsx_handle h, const gsx_lm_params* p) {
+  if (!h || !p) return GSX_E_INVALID;
+  gsx_status st = ensure_ready(h, true, false);
+  if (st != GSX_OK) return st;
+  hipSetDevice(h->device);
+  st = compute_error_sync(h, &h->lm_error);
+  if (st != GSX_OK) return st;
+  h->lm_lambda = p->lambda_initial;
+  h->lm_factor = p->lambda_factor;
+  h->lm_iterations = 0;
+  h->lm_inner = 0;
+  return GSX_OK;
+}
+
+gsx_status gsx_lm_iterate(gsx_handle h, const gsx_lm_params* p, double* error, double* lambda) {
+  if (!h || !p) return GSX_E_INVALID;
+  gsx_status st = ensure_ready(h, true, true);
+  if (st != GSX_OK) return st;
+  hipSetDevice(h->device);
+  Trace tr{nullptr};
+  st = lm_iterate(h, *p, tr, nullptr);
+  if (st != GSX_OK) return st;
+  if (error) *error = h->lm_error;
+  if (lambda) *lambda = h->lm_lambda;
+  return GSX_OK;
+}
+
+// NonlinearOptimizer::defaultOptimize — gtsam/nonlinear/NonlinearOptimizer.cpp:62-117
+gsx_status gsx_lm_optimize(gsx_handle h, const gsx_lm_params* p, gsx_lm_result* r) {
+  if (!h || !p) return GSX_E_INVALID;
+  gsx_status st = ensure_ready(h, true, true);
+  if (st != GSX_OK) return st;
+  st = gsx_lm_reset(h, p);
+  if (st != GSX_OK) return st;
+  Trace tr{r};
+  if (r) {
+    r->initial_error = h->lm_error;
+    r->trace_len = 0;
+    r->n_solve_failures = 0;
+  }
+  double currentError = h->lm_error;
+  if (!(currentError <= p->error_tol) && !(h->lm_iterations >= p->max_iterations)) {
+    double newError = currentError;
+    do {
+      currentError = newError;
+      st = lm_iterate(h, *p, tr, r);
+      if (st != GSX_OK) return st;
+      newError = h->lm_error;
+    } while (h->lm_iterations < p->max_iterations &&
+             !check_convergence(p->relative_error_tol, p->absolute_error_tol, p->error_tol, currentError, newError) &&
+             std::isfinite(currentError));
+  }
+  if (r) {
+    r->final_error = h->lm_error;
+    r->final_lambda = h->lm_lambda;
+    r->iterations = h->lm_iterations;
+    r->inner_iterations = h->lm_inner;
+  }
+  return GSX_OK;
+}
+
+// GaussNewtonOptimizer::iterate — gtsam/nonlinear/GaussNewtonOptimizer.cpp:44-66
+gsx_status gsx_gn_optimize(gsx_handle h, int32_t max_iterations, double relTol, double absTol, double errTol,
+                           gsx_lm_result* r) {
+  if (!h) return GSX_E_INVALID;
+  gsx_status st = ensure_ready(h, true, true);
+  if (st != GSX_OK) return st;
+  hipSetDevice(h->device);
+  st = compute_error_sync(h, &h->lm_error);
+  if (st != GSX_OK) return st;
+  h->lm_iterations = 0;
+  Trace tr{r};
+  if (r) {
+    r->initial_error = h->lm_error;
+    r->trace_len = 0;
+    r->n_solve_failures = 0;
+  }
+  double currentError = h->lm_error;
+  if (!(currentError <= errTol) && max_iterations > 0) {
+    double newError = currentError;
+    do {
+      currentError = newError;
+      dev_linearize(h);
+      dev_assemble_h(h);
+      dev_damping(h, 0, 0, 0);
+      dev_factorize(h, 0.0);
+      dev_backsolve(h);
+      dev_retract(h, h->d_delta.p);
+      dev_error(h, h->d_trial.p, SC_TRIAL_ERR);
+      st = readback(h);
+      if (st != GSX_OK) return st;
+      if (h->h_status->n_fail > 0 || h->h_status->n_nonfinite > 0) {
+        h->err = "indeterminate linear system";
+        return GSX_E_INDETERMINATE;
+      }
+      std::swap(h->d_values.p, h->d_trial.p);
+      h->linearized = h->h_ready = h->solved = false;
+      h->lm_error = h->h_scalars[SC_TRIAL_ERR];
+      h->lm_iterations++;
+      newError = h->lm_error;
+      tr.push(newError, 0.0, 1);
+    } while (h->lm_iterations < max_iterations && !check_convergence(relTol, absTol, errTol, currentError, newError) &&
+             std::isfinite(currentError));
+  }
+  if (r) {
+    r->final_error = h->lm_error;
+    r->final_lambda = 0;
+    r->iterations = h->lm_iterations;
+    r->inner_iterations = h->lm_iterations;
+  }
+  return GSX_OK;
+}
+
+gsx_status gsx_solve_gfg(const gsx_problem_desc* desc, const uint64_t* ordering, int32_t device, double* delta_out,
+                         int64_t n, uint64_t* bad_key) {
+  if (!desc || !delta_out) return GSX_E_INVALID;
+  for (int f = 0; f < desc->n_factors; ++f)
+    if (desc->f_type[f] != GSX_F_LINEAR) return GSX_E_INVALID;
+  gsx_handle h = nullptr;
+  gsx_status st = gsx_create(desc, device, &h);
+  if (st != GSX_OK) return st;
+  std::vector<uint64_t> ord(desc->n_vars);
+  if (ordering) std::copy(ordering, ordering + desc->n_vars, ord.begin());
+  else st = gsx_compute_ordering(h, GSX_ORDER_MINDEGREE, ord.data());
+  if (st == GSX_OK) st = gsx_set_ordering(h, ord.data(), desc->n_vars);
+  std::vector<double> zeros(h->P.state_size, 0.0);
+  if (st == GSX_OK) st = gsx_set_values(h, zeros.data(), h->P.state_size);
+  if (st == GSX_OK) st = gsx_linearize(h);
+  if (st == GSX_OK) st = gsx_solve(h, 0.0, 0, 0, 0, delta_out, n, bad_key);
+  gsx_destroy(h);
+  return st;
+}
+
+gsx_status gsx_cholesky_partial(double* abc, int32_t n, int32_t nfrontal, int32_t device, int32_t* ok) {
+  if (!abc || n <= 0 || nfrontal < 0 || nfrontal > n || !ok) return GSX_E_INVALID;
+  int nd = 0;
+  if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0 || device >= nd || hipSetDevice(device) != hipSuccess)
+    return GSX_E_NO_DEVICE;
+  *ok = 1;
+  if (nfrontal == 0) return GSX_OK;
+  // lower (ours) = transpose of upper (reference)
+  std::vector<double> a((size_t)n * n);
+  for (int c = 0; c < n; ++c)
+    for (int r = 0; r < n; ++r) a[(size_t)c * n + r] = (r >= c) ? abc[(size_t)r * n + c] : 0.0;
+  double* d = nullptr;
+  DevStatus* ds = nullptr;
+  hipStream_t st;
+  if (hipStreamCreate(&st) != hipSuccess) return GSX_E_NO_DEVICE;
+  if (hipMalloc((void**)&d, a.size() * sizeof(double)) != hipSuccess) return GSX_E_NOMEM;
+  hipMalloc((void**)&ds, sizeof(DevStatus));
+  DevStatus init{0, INT_MAX, 0, 0};
+  hipMemcpyAsync(ds, &init, sizeof(init), hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(d, a.data(), a.size() * sizeof(double), hipMemcpyHostToDevice, st);
+  launch_dense_partial(d, n, nfrontal, ds, st);
+  hipMemcpyAsync(a.data(), d, a.size() * sizeof(double), hipMemcpyDeviceToHost, st);
+  hipMemcpyAsync(&init, ds, sizeof(init), hipMemcpyDeviceToHost, st);
+  hipError_t e = hipStreamSynchronize(st);
+  hipFree(d);
+  hipFree(ds);
+  hipStreamDestroy(st);
+  if (e != hipSuccess) return GSX_E_NO_DEVICE;
+  *ok = init.n_fail == 0 ? 1 : 0;
+  for (int c = 0; c < n; ++c)
+    for (int r = 0; r <= c; ++r) abc[(size_t)c * n + r] = a[(size_t)r * n + c];
+  return GSX_OK;
+}
+
+gsx_status gsx_get_stats(gsx_handle h, gsx_stats* out) {
+  if (!h || !out) return GSX_E_INVALID;
+  std::memset(out, 0, sizeof(*out));
+  if (h->has_symbolic) {
+    const Symbolic& S = h->S;
+    out->n_fronts = S.n_fronts;
+    out->n_levels = S.n_levels;
+    out->max_front_dim = S.max_F;
+    out->max_front_rows = S.max_rows;
+    out->n_small_fronts = S.n_small;
+    out->n_big_fronts = S.n_big;
+    out->factor_flops = S.flops;
+    out->front_bytes = S.front_bytes;
+    out->lpanel_bytes = S.lpanel_bytes;
+    out->hessian_bytes = 8.0 * (double)S.h_size;
+  }
+  out->jacobian_bytes = 8.0 * (double)h->P.jac_size;
+  out->total_dim = (double)h->P.tan_size;
+  if (h->has_device) {
+    hipSetDevice(h->device);
+    timers_resolve(h);
+  }
+  out->ms_linearize = h->timers[PH_LINEARIZE].ms;
+  out->ms_assemble_hessian = h->timers[PH_ASSEMBLE_H].ms;
+  out->ms_factorize = h->timers[PH_FACTORIZE].ms;
+  out->ms_backsolve = h->timers[PH_BACKSOLVE].ms;
+  out->ms_linear_error = h->timers[PH_LINERR].ms;
+  out->ms_retract = h->timers[PH_RETRACT].ms;
+  out->ms_error = h->timers[PH_ERROR].ms;
+  out->n_linearize = h->timers[PH_LINEARIZE].count;
+  out->n_factorize = h->timers[PH_FACTORIZE].count;
+  out->n_backsolve = h->timers[PH_BACKSOLVE].count;
+  out->n_error = h->timers[PH_ERROR].count;
+  out->n_cheirality = h->n_cheirality;
+  return GSX_OK;
+}
+
+gsx_status gsx_reset_stats(gsx_handle h) {
+  if (!h) return GSX_E_INVALID;
+  if (h->has_device) {
+    hipSetDevice(h->device);
+    timers_resolve(h);
+  }
+  for (auto& t : h->timers) {
+    t.ms = 0;
+    t.count = 0;
+  }
+  return GSX_OK;
+}
+
+gsx_status gsx_synchronize(gsx_handle h) {
+  if (!h) return GSX_E_INVALID;
+  gsx_status st = need_device(h);
+  if (st != GSX_OK) return st;
+  hipSetDevice(h->device);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return GSX_OK;
+}
+
+gsx_status gsx_set_profiling(gsx_handle h, int32_t level) {
+  if (!h) return GSX_E_INVALID;
+  h->profiling = level;
+  return GSX_OK;
+}
+
+gsx_status gsx_kernel_time(gsx_handle h, const char* name, double* avg_ms, int64_t* launches) {
+  if (!h || !name || !avg_ms) return GSX_E_INVALID;
+  if (h->has_device) {
+    hipSetDevice(h->device);
+    timers_resolve(h);
+  }
+  for (int ph = 0; ph < PH_COUNT; ++ph)
+    if (std::strcmp(name, kPhaseNames[ph]) == 0) {
+      *avg_ms = h->timers[ph].count ? h->timers[ph].ms / (double)h->timers[ph].count : 0.0;
+      if (launches) *launches = h->timers[ph].count;
+      return GSX_OK;
+    }
+  return GSX_E_INVALID;
+}
+
+}  // extern "C"

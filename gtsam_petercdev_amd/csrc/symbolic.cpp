@@ -1,0 +1,382 @@
+// symbolic.cpp — symbolic analysis, done ONCE per (graph, ordering) and cached in the handle.
+//
+// Produces the same Bayes-tree cliques as the reference's EliminationTree constructor
+// (gtsam/inference/EliminationTree-inst.h:78-156: a factor hangs off its first-eliminated
+// variable, children are attached in factor order) followed by the JunctionTree constructor
+// (gtsam/inference/JunctionTree-inst.h:51-153: symbolic elimination + the merge rule
+// "myNrParents + myNrFrontals == child.nrParents", ClusterTree-inst.h:58-96) — but with its own
+// data structures (flat arrays, path-compressed root finding, no recursion), and it goes on to
+// build everything the device needs: per-front variable lists and scalar row maps, the
+// per-variable Hessian panels with their assembly term lists, the level schedule and the arena
+// layout.  The reference redoes this work at every solve (EliminateableFactorGraph-inst.h:123-146).
+#include <algorithm>
+#include <numeric>
+
+#include "gsx_internal.h"
+
+namespace gsx {
+
+gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order, Symbolic& S, std::string& err) {
+  const int n = P.n_vars, m = P.n_factors;
+  if ((int)order.size() != n) {
+    err = "ordering size differs from the number of variables";
+    return GSX_E_BAD_ORDERING;
+  }
+  S = Symbolic();
+  S.order = order;
+  S.pos.assign(n, -1);
+  for (int j = 0; j < n; ++j) {
+    const int v = order[j];
+    if (v < 0 || v >= n || S.pos[v] != -1) {
+      err = "ordering is not a permutation of the variables";
+      return GSX_E_BAD_ORDERING;
+    }
+    S.pos[v] = j;
+  }
+  // variable -> factors (ascending factor index), CSR
+  std::vector<int> vf_ptr(n + 1, 0), vf;
+  for (int k = 0; k < (int)P.f_vars.size(); ++k) vf_ptr[P.f_vars[k] + 1]++;
+  for (int v = 0; v < n; ++v) vf_ptr[v + 1] += vf_ptr[v];
+  vf.resize(P.f_vars.size());
+  {
+    std::vector<int> fill(vf_ptr.begin(), vf_ptr.end() - 1);
+    for (int f = 0; f < m; ++f)
+      for (int k = P.f_key_ptr[f]; k < P.f_key_ptr[f + 1]; ++k) vf[fill[P.f_vars[k]]++] = f;
+  }
+  // ---- elimination tree (nodes are elimination positions) -------------------------------------
+  std::vector<int> eparent(n, -1), ancestor(n, -1), prevCol(m, -1);
+  std::vector<int> ech_ptr(n + 1, 0);
+  std::vector<std::pair<int, int>> child_edges;  // (parent j, child r) in attachment order
+  child_edges.reserve(n);
+  for (int j = 0; j < n; ++j) {
+    const int v = order[j];
+    for (int k = vf_ptr[v]; k < vf_ptr[v + 1]; ++k) {
+      const int f = vf[k];
+      if (prevCol[f] != -1) {
+        int r = prevCol[f];
+        // root of the current subtree containing r (path-compressed ancestor walk)
+        int t = r;
+        while (ancestor[t] != -1 && ancestor[t] != j) t = ancestor[t];
+        const int root = t;
+        t = r;
+        while (t != root) {  // compress
+          const int nx = ancestor[t];
+          ancestor[t] = j;
+          t = nx;
+        }
+        if (root != j) {
+          if (ancestor[root] == -1) {
+            ancestor[root] = j;
+            eparent[root] = j;
+            child_edges.push_back({j, root});
+          }
+        }
+      }
+      prevCol[f] = j;
+    }
+  }
+  for (auto& e : child_edges) ech_ptr[e.first + 1]++;
+  for (int j = 0; j < n; ++j) ech_ptr[j + 1] += ech_ptr[j];
+  std::vector<int> ech(child_edges.size());
+  {
+    std::vector<int> fill(ech_ptr.begin(), ech_ptr.end() - 1);
+    for (auto& e : child_edges) ech[fill[e.first]++] = e.second;  // attachment order preserved
+  }
+  // ---- symbolic column structures: struct[j] = later positions coupled to j, ascending ----------
+  std::vector<std::vector<int>> st(n);
+  std::vector<int> stamp(n, -1);
+  for (int j = 0; j < n; ++j) {
+    const int v = order[j];
+    std::vector<int>& s = st[j];
+    stamp[j] = j;
+    for (int k = vf_ptr[v]; k < vf_ptr[v + 1]; ++k) {
+      const int f = vf[k];
+      for (int q = P.f_key_ptr[f]; q < P.f_key_ptr[f + 1]; ++q) {
+        const int pj = S.pos[P.f_vars[q]];
+        if (pj > j && stamp[pj] != j) {
+          stamp[pj] = j;
+          s.push_back(pj);
+        }
+      }
+    }
+    for (int c = ech_ptr[j]; c < ech_ptr[j + 1]; ++c)
+      for (int pj : st[ech[c]])
+        if (pj > j && stamp[pj] != j) {
+          stamp[pj] = j;
+          s.push_back(pj);
+        }
+    std::sort(s.begin(), s.end());
+  }
+  // ---- supernodes: the reference's merge rule ------------------------------------------------------
+  // merged[j] = true when node j was merged into its etree parent's cluster.
+  std::vector<char> merged(n, 0);
+  std::vector<int> nfront_of(n, 1);  // frontal variable count of the cluster topped by node j
+  for (int j = 0; j < n; ++j) {
+    const size_t myNrParents = st[j].size();
+    size_t myNrFrontals = 1;
+    for (int c = ech_ptr[j]; c < ech_ptr[j + 1]; ++c) {
+      const int ch = ech[c];
+      if (myNrParents + myNrFrontals == st[ch].size()) {
+        myNrFrontals += nfront_of[ch];
+        merged[ch] = 1;
+      }
+    }
+    nfront_of[j] = (int)myNrFrontals;
+  }
+  // top node of the cluster containing each node
+  std::vector<int> top(n);
+  for (int j = n - 1; j >= 0; --j) top[j] = merged[j] ? top[eparent[j]] : j;
+  // fronts numbered by ascending top position (children before parents)
+  std::vector<int> front_of_top(n, -1);
+  int nfr = 0;
+  for (int j = 0; j < n; ++j)
+    if (!merged[j]) front_of_top[j] = nfr++;
+  S.n_fronts = nfr;
+  S.front_of_var.assign(n, -1);
+  std::vector<int> nfv(nfr, 0);
+  for (int j = 0; j < n; ++j) {
+    const int fr = front_of_top[top[j]];
+    S.front_of_var[order[j]] = fr;
+    nfv[fr]++;
+  }
+  S.nfrontal_vars = nfv;
+  S.parent.assign(nfr, -1);
+  for (int j = 0; j < n; ++j)
+    if (!merged[j] && eparent[j] != -1) S.parent[front_of_top[j]] = front_of_top[top[eparent[j]]];
+  // children of fronts in the reference's order: walk the cluster's nodes; a non-merged etree child
+  // of any node of the cluster is a child cluster.  Order: for the top node, children in attachment
+  // order with merged ones replaced by their own (recursively expanded) children.
+  S.child_ptr.assign(nfr + 1, 0);
+  {
+    std::vector<std::vector<int>> kids(nfr);
+    // expanded child list per node, built bottom-up
+    std::vector<std::vector<int>> expanded(n);
+    for (int j = 0; j < n; ++j) {
+      std::vector<int>& ex = expanded[j];
+      for (int c = ech_ptr[j]; c < ech_ptr[j + 1]; ++c) {
+        const int ch = ech[c];
+        if (merged[ch]) {
+          ex.insert(ex.end(), expanded[ch].begin(), expanded[ch].end());
+          std::vector<int>().swap(expanded[ch]);
+        } else {
+          ex.push_back(front_of_top[ch]);
+        }
+      }
+      if (!merged[j]) {
+        kids[front_of_top[j]] = ex;
+        std::vector<int>().swap(ex);
+      }
+    }
+    for (int f = 0; f < nfr; ++f) S.child_ptr[f + 1] = S.child_ptr[f] + (int)kids[f].size();
+    S.children.resize(S.child_ptr[nfr]);
+    for (int f = 0; f < nfr; ++f) std::copy(kids[f].begin(), kids[f].end(), S.children.begin() + S.child_ptr[f]);
+  }
+  // ---- per-front variable lists (frontals by position, then separator = struct of the top) -------
+  S.fvar_ptr.assign(nfr + 1, 0);
+  {
+    std::vector<int> top_of_front(nfr);
+    for (int j = 0; j < n; ++j)
+      if (!merged[j]) top_of_front[front_of_top[j]] = j;
+    for (int f = 0; f < nfr; ++f) S.fvar_ptr[f + 1] = S.fvar_ptr[f] + nfv[f] + (int)st[top_of_front[f]].size();
+    S.fvars.resize(S.fvar_ptr[nfr]);
+    std::vector<int> fill(S.fvar_ptr.begin(), S.fvar_ptr.end() - 1);
+    for (int j = 0; j < n; ++j) {  // ascending position => frontals sorted by position
+      const int f = front_of_top[top[j]];
+      S.fvars[fill[f]++] = order[j];
+    }
+    for (int f = 0; f < nfr; ++f)
+      for (int pj : st[top_of_front[f]]) S.fvars[fill[f]++] = order[pj];
+  }
+  std::vector<std::vector<int>>().swap(st);
+  // ---- dims, arena layout, levels ---------------------------------------------------------------------
+  S.F.assign(nfr, 0);
+  S.S.assign(nfr, 0);
+  S.N.assign(nfr, 0);
+  S.off.assign(nfr + 1, 0);
+  S.level.assign(nfr, 0);
+  for (int f = 0; f < nfr; ++f) {
+    int F = 0, Sd = 0;
+    for (int k = 0; k < nfv[f]; ++k) F += P.dims[S.fvars[S.fvar_ptr[f] + k]];
+    for (int k = S.fvar_ptr[f] + nfv[f]; k < S.fvar_ptr[f + 1]; ++k) Sd += P.dims[S.fvars[k]];
+    S.F[f] = F;
+    S.S[f] = Sd;
+    S.N[f] = F + Sd + 1;
+    const int64_t nn = (int64_t)S.N[f] * S.N[f];
+    S.off[f + 1] = S.off[f] + ((nn + 1) & ~int64_t(1));  // 16-byte aligned fronts
+    const double s1 = Sd + 1.0;
+    S.flops += (double)F * F * F / 3.0 + (double)F * F * s1 + (double)F * s1 * s1;
+    S.front_bytes += 8.0 * (double)nn;
+    S.lpanel_bytes += 8.0 * (double)F * S.N[f];
+    S.max_F = std::max<int64_t>(S.max_F, F);
+    S.max_rows = std::max<int64_t>(S.max_rows, F + Sd);
+    if (S.N[f] <= kSmallMaxN) S.n_small++; else S.n_big++;
+  }
+  S.arena_size = S.off[nfr];
+  for (int f = 0; f < nfr; ++f)  // children have smaller ids
+    if (S.parent[f] >= 0) S.level[S.parent[f]] = std::max(S.level[S.parent[f]], S.level[f] + 1);
+  S.n_levels = 0;
+  for (int f = 0; f < nfr; ++f) S.n_levels = std::max(S.n_levels, S.level[f] + 1);
+  // ---- H panels and assembly terms (per variable) -----------------------------------------------------
+  S.h_off.assign(n + 1, 0);
+  S.h_rows.assign(n, 0);
+  S.hmap_ptr.assign(n + 1, 0);
+  S.h_loc.assign(n, 0);
+  S.term_ptr.assign(n + 1, 0);
+  std::vector<int> nb_ptr(n + 1, 0), nb;  // later neighbours per variable, ascending position
+  {
+    std::vector<int> tmp;
+    std::fill(stamp.begin(), stamp.end(), -1);
+    for (int v = 0; v < n; ++v) {
+      tmp.clear();
+      for (int k = vf_ptr[v]; k < vf_ptr[v + 1]; ++k) {
+        const int f = vf[k];
+        for (int q = P.f_key_ptr[f]; q < P.f_key_ptr[f + 1]; ++q) {
+          const int u = P.f_vars[q];
+          if (S.pos[u] > S.pos[v] && stamp[u] != v) {
+            stamp[u] = v;
+            tmp.push_back(u);
+          }
+        }
+      }
+      std::sort(tmp.begin(), tmp.end(), [&](int a, int b) { return S.pos[a] < S.pos[b]; });
+      nb_ptr[v + 1] = nb_ptr[v] + (int)tmp.size();
+      nb.insert(nb.end(), tmp.begin(), tmp.end());
+      int rows = P.dims[v] + 1;
+      for (int u : tmp) rows += P.dims[u];
+      S.h_rows[v] = rows;
+      S.h_off[v + 1] = S.h_off[v] + (((int64_t)rows * P.dims[v] + 1) & ~int64_t(1));
+      S.hmap_ptr[v + 1] = S.hmap_ptr[v] + rows;
+    }
+    S.h_size = S.h_off[n];
+  }
+  // terms
+  {
+    std::vector<int> rowoff(n, -1);  // panel row offset of neighbour u in the current variable's panel
+    int64_t nterms = 0;
+    for (int v = 0; v < n; ++v) {
+      int64_t c = 0;
+      for (int k = vf_ptr[v]; k < vf_ptr[v + 1]; ++k) {
+        const int f = vf[k];
+        c += 2;  // diagonal + rhs
+        for (int q = P.f_key_ptr[f]; q < P.f_key_ptr[f + 1]; ++q)
+          if (S.pos[P.f_vars[q]] > S.pos[v]) ++c;
+      }
+      nterms += c;
+      S.term_ptr[v + 1] = nterms;
+    }
+    S.t_jac.resize(nterms);
+    S.t_m.resize(nterms);
+    S.t_colA.resize(nterms);
+    S.t_colB.resize(nterms);
+    S.t_dB.resize(nterms);
+    S.t_dst.resize(nterms);
+    for (int v = 0; v < n; ++v) {
+      int r = P.dims[v];
+      for (int k = nb_ptr[v]; k < nb_ptr[v + 1]; ++k) {
+        rowoff[nb[k]] = r;
+        r += P.dims[nb[k]];
+      }
+      int64_t t = S.term_ptr[v];
+      for (int k = vf_ptr[v]; k < vf_ptr[v + 1]; ++k) {
+        const int f = vf[k];
+        int colA = 0, col = 0;
+        for (int q = P.f_key_ptr[f]; q < P.f_key_ptr[f + 1]; ++q) {
+          if (P.f_vars[q] == v) colA = col;
+          col += P.dims[P.f_vars[q]];
+        }
+        auto put = [&](int colB, int dB, int dst) {
+          S.t_jac[t] = P.f_jac_off[f];
+          S.t_m[t] = P.f_rows[f];
+          S.t_colA[t] = colA;
+          S.t_colB[t] = colB;
+          S.t_dB[t] = dB;
+          S.t_dst[t] = dst;
+          ++t;
+        };
+        put(colA, P.dims[v], 0);
+        col = 0;
+        for (int q = P.f_key_ptr[f]; q < P.f_key_ptr[f + 1]; ++q) {
+          const int u = P.f_vars[q];
+          if (S.pos[u] > S.pos[v]) put(col, P.dims[u], rowoff[u]);
+          col += P.dims[u];
+        }
+        put(col, 1, S.h_rows[v] - 1);
+      }
+    }
+  }
+  // ---- scalar row maps ----------------------------------------------------------------------------------
+  S.cmap_ptr.assign(nfr + 1, 0);
+  S.gidx_ptr.assign(nfr + 1, 0);
+  for (int f = 0; f < nfr; ++f) {
+    S.cmap_ptr[f + 1] = S.cmap_ptr[f] + S.S[f] + 1;
+    S.gidx_ptr[f + 1] = S.gidx_ptr[f] + S.F[f] + S.S[f];
+  }
+  S.cmap.assign(S.cmap_ptr[nfr], 0);
+  S.gidx.assign(S.gidx_ptr[nfr], 0);
+  S.hmap.assign(S.hmap_ptr[n], 0);
+  {
+    std::vector<int> loc(n, -1);
+    for (int f = 0; f < nfr; ++f) {
+      int o = 0;
+      int64_t g = S.gidx_ptr[f];
+      for (int k = S.fvar_ptr[f]; k < S.fvar_ptr[f + 1]; ++k) {
+        const int v = S.fvars[k];
+        loc[v] = o;
+        for (int d = 0; d < P.dims[v]; ++d) S.gidx[g++] = P.tan_off[v] + d;
+        o += P.dims[v];
+      }
+      // H panel maps of the frontal variables
+      for (int k = 0; k < nfv[f]; ++k) {
+        const int v = S.fvars[S.fvar_ptr[f] + k];
+        S.h_loc[v] = loc[v];
+        int64_t h = S.hmap_ptr[v];
+        for (int d = 0; d < P.dims[v]; ++d) S.hmap[h++] = loc[v] + d;
+        for (int q = nb_ptr[v]; q < nb_ptr[v + 1]; ++q) {
+          const int u = nb[q];
+          if (loc[u] < 0) {
+            err = "internal: neighbour missing from front";
+            return GSX_E_INVALID;
+          }
+          for (int d = 0; d < P.dims[u]; ++d) S.hmap[h++] = loc[u] + d;
+        }
+        S.hmap[h++] = S.N[f] - 1;
+      }
+      // update-row maps of the children
+      for (int c = S.child_ptr[f]; c < S.child_ptr[f + 1]; ++c) {
+        const int ch = S.children[c];
+        int64_t cm = S.cmap_ptr[ch];
+        for (int k = S.fvar_ptr[ch] + nfv[ch]; k < S.fvar_ptr[ch + 1]; ++k) {
+          const int u = S.fvars[k];
+          if (loc[u] < 0) {
+            err = "internal: child separator variable missing from parent front";
+            return GSX_E_INVALID;
+          }
+          for (int d = 0; d < P.dims[u]; ++d) S.cmap[cm++] = loc[u] + d;
+        }
+        S.cmap[cm++] = S.N[f] - 1;
+      }
+      for (int k = S.fvar_ptr[f]; k < S.fvar_ptr[f + 1]; ++k) loc[S.fvars[k]] = -1;
+    }
+  }
+  // ---- schedule: by level, small (LDS) fronts first sorted by N, then big fronts -------------------------
+  S.sched.resize(nfr);
+  std::iota(S.sched.begin(), S.sched.end(), 0);
+  std::stable_sort(S.sched.begin(), S.sched.end(), [&](int a, int b) {
+    if (S.level[a] != S.level[b]) return S.level[a] < S.level[b];
+    const bool ba = S.N[a] > kSmallMaxN, bb = S.N[b] > kSmallMaxN;
+    if (ba != bb) return !ba;
+    return S.N[a] < S.N[b];
+  });
+  S.lvl_ptr.assign(S.n_levels + 1, 0);
+  S.lvl_small_end.assign(S.n_levels, 0);
+  for (int f = 0; f < nfr; ++f) S.lvl_ptr[S.level[f] + 1]++;
+  for (int l = 0; l < S.n_levels; ++l) S.lvl_ptr[l + 1] += S.lvl_ptr[l];
+  for (int l = 0; l < S.n_levels; ++l) {
+    int e = S.lvl_ptr[l];
+    while (e < S.lvl_ptr[l + 1] && S.N[S.sched[e]] <= kSmallMaxN) ++e;
+    S.lvl_small_end[l] = e;
+  }
+  return GSX_OK;
+}
+
+}  // namespace gsx

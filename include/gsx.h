@@ -275,22 +275,12 @@ gsx_status gsx_solve_gfg(const gsx_problem_desc* desc, const uint64_t* ordering,
 gsx_status gsx_cholesky_partial(double* abc, int32_t n, int32_t nfrontal, int32_t device,
                                 int32_t* ok);
 
-/* ---- multi-GPU (one process per GPU; the caller owns the collective) -------- */
-/* Restrict the handle to the factors owned by `rank` of `world` (factors are
- * dealt by their first-eliminated variable's subtree).  Separator fronts are
- * exposed as one contiguous FP64 device buffer that the caller all-reduces
- * (RCCL via torch.distributed) between gsx_factorize_local and
- * gsx_factorize_finish.  See DESIGN.md §multi-GPU. */
-gsx_status gsx_set_partition(gsx_handle h, int32_t rank, int32_t world);
-gsx_status gsx_partition_buffer(gsx_handle h, void** device_ptr, int64_t* n_doubles);
-gsx_status gsx_factorize_local(gsx_handle h, double lambda, int32_t diagonal_damping,
-                               double min_diagonal, double max_diagonal);
-gsx_status gsx_factorize_finish(gsx_handle h, double* delta_out, int64_t n, uint64_t* bad_key);
-
 /* ---- stats / stream ---------------------------------------------------------- */
 gsx_status gsx_get_stats(gsx_handle h, gsx_stats* out);
 gsx_status gsx_reset_stats(gsx_handle h);
 gsx_status gsx_synchronize(gsx_handle h);
+/* level 1: additionally time every factor_small / factor_big launch (HIP events per launch) */
+gsx_status gsx_set_profiling(gsx_handle h, int32_t level);
 /* average duration (ms) of the named kernel class over launches since the last
  * gsx_reset_stats, measured with HIP events on the handle's stream; names:
  * "linearize", "assemble_hessian", "factor_small", "factor_big", "backsolve",

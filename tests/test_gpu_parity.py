@@ -1,0 +1,307 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI of include/gsx.h) against the CPU
+oracle on the same seeded inputs, and against the reference's golden values.
+
+Tolerances: the path is FP64; Jacobians/residuals are compared at 1e-11 relative, solve results
+(delta, errors) at 1e-8 relative to the vector norm (the north star asks for 1e-6), integer
+structure (Bayes tree, orderings) exactly.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import gtsam_petercdev_amd as gt
+from gtsam_petercdev_amd import _abi as A
+from gtsam_petercdev_amd import datasets
+from gtsam_petercdev_amd.graph import (X, L, Pose2, Pose3, Rot3, Point2, Point3, Values, NonlinearFactorGraph,
+                                       GaussianFactorGraph, JacobianFactor, PriorFactor, BetweenFactor,
+                                       GeneralSFMFactor, Cal3Bundler, PinholeCameraCal3Bundler, noiseModel,
+                                       Ordering, LevenbergMarquardtOptimizer, LevenbergMarquardtParams,
+                                       GaussNewtonOptimizer)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from gtsam_petercdev_amd import _lib
+    assert _lib.device_count() > 0, "no GPU visible: the HIP path has no fallback"
+    return _lib
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+# ---- dense kernel: choleskyPartial (gtsam/base/tests/testCholesky.cpp) ------------------------------
+def _gpu_cholesky(gpu, abc, nf):
+    import ctypes as C
+    m = np.asfortranarray(abc, dtype=np.float64).copy(order="F")
+    ok = C.c_int32()
+    st = gpu.load().gsx_cholesky_partial(m.ctypes.data_as(C.POINTER(C.c_double)), C.c_int32(m.shape[0]),
+                                         C.c_int32(nf), C.c_int32(0), C.byref(ok))
+    assert st == 0
+    return m, bool(ok.value)
+
+
+def test_choleskyPartial_golden(gpu, oracle):
+    from tests.test_oracle_golden import ABC7
+    got, ok = _gpu_cholesky(gpu, ABC7, 3)
+    exp, ok2 = oracle.cholesky_partial(ABC7, 3)
+    assert ok and ok2
+    assert np.allclose(np.triu(got), np.triu(exp), atol=1e-12)
+    got0, ok = _gpu_cholesky(gpu, ABC7[:3, :3], 0)
+    assert ok and np.allclose(got0, ABC7[:3, :3])
+
+
+@pytest.mark.parametrize("n,nf", [(5, 5), (43, 3), (64, 12), (97, 33), (140, 64), (141, 31), (200, 200), (333, 150),
+                                   (515, 257)])
+def test_choleskyPartial_random(gpu, oracle, n, nf):
+    rng = np.random.default_rng(n * 1000 + nf)
+    Bm = rng.normal(size=(n + 5, n))
+    S = Bm.T @ Bm + n * np.eye(n)
+    got, ok = _gpu_cholesky(gpu, S, nf)
+    exp, ok2 = oracle.cholesky_partial(S, nf)
+    assert ok and ok2
+    assert relerr(np.triu(got), np.triu(exp)) < 1e-12
+
+
+def test_cholesky_underconstrained(gpu):
+    Lm = np.array([
+        [1, 0, 0, 0, 0, 0],
+        [1.11177808157954, 1.06204809504665, 0.507342638873381, 1.34953401829486, 1, 0],
+        [0.155864888199928, 1.10933048588373, 0.501255576961674, 1, 0, 0],
+        [1.12108665967793, 1.01584408366945, 1, 0, 0, 0],
+        [0.776164062474843, 0.117617236580373, -0.0236628691347294, 0.814118199972143, 0.694309975328922, 1],
+        [0.1197220685104, 1, 0, 0, 0, 0]])
+    d = [0.814723686393179, 0.811780089277421, 1.82596950680844, 0.240287537694585]
+    for tail in ([1.34342584865901, 1e-12], [0, 0], [-0.5, -0.6]):
+        _, ok = _gpu_cholesky(gpu, Lm @ np.diag(d + tail) @ Lm.T, 6)
+        assert not ok
+
+
+# ---- per-step parity on seeded problems ---------------------------------------------------------------------
+def _mixed_noise(arr, rng):
+    """Give the factors of a synthetic problem a mix of Unit / Isotropic / Diagonal / Gaussian noise."""
+    kinds, ptr, vals = [], [0], []
+    for f in range(arr.n_factors):
+        m = int(arr.f_rows[f])
+        k = int(rng.integers(0, 4))
+        if k == A.NOISE_UNIT:
+            p = np.zeros(0)
+        elif k == A.NOISE_ISOTROPIC:
+            p = rng.uniform(0.5, 2.0, 1)
+        elif k == A.NOISE_DIAGONAL:
+            p = rng.uniform(0.5, 2.0, m)
+        else:
+            p = np.triu(rng.normal(size=(m, m)) * 0.2 + np.eye(m) * rng.uniform(0.8, 1.5)).reshape(-1)
+        kinds.append(k)
+        vals.append(p)
+        ptr.append(ptr[-1] + p.size)
+    return A.ProblemArrays(arr.var_keys, arr.var_types, arr.var_dims, arr.f_type, arr.f_rows, arr.f_key_ptr,
+                           arr.f_vars, arr.f_meas_ptr, arr.meas, kinds, ptr, np.concatenate(vals), arr.values,
+                           dict(arr.meta))
+
+
+def _problems():
+    rng = np.random.default_rng(5)
+    bal = datasets.synth_bal_arrays(6, 40, 150, seed=11, priors=True)
+    yield "bal_small", bal
+    yield "bal_mixed_noise", _mixed_noise(bal, rng)
+    yield "bal_bigfront", datasets.synth_bal_arrays(24, 300, 2400, seed=12, long_range=0.5)
+    p2 = datasets.synth_manhattan_pose2(400, seed=3)
+    yield "pose2", p2
+    yield "pose2_mixed_noise", _mixed_noise(p2, rng)
+    p3 = datasets.synth_manhattan_pose3(300, seed=4)
+    yield "pose3", p3
+    yield "pose3_mixed_noise", _mixed_noise(p3, rng)
+
+
+PROBLEMS = dict(_problems())
+
+
+@pytest.mark.parametrize("name", list(PROBLEMS))
+def test_step_parity(gpu, oracle, name):
+    arr = PROBLEMS[name]
+    gb = gpu.product_backend(arr)
+    ob = oracle.oracle_backend(arr)
+    # nonlinear error
+    assert abs(gb.error() - ob.error()) <= 1e-11 * abs(ob.error())
+    # Jacobians
+    gb.linearize()
+    ob.linearize()
+    jg, jo = gb.jacobians(), ob.jacobians()
+    assert np.max(np.abs(jg - jo)) <= 1e-11 * max(1.0, np.max(np.abs(jo)))
+    for kind in (A.ORDER_MINDEGREE, A.ORDER_ND):
+        ordering = gb.compute_ordering(kind)
+        gb.set_ordering(ordering)
+        ob.set_ordering(ordering)
+        gb.linearize()
+        hd_g, hd_o = gb.hessian_diagonal(), ob.hessian_diagonal()
+        assert relerr(hd_g, hd_o) < 1e-12
+        for lam, diag in ((1e-3, False), (1.0, True), (1e-5, False)):
+            dg = gb.solve(lam, diag)
+            do = ob.solve(lam, diag)
+            assert relerr(dg, do) < 1e-8, (name, kind, lam, diag)
+            e0g, edg = gb.linear_error()
+            e0o, edo = ob.linear_error()
+            assert abs(e0g - e0o) <= 1e-10 * abs(e0o) and abs(edg - edo) <= 1e-8 * max(abs(edo), 1e-12 * abs(e0o))
+            tg = gb.retract(None, commit=False)
+            to = ob.retract(None, commit=False)
+            assert abs(tg - to) <= 1e-8 * max(abs(to), 1e-9)
+        # the Bayes tree is the reference's (integer structure: exact)
+        pg, fg = gb.get_tree()
+        po, fo = ob.get_tree()
+        tg = {tuple(sorted(f)): tuple(sorted(s)) for f, s in fg}
+        to = {tuple(sorted(f)): tuple(sorted(s)) for f, s in fo}
+        assert tg == to
+    # committing a retraction moves the values identically
+    d = ob.solve(1e-3, False)
+    gb.solve(1e-3, False)
+    gb.retract(None, commit=True, want_error=False)
+    ob.retract(None, commit=True, want_error=False)
+    assert relerr(gb.get_values(), ob.get_values()) < 1e-10
+
+
+@pytest.mark.parametrize("name", ["bal_small", "bal_bigfront", "pose2", "pose3"])
+@pytest.mark.parametrize("preset", ["legacy", "ceres"])
+def test_lm_trajectory_parity(gpu, oracle, name, preset):
+    """Same accept/reject decisions and the same (error, lambda) trace as the oracle; final chi^2 within 1e-6."""
+    arr = PROBLEMS[name]
+    p = A.lm_params_legacy() if preset == "legacy" else A.lm_params_ceres()
+    p.max_iterations = 12
+    gb = gpu.product_backend(arr)
+    ob = oracle.oracle_backend(arr)
+    ordering = gb.compute_ordering(A.ORDER_MINDEGREE)
+    gb.set_ordering(ordering)
+    ob.set_ordering(ordering)
+    rg, ro = gb.lm_optimize(p), ob.lm_optimize(p)
+    assert rg["iterations"] == ro["iterations"] and rg["inner_iterations"] == ro["inner_iterations"]
+    assert np.array_equal(rg["trace_accepted"], ro["trace_accepted"])
+    assert np.allclose(rg["trace_lambda"], ro["trace_lambda"], rtol=1e-9)
+    fin = np.isfinite(ro["trace_error"])
+    assert np.allclose(rg["trace_error"][fin], ro["trace_error"][fin], rtol=1e-6)
+    assert abs(rg["final_error"] - ro["final_error"]) <= 1e-6 * ro["final_error"]
+    assert rg["final_error"] < 0.5 * rg["initial_error"]
+
+
+# ---- the reference's own known-answer tests through the HIP path --------------------------------------------------
+def test_PinholeCamera_BAL(gpu, golden_dir):
+    """tests/testGeneralSFMFactorB.cpp:44-63: dubrovnik-3-7-pre, default LM -> graph.error = 0.0199833 +- 1e-5."""
+    sfm = datasets.read_bal(golden_dir + "/dubrovnik-3-7-pre.txt")
+    arrays = datasets.bal_arrays(sfm, priors=False)
+    be = gpu.product_backend(arrays)
+    be.set_ordering(np.load(golden_dir + "/dubrovnik_colamd_ordering.npy"))  # the reference's CCOLAMD result
+    res = be.lm_optimize(A.lm_params_legacy())
+    assert abs(res["final_error"] - 0.0199833) < 1e-5
+    assert abs(be.error() - 0.0199833) < 1e-5
+
+
+def test_optimizeMultiFrontal2(gpu):
+    """tests/testGaussianJunctionTreeB.cpp:127-140 through gsx_solve_gfg-style linear solve."""
+    from tests.test_oracle_golden import small_gaussian_factor_graph, CORRECT_DELTA
+    for ordering in ([L(1), X(1), X(2)], [X(2), L(1), X(1)], None):
+        actual = small_gaussian_factor_graph().optimize(ordering)
+        for k, v in CORRECT_DELTA.items():
+            assert np.allclose(actual[k], v, atol=1e-9)
+
+
+def test_solve_gfg_entry_point(gpu):
+    import ctypes as C
+    from tests.test_oracle_golden import small_gaussian_factor_graph, CORRECT_DELTA
+    arrays = small_gaussian_factor_graph().to_arrays(None)
+    desc = arrays.desc()
+    out = np.zeros(6)
+    bad = C.c_uint64()
+    st = gpu.load().gsx_solve_gfg(C.byref(desc), None, C.c_int32(0), out.ctypes.data_as(C.POINTER(C.c_double)),
+                                  C.c_int64(6), C.byref(bad))
+    assert st == 0
+    exp = np.concatenate([CORRECT_DELTA[int(k)] for k in arrays.var_keys])
+    assert np.allclose(out, exp, atol=1e-9)
+
+
+def test_smoother_zero_delta(gpu):
+    from tests.test_oracle_golden import nonlinear_smoother
+    g, v = nonlinear_smoother(7)
+    be = gpu.product_backend(g.to_arrays(v))
+    be.set_ordering([X(1), X(3), X(5), X(7), X(2), X(6), X(4)])
+    be.linearize()
+    assert np.allclose(be.solve(0.0), 0.0, atol=1e-9)
+
+
+def test_Factorization(gpu):
+    """tests/testNonlinearOptimizer.cpp:185-208."""
+    config = Values()
+    config.insert(X(1), Pose2(0., 0., 0.))
+    config.insert(X(2), Pose2(1.5, 0., 0.))
+    graph = NonlinearFactorGraph()
+    graph.addPrior(X(1), Pose2(0., 0., 0.), noiseModel.Isotropic.Sigma(3, 1e-10))
+    graph.add(BetweenFactor(X(1), X(2), Pose2(1., 0., 0.), noiseModel.Isotropic.Sigma(3, 1)))
+    opt = LevenbergMarquardtOptimizer(graph, config, Ordering([X(1), X(2)]), LevenbergMarquardtParams.LegacyDefaults())
+    opt.iterate()
+    res = opt.values()
+    assert res.at(X(1)).equals(Pose2(0., 0., 0.), 1e-5) and res.at(X(2)).equals(Pose2(1., 0., 0.), 1e-5)
+
+
+def test_MoreOptimization(gpu):
+    """tests/testNonlinearOptimizer.cpp:248-281 — with the library's own ordering."""
+    from tests.test_oracle_golden import more_optimization_graph
+    fg = more_optimization_graph()
+    init = Values()
+    init.insert(0, Pose2(3, 4, -math.pi))
+    init.insert(1, Pose2(10, 2, -math.pi))
+    init.insert(2, Pose2(11, 7, -math.pi))
+    expected = {0: Pose2(0, 0, 0), 1: Pose2(1, 0, math.pi / 2), 2: Pose2(1, 1, math.pi)}
+    actual = LevenbergMarquardtOptimizer(fg, init, LevenbergMarquardtParams.LegacyDefaults()).optimize()
+    for k, e in expected.items():
+        assert actual.at(k).equals(e, 1e-6)
+    actual = GaussNewtonOptimizer(fg, actual).optimize()
+    for k, e in expected.items():
+        assert actual.at(k).equals(e, 1e-6)
+
+
+def test_indeterminate_system(gpu):
+    fg = NonlinearFactorGraph()
+    fg.add(BetweenFactor(0, 1, Pose2(1, 0, 0), noiseModel.Isotropic.Sigma(3, 1)))
+    v = Values()
+    v.insert(0, Pose2(0, 0, 0))
+    v.insert(1, Pose2(1, 0, 0))
+    be = gpu.product_backend(fg.to_arrays(v))
+    be.set_ordering([0, 1])
+    be.linearize()
+    with pytest.raises(gt.IndeterminantLinearSystemException) as ei:
+        be.solve(0.0)
+    assert ei.value.key in (0, 1)
+    # ... and LM recovers by raising lambda (LevenbergMarquardtOptimizer.cpp:158-160)
+    res = be.lm_optimize(A.lm_params_legacy())
+    assert res["n_solve_failures"] >= 0 and np.isfinite(res["final_error"])
+
+
+def test_cheirality_zeroes_factor(gpu, oracle):
+    g, v = NonlinearFactorGraph(), Values()
+    g.add(GeneralSFMFactor(Point2(3., 0.), noiseModel.Unit.Create(2), X(1), L(1)))
+    g.add(GeneralSFMFactor(Point2(1., 1.), noiseModel.Unit.Create(2), X(1), L(2)))
+    v.insert(X(1), PinholeCameraCal3Bundler(Pose3(Rot3(), Point3(0, 0, -6)), Cal3Bundler(1.0, 0.0, 0.0)))
+    v.insert(L(1), Point3(0, 0, 0))
+    v.insert(L(2), Point3(0, 0, -10))  # behind the camera
+    arr = g.to_arrays(v)
+    gb, ob = gpu.product_backend(arr), oracle.oracle_backend(arr)
+    gb.linearize()
+    ob.linearize()
+    assert np.allclose(gb.jacobians(), ob.jacobians(), atol=1e-13)
+    assert np.all(gb.jacobians()[26:] == 0.0)
+    assert gb.stats()["n_cheirality"] == 1
+    assert abs(gb.error() - 4.5) < 1e-12
+
+
+def test_bad_ordering_is_rejected(gpu):
+    arr = PROBLEMS["pose2"]
+    be = gpu.product_backend(arr)
+    with pytest.raises(gt.GsxError) as ei:
+        be.set_ordering(arr.var_keys[:-1])
+    assert ei.value.status == A.GSX_E_BAD_ORDERING
+    bad = arr.var_keys.copy()
+    bad[0] = bad[1]
+    with pytest.raises(gt.GsxError):
+        be.set_ordering(bad)
