@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py — LM iterations/sec and ms/linear-solve of the HIP hot path on MI355X.
+
+A "step" is ONE Levenberg-Marquardt inner iteration at a fixed linearization point, with the
+amortised linearize included: linearize -> Hessian panels -> damped multifrontal
+Cholesky -> back-substitution -> 2 linear errors -> retract -> nonlinear error.  Nothing is
+committed, so every step does identical work on data already resident in HBM.
+
+  N = 1   workload = BAL Ladybug-1723 shape (1 723 cameras / 156 502 points / 678 718 observations,
+          seeded synthetic: 70 % ring-local + 30 % half-lap revisit co-visibility), Schur ordering.
+  N > 1   one process per GPU (torch.distributed, backend nccl = RCCL), every rank an independent
+          seeded replica of the same shape (weak scaling; see DESIGN.md "multi-GPU": the clique-partitioned
+          single-problem path is not built yet, so no data-path collective is invented here).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP64_PEAK_TFLOPS = 78.6    # MI355X FP64 vector = matrix peak (public spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="bal1723", choices=["bal1723", "bal49", "pose3_100k", "pose2_100k"])
+    ap.add_argument("--ordering", default=None, choices=[None, "schur", "mindegree", "nd"])
+    ap.add_argument("--lam", type=float, default=1e-5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    return ap.parse_args()
+
+
+def make_problem(name, seed):
+    from gtsam_petercdev_amd import datasets
+    if name == "bal1723":
+        return datasets.synth_bal_arrays(1723, 156502, 678718, seed=seed, long_range=0.3), "schur"
+    if name == "bal49":
+        return datasets.synth_bal_arrays(49, 7776, 31843, seed=seed, long_range=0.3), "schur"
+    if name == "pose3_100k":
+        return datasets.synth_manhattan_pose3(100000, seed=seed), "nd"
+    return datasets.synth_manhattan_pose2(100000, seed=seed), "nd"
+
+
+def front_split(be, arrays, small_max_n=140):
+    """Algorithmic bytes / flops of the factorization split by kernel class."""
+    parent, fronts = be.get_tree()
+    dims = arrays.var_dims
+    out = dict(small_bytes=0.0, big_bytes=0.0, small_flops=0.0, big_flops=0.0, n_small=0, n_big=0, lpanel_bytes=0.0)
+    for fv, sv in fronts:
+        f = float(dims[fv].sum())
+        s1 = float(dims[sv].sum()) + 1.0
+        n = f + s1
+        fl = f ** 3 / 3 + f * f * s1 + f * s1 * s1
+        k = "small" if n <= small_max_n else "big"
+        out[k + "_bytes"] += 8.0 * n * n
+        out[k + "_flops"] += fl
+        out["n_" + k] += 1
+        out["lpanel_bytes"] += 8.0 * f * n
+    return out
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    from gtsam_petercdev_amd import _abi as A, _lib
+
+    arrays, default_order = make_problem(args.workload, seed=42 + rank)
+    be = _lib.product_backend(arrays, device=local_rank)
+    okind = {"schur": A.ORDER_SCHUR, "mindegree": A.ORDER_MINDEGREE, "nd": A.ORDER_ND}[args.ordering or default_order]
+    t0 = time.time()
+    ordering = be.compute_ordering(okind)
+    t_order = time.time() - t0
+    t0 = time.time()
+    be.set_ordering(ordering)
+    t_symbolic = time.time() - t0
+    lam = args.lam
+
+    def step():
+        be.linearize()
+        be.solve(lam, False, want_delta=False)
+        be.linear_error()
+        be.retract(None, commit=False)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        be.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    be.reset_stats()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    st = be.stats()
+    ms_step = 1e3 * elapsed / args.steps
+    value = world * args.steps / elapsed
+    ms_solve = (st["ms_factorize"] + st["ms_backsolve"]) / max(st["n_factorize"], 1)
+
+    # ---- per-kernel timing pass (HIP events on the library's stream around every launch) ------------
+    be.set_profiling(1)
+    be.reset_stats()
+    for _ in range(3):
+        step()
+    small_ms, small_n = be.kernel_time("factor_small")
+    big_ms, big_n = be.kernel_time("factor_big")
+    st_prof = be.stats()
+    be.set_profiling(0)
+    split = front_split(be, arrays)
+    nfac = max(st_prof["n_factorize"], 1)
+    phases = {k: st_prof[k] / nfac for k in ("ms_linearize", "ms_assemble_hessian", "ms_factorize", "ms_backsolve",
+                                             "ms_linear_error", "ms_retract", "ms_error")}
+    tot_small, tot_big = small_ms * small_n / nfac, big_ms * big_n / nfac
+    if tot_small >= tot_big:
+        # fused assemble + eliminate of the small cliques: HBM-bound (8 (f+s+1)^2 per front,
+        # read + written once)
+        per_launch_bytes = split["small_bytes"] * nfac / max(small_n, 1)
+        achieved = per_launch_bytes / (small_ms * 1e-3) / 1e9 if small_ms > 0 else 0.0
+        roofline = dict(kernel="front_small_kernel", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=achieved / HBM_PEAK_GBS, traffic=None, launches_per_factorization=small_n / nfac,
+                        avg_launch_ms=small_ms, algorithmic_bytes_per_launch=per_launch_bytes)
+    else:
+        per_launch_flops = split["big_flops"] * nfac / max(big_n, 1)
+        achieved = per_launch_flops / (big_ms * 1e-3) / 1e12 if big_ms > 0 else 0.0
+        roofline = dict(kernel="big_syrk_kernel+big_trsm_kernel (per level)", bound="mfma", achieved=achieved,
+                        peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / FP64_PEAK_TFLOPS, traffic=None,
+                        launches_per_factorization=big_n / nfac, avg_launch_ms=big_ms,
+                        algorithmic_flops_per_launch=per_launch_flops)
+
+    out = {
+        "metric": "lm_iterations_per_sec", "value": value, "unit": "LM iterations/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": args.workload, "shape": arrays.meta, "ordering": args.ordering or default_order,
+                   "lambda": lam, "replicas": world},
+        "ms_per_linear_solve": ms_solve,
+        "phases_ms": phases,
+        "factor_small_ms": tot_small, "factor_big_ms": tot_big,
+        "symbolic": {k: st[k] for k in ("n_fronts", "n_levels", "max_front_dim", "max_front_rows", "n_small_fronts",
+                                        "n_big_fronts", "factor_flops", "front_bytes", "lpanel_bytes",
+                                        "jacobian_bytes", "hessian_bytes", "total_dim")},
+        "front_split": split, "host_ordering_s": t_order, "host_symbolic_s": t_symbolic,
+        "roofline": roofline,
+    }
+    out["config"]["shape"] = {k: (v if not hasattr(v, "tolist") else None) for k, v in arrays.meta.items()
+                              if not hasattr(v, "shape")}
+
+    # ---- CPU baseline: the oracle ("port", 1 thread) on a bounded sample of the same workload ---------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        ob = orc.oracle_backend(arrays)
+        ob.set_ordering(ordering)
+        ob.reset_timing()
+        t0 = time.perf_counter()
+        for _ in range(args.cpu_iters):
+            ob.linearize()
+            ob.solve(lam, False, want_delta=False)
+            ob.linear_error()
+            ob.retract(None, commit=False)
+        cpu_s = time.perf_counter() - t0
+        tm, tree = ob.timing()
+        out["cpu_baseline"] = {
+            "value": args.cpu_iters / cpu_s, "unit": "LM iterations/s", "cores": 1, "kind": "port",
+            "sample": f"{args.cpu_iters} identical LM inner iterations (linearize + damped multifrontal solve + "
+                      f"2 linear errors + retract + error) of the same {args.workload} problem and ordering",
+            "ms_per_step": 1e3 * cpu_s / args.cpu_iters,
+            "ms_per_linear_solve": 1e3 * (tm["damp"] + tm["symbolic"] + tm["eliminate"] + tm["backsub"]) / args.cpu_iters,
+            "phases_s": {k: v / args.cpu_iters for k, v in tm.items()}, "host_cpus": os.cpu_count(),
+        }
+        out["speedup_vs_cpu_port"] = value / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

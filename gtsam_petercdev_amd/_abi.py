@@ -2,7 +2,8 @@
 
 The wrapper is parametrised by (library, symbol prefix) so that the very same
 Python code can drive the product (``libgsx.so``, prefix ``gsx_``) and — from
-tests/ only — the CPU oracle (``oracle/liboracle.so``, prefix ``orc_``).
+tests/ only — the CPU checker, which exports the same entry points under the
+prefix ``orc_`` (this package never loads it).
 Nothing in this module computes anything: it marshals numpy arrays.
 """
 from __future__ import annotations

@@ -49,6 +49,9 @@ class ProductBackend(A.Backend):
     def reset_stats(self):
         self._check(self._fn("reset_stats")(self._h), "reset_stats")
 
+    def set_profiling(self, level: int):
+        self._check(self._fn("set_profiling")(self._h, C.c_int32(level)), "set_profiling")
+
     def synchronize(self):
         self._check(self._fn("synchronize")(self._h), "synchronize")
 

@@ -168,7 +168,7 @@ def synth_bal(n_cams: int, n_points: int, n_obs: int, seed: int = 42, long_range
     """Seeded BAL-shaped problem: cameras on a ring r=30 looking at the origin,
     Cal3Bundler(f~800+-100, k1~-1e-7, k2~1e-13), points U[-8,8]^3, each point seen by k>=2 cameras
     (sum k = n_obs exactly): a ring-local window of consecutive cameras, a `long_range` fraction of
-    the observations going to uniformly random cameras instead.  Returns (truth SfmData,
+    the observations coming from the cameras half a lap away instead (loop-closure revisits).  Returns (truth SfmData,
     perturbed-initial SfmData)."""
     rng = np.random.default_rng(seed)
     phi = 2 * np.pi * np.arange(n_cams) / n_cams
@@ -205,7 +205,10 @@ def synth_bal(n_cams: int, n_points: int, n_obs: int, seed: int = 42, long_range
     if long_range > 0:
         far = rng.random(pt_idx.size) < long_range
         far &= within >= 1  # keep the first observation local
-        cam_idx = np.where(far, rng.integers(0, n_cams, pt_idx.size), cam_idx)
+        # "revisit" structure (a vehicle passing the same place twice, as in the Ladybug sequences):
+        # a far observation comes from the camera half a lap away from the local window, so the
+        # reduced camera graph is a band plus a shifted band, not a dense blob
+        cam_idx = np.where(far, (cam_idx + n_cams // 2) % n_cams, cam_idx)
         # remove duplicate (cam, point) pairs by re-drawing deterministically
         for _ in range(8):
             key = pt_idx * n_cams + cam_idx
@@ -454,14 +457,15 @@ def read_g2o(path: str, is3D: bool = False, add_prior: bool = True) -> A.Problem
 def write_g2o(path: str, arrays: A.ProblemArrays, packed_values: np.ndarray):
     """writeG2o (gtsam/slam/dataset.cpp:636-735) for Pose2 / Pose3 graphs with Diagonal or Gaussian noise."""
     so = arrays.state_offsets()
+    _f = lambda x: repr(float(x))
     with open(path, "w") as fh:
         for i, k in enumerate(arrays.var_keys):
             s = packed_values[so[i]:so[i + 1]]
             if arrays.var_types[i] == A.VAR_POSE2:
-                fh.write(f"VERTEX_SE2 {int(k)} {s[0]!r} {s[1]!r} {s[2]!r}\n")
+                fh.write(f"VERTEX_SE2 {int(k)} {_f(s[0])} {_f(s[1])} {_f(s[2])}\n")
             elif arrays.var_types[i] == A.VAR_POSE3:
                 qw, qx, qy, qz = _quat_from_R(s[:9].reshape(3, 3))
-                fh.write(f"VERTEX_SE3:QUAT {int(k)} {s[9]!r} {s[10]!r} {s[11]!r} {qx!r} {qy!r} {qz!r} {qw!r}\n")
+                fh.write(f"VERTEX_SE3:QUAT {int(k)} {_f(s[9])} {_f(s[10])} {_f(s[11])} {_f(qx)} {_f(qy)} {_f(qz)} {_f(qw)}\n")
         for f in range(arrays.n_factors):
             if arrays.f_type[f] != A.F_BETWEEN:
                 continue
@@ -481,14 +485,14 @@ def write_g2o(path: str, arrays: A.ProblemArrays, packed_values: np.ndarray):
             ka, kb = int(arrays.var_keys[a]), int(arrays.var_keys[b])
             if d == 3:
                 up = [info[0, 0], info[0, 1], info[0, 2], info[1, 1], info[1, 2], info[2, 2]]
-                fh.write(f"EDGE_SE2 {ka} {kb} {z[0]!r} {z[1]!r} {z[2]!r} " + " ".join(repr(float(v)) for v in up) + "\n")
+                fh.write(f"EDGE_SE2 {ka} {kb} {_f(z[0])} {_f(z[1])} {_f(z[2])} " + " ".join(repr(float(v)) for v in up) + "\n")
             else:
                 qw, qx, qy, qz = _quat_from_R(z[:9].reshape(3, 3))
                 m = np.zeros((6, 6))
                 m[:3, :3], m[3:, 3:] = info[3:, 3:], info[:3, :3]
                 m[:3, 3:], m[3:, :3] = info[3:, :3], info[:3, 3:]
                 up = m[np.triu_indices(6)]
-                fh.write(f"EDGE_SE3:QUAT {ka} {kb} {z[9]!r} {z[10]!r} {z[11]!r} {qx!r} {qy!r} {qz!r} {qw!r} "
+                fh.write(f"EDGE_SE3:QUAT {ka} {kb} {_f(z[9])} {_f(z[10])} {_f(z[11])} {_f(qx)} {_f(qy)} {_f(qz)} {_f(qw)} "
                          + " ".join(repr(float(v)) for v in up) + "\n")
 
 

@@ -1,0 +1,167 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads and exports exactly what
+include/gsx.h declares, the host algorithms (orderings, symbolic analysis = Bayes tree) agree with
+the oracle, and the numeric entry points fail loudly without a GPU (no fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import gtsam_petercdev_amd as gt
+from gtsam_petercdev_amd import _abi as A
+from gtsam_petercdev_amd import datasets, _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from gtsam_petercdev_amd import build
+    build.build_lib()
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "gsx.h")).read()
+    declared = set(re.findall(r"\b(gsx_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"gsx_status", "gsx_handle"}
+    assert len(declared) >= 30
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (gsx_[a-z0-9_]+)", out))
+    assert declared <= exported, sorted(declared - exported)
+    assert exported <= declared, f"exported but not declared in include/gsx.h: {sorted(exported - declared)}"
+
+
+def test_product_does_not_link_or_import_the_oracle():
+    out = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+    pkg = os.path.join(ROOT, "gtsam_petercdev_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "liboracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+                assert "orc_" not in src or f == "_abi.py", f
+
+
+def _tree_set(be):
+    parent, fronts = be.get_tree()
+    out = {}
+    for c, (f, s) in enumerate(fronts):
+        p = parent[c]
+        out[tuple(sorted(f))] = (tuple(sorted(s)), tuple(sorted(fronts[p][0])) if p >= 0 else None)
+    return out
+
+
+PROBLEMS = {
+    "bal": lambda: datasets.synth_bal_arrays(8, 60, 200, seed=1, long_range=0.3),
+    "pose2": lambda: datasets.synth_manhattan_pose2(300, seed=3),
+    "pose3": lambda: datasets.synth_manhattan_pose3(200, seed=4),
+}
+
+
+@pytest.mark.parametrize("name", list(PROBLEMS))
+def test_bayes_tree_identical_to_reference_construction(lib, oracle, name):
+    """The product's symbolic analysis must give the cliques, separators and parents that the
+    reference's EliminationTree + JunctionTree constructors give (restated literally in the oracle),
+    for its own orderings and for the reference's CCOLAMD ordering."""
+    arr = PROBLEMS[name]()
+    pb = _lib.ProductBackend(arr, host_only=True)
+    ob = oracle.oracle_backend(arr)
+    orderings = [pb.compute_ordering(k) for k in (A.ORDER_NATURAL, A.ORDER_MINDEGREE, A.ORDER_ND, A.ORDER_SCHUR)]
+    if oracle.have_ref_colamd():
+        orderings.append(oracle.colamd_ordering(arr))
+    for ordering in orderings:
+        assert sorted(ordering.tolist()) == sorted(arr.var_keys.tolist())  # a permutation
+        pb.set_ordering(ordering)
+        ob.set_ordering(ordering)
+        ob.linearize()
+        ob.solve(1e-3)
+        assert _tree_set(pb) == _tree_set(ob)
+        st = pb.stats()
+        _, tree = ob.timing()
+        assert st["n_fronts"] == tree["cliques"]
+        assert abs(st["factor_flops"] - tree["flops"]) <= 1e-9 * tree["flops"]
+        assert abs(st["front_bytes"] - tree["bytes"]) <= 1e-9 * tree["bytes"]
+        assert st["max_front_dim"] == tree["max_f"]
+
+
+def test_ordering_errors(lib):
+    arr = PROBLEMS["pose2"]()
+    pb = _lib.ProductBackend(arr, host_only=True)
+    with pytest.raises(gt.GsxError) as ei:
+        pb.set_ordering(arr.var_keys[:-1])
+    assert ei.value.status == A.GSX_E_BAD_ORDERING
+    bad = arr.var_keys.copy()
+    bad[0] = bad[1]
+    with pytest.raises(gt.GsxError) as ei:
+        pb.set_ordering(bad)
+    assert ei.value.status == A.GSX_E_BAD_ORDERING
+    bad = arr.var_keys.copy()
+    bad[0] = 10 ** 9
+    with pytest.raises(gt.GsxError):
+        pb.set_ordering(bad)
+
+
+def test_malformed_description_is_rejected(lib):
+    arr = PROBLEMS["pose2"]()
+    arr.f_rows[0] = 5  # Pose2 between factor must have 3 rows
+    with pytest.raises(gt.GsxError) as ei:
+        _lib.ProductBackend(arr, host_only=True)
+    assert ei.value.status == A.GSX_E_INVALID
+
+
+def test_schur_ordering_puts_landmarks_first(lib):
+    arr = PROBLEMS["bal"]()
+    pb = _lib.ProductBackend(arr, host_only=True)
+    o = pb.compute_ordering(A.ORDER_SCHUR)
+    idx = {int(k): i for i, k in enumerate(arr.var_keys)}
+    types = [int(arr.var_types[idx[int(k)]]) for k in o]
+    n_pts = arr.meta["n_points"]
+    assert all(t == A.VAR_VECTOR for t in types[:n_pts]) and all(t == A.VAR_CAMERA for t in types[n_pts:])
+
+
+@pytest.mark.skipif(_lib.device_count() > 0, reason="only meaningful without a GPU")
+def test_no_gpu_means_loud_failure_not_fallback(lib):
+    arr = PROBLEMS["pose2"]()
+    with pytest.raises(gt.GsxError) as ei:
+        _lib.ProductBackend(arr)  # uploads the initial values -> needs a device
+    assert ei.value.status == A.GSX_E_NO_DEVICE
+    pb = _lib.ProductBackend(arr, host_only=True)
+    for call in (pb.error, pb.linearize, lambda: pb.solve(0.0), pb.get_values):
+        with pytest.raises(gt.GsxError) as ei:
+            call()
+        assert ei.value.status in (A.GSX_E_NO_DEVICE, A.GSX_E_STATE)
+    ok = C.c_int32()
+    m = np.eye(3)
+    st = lib.gsx_cholesky_partial(m.ctypes.data_as(C.POINTER(C.c_double)), C.c_int32(3), C.c_int32(2), C.c_int32(0),
+                                  C.byref(ok))
+    assert st == A.GSX_E_NO_DEVICE
+
+
+def test_datasets_roundtrip_g2o(tmp_path, golden_dir):
+    """g2o reader/writer (gtsam/slam/dataset.cpp): read the reference's example files, write, re-read."""
+    for fname, is3d in (("noisyToyGraph.txt", False), ("pose3example.txt", True)):
+        arr = datasets.read_g2o(os.path.join(golden_dir, fname), is3D=is3d)
+        assert arr.n_vars > 0 and arr.n_factors > arr.n_vars - 1
+        p = tmp_path / ("rt_" + fname)
+        datasets.write_g2o(str(p), arr, arr.values)
+        arr2 = datasets.read_g2o(str(p), is3D=is3d)
+        assert np.array_equal(arr.var_keys, arr2.var_keys)
+        assert np.allclose(arr.values, arr2.values, atol=1e-12)
+        assert np.allclose(arr.meas, arr2.meas, atol=1e-9)
+
+
+def test_pose3example_oracle_gn_converges(oracle, golden_dir):
+    """examples/Pose3SLAMExample_g2o.cpp on examples/Data/pose3example.txt (oracle, CPU): the error must
+    drop monotonically under Gauss-Newton with the anchoring prior."""
+    arr = datasets.read_g2o(os.path.join(golden_dir, "pose3example.txt"), is3D=True)
+    ob = oracle.oracle_backend(arr)
+    ob.set_ordering(arr.var_keys if not oracle.have_ref_colamd() else oracle.colamd_ordering(arr))
+    r = ob.gn_optimize(100)
+    # SURVEY.md §6.2 records what the reference's own example binary prints for this file:
+    # "Pose3SLAMExample_g2o pose3example.txt  64 941.32 -> 19 130.66" (Gauss-Newton, default params)
+    assert abs(r["initial_error"] - 64941.32) < 0.01
+    assert abs(r["final_error"] - 19130.66) < 0.01
