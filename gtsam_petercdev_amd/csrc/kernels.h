@@ -70,6 +70,7 @@ void launch_front_small(const DevProblem& P, const DevSymbolic& S, const int* id
 void launch_big_init(const DevProblem& P, const DevSymbolic& S, const BigDesc* descs, int count, int max_n,
                      int max_nfv, const double* H, const double* damp, const double* scalars, double* arena,
                      hipStream_t st);
+void launch_big_potrf0(const BigDesc* descs, int count, double* arena, DevStatus* status, hipStream_t st);
 void launch_big_step(const DevSymbolic& S, const BigDesc* descs, int count, int kb, int max_row_tiles,
                      int max_pairs, double* arena, DevStatus* status, hipStream_t st);
 void launch_big_scatter(const DevSymbolic& S, const BigDesc* descs, int count, int max_s1, double* arena,

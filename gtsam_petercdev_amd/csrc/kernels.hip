@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <climits>
+#include <cstdlib>
 
 #include "device_geometry.h"
 #include "gsx_internal.h"
@@ -594,6 +595,7 @@ __device__ inline void report_failure(DevStatus* status, int front) {
 //   4. L panel -> arena (kept for back-substitution); Schur complement -> arena (pulled by a small
 //      parent) or atomically added into a big parent's front.
 // ---------------------------------------------------------------------------------------------
+__device__ int g_debug_no_push = 0;  // timing experiments only (GSX_DEBUG_NO_PUSH=1): skips the atomic push
 __global__ void front_small_kernel(DevProblem P, DevSymbolic S, const int* ids, const double* H, const double* damp,
                                    const double* scalars, double* arena, DevStatus* status) {
   extern __shared__ double L[];
@@ -641,7 +643,7 @@ __global__ void front_small_kernel(DevProblem P, DevSymbolic S, const int* ids, 
     for (int r = c + lane; r < n; r += 64) A[r + (i64)c * n] = L[r + c * n];
   const int parent = S.fr_parent[f];
   const int s1 = n - F;
-  if (parent >= 0 && S.fr_N[parent] > kSmallMaxN) {
+  if (parent >= 0 && S.fr_N[parent] > kSmallMaxN && !g_debug_no_push) {
     const int* pm = S.cmap + S.cmap_ptr[f];
     const int pn = S.fr_N[parent];
     double* PA = arena + S.fr_off[parent];
@@ -661,6 +663,10 @@ void launch_front_small(const DevProblem& P, const DevSymbolic& S, const int* id
   static bool attr = false;
   if (!attr) {
     hipFuncSetAttribute((const void*)front_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (const char* e = getenv("GSX_DEBUG_NO_PUSH")) {
+      int v = atoi(e);
+      hipMemcpyToSymbol(HIP_SYMBOL(g_debug_no_push), &v, sizeof(int));
+    }
     attr = true;
   }
   if (count)
@@ -706,30 +712,118 @@ void launch_big_init(const DevProblem& P, const DevSymbolic& S, const BigDesc* d
   big_add_h_kernel<<<dim3(max_nfv, count), 128, 0, st>>>(P, S, descs, H, damp, scalars, arena);
 }
 
-// factor a w x w lower tile held in LDS (ld = T+1); all 256 threads; returns fail flag
-__device__ inline int lds_tile_potrf(double (*D)[T + 1], int w) {
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {  // src_lane must be wave-uniform
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, src_lane);
+  hi = __builtin_amdgcn_readlane(hi, src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+// Factor the diagonal tile (c0, w) of a big front ONCE, with a 256-thread workgroup.
+//   Ls (row-major, ld T+1) holds the tile on entry (lower triangle meaningful) and L on exit;
+//   Xs receives L^-1 (recursive doubling: X21 = -X22 (L21 X11), 5 levels of small parallel products);
+//   the front gets L in the lower triangle and (L^-1)' in the strictly upper triangle of the tile, so
+//   that the panel solve and the back-substitution are plain tile products; pivots are checked with
+//   choleskyPartial's failure semantics (gtsam/base/cholesky.cpp:145-158).
+// Potrf: every thread keeps its 4 tile entries in registers; per pivot the only shared traffic is the
+// current column (double-buffered in LDS) => ONE barrier, one LDS round trip and one rsqrt per pivot
+// (a lone wave issues ~1 instruction / 5 cycles on MI355X, so the chain is kept this short on purpose).
+__device__ __forceinline__ void diag_tile_factor(double* A, int n, int F, int c0, int w, double (*Ls)[T + 1],
+                                                 double (*Xs)[T + 1], double (*Tm)[T + 1], DevStatus* status,
+                                                 int front) {
+  __shared__ double colb[2][T];
   const int tid = threadIdx.x;
+  const int r = tid & (T - 1), cbase = tid >> 5;  // entries (r, cbase + 8 q), q = 0..3
+  double v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = cbase + 8 * q;
+    v[q] = (r >= c && r < w) ? Ls[r][c] : 0.0;
+  }
+  if (cbase == 0) colb[0][r] = v[0];
   int fail = 0;
   for (int j = 0; j < w; ++j) {
-    const double p = D[j][j];
+    __syncthreads();
+    const double* cur = colb[j & 1];
+    double* nxt = colb[(j + 1) & 1];
+    const double p = cur[j];
     if (!(p > 0)) fail = 1;
-    const double s = (p > 0) ? sqrt(p) : 1.0;
-    const double inv = 1.0 / s;
+    const double inv = (p > 0) ? rsqrt(p) : 1.0;
+    const double lr = (r > j) ? cur[r] * inv : 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = cbase + 8 * q;
+      if (c == j) {
+        v[q] = (r == j) ? p * inv : lr;  // final L[r][j]
+      } else if (c > j && r >= c) {
+        v[q] -= lr * (cur[c] * inv);
+        if (c == j + 1) nxt[r] = v[q];
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = cbase + 8 * q;
+    Ls[r][c] = (r >= c) ? v[q] : 0.0;
+    Xs[r][c] = (r == c && r < w) ? 1.0 / v[q] : 0.0;
+  }
+  __syncthreads();
+  for (int b = 1; b < T; b <<= 1) {
+    const int bb = b * b, total = (T / (2 * b)) * bb;
+    for (int e = tid; e < total; e += 256) {
+      const int pair = e / bb, loc = e - pair * bb, i = loc % b, jx = loc / b, s0 = pair * 2 * b;
+      double acc = 0;
+      for (int k = jx; k < b; ++k) acc += Ls[s0 + b + i][s0 + k] * Xs[s0 + k][s0 + jx];
+      Tm[s0 + b + i][s0 + jx] = acc;
+    }
     __syncthreads();
-    if (tid == 0) D[j][j] = s;
-    for (int r = j + 1 + tid; r < w; r += blockDim.x) D[r][j] *= inv;
-    __syncthreads();
-    const int ww = w - j - 1;
-    for (int e = tid; e < ww * ww; e += blockDim.x) {
-      const int rr = j + 1 + e % ww, cc = j + 1 + e / ww;
-      if (rr >= cc) D[rr][cc] -= D[rr][j] * D[cc][j];
+    for (int e = tid; e < total; e += 256) {
+      const int pair = e / bb, loc = e - pair * bb, i = loc % b, jx = loc / b, s0 = pair * 2 * b;
+      double acc = 0;
+      for (int k = 0; k <= i; ++k) acc += Xs[s0 + b + i][s0 + b + k] * Tm[s0 + b + k][s0 + jx];
+      Xs[s0 + b + i][s0 + jx] = -acc;
     }
     __syncthreads();
   }
-  return fail;
+  // write back: L in the lower triangle (incl. diagonal), (L^-1)' in the strictly upper triangle
+  for (int e = tid; e < w * w; e += 256) {
+    const int rr = e % w, cc = e / w;
+    A[(c0 + rr) + (i64)(c0 + cc) * n] = (rr >= cc) ? Ls[rr][cc] : Xs[cc][rr];
+  }
+  if (tid == 0) {
+    if (c0 + w == F) {  // last panel: conditioning test on the last two pivots
+      const double p1 = Ls[w - 1][w - 1];
+      int e1, e2;
+      (void)frexp(p1, &e1);
+      if (F >= 2) {
+        const double p2 = (w >= 2) ? Ls[w - 2][w - 2] : A[(F - 2) + (i64)(F - 2) * n];
+        (void)frexp(p2, &e2);
+        if (!(e2 - e1 < 12)) fail = 1;
+      } else if (!(e1 > -12)) {
+        fail = 1;
+      }
+    }
+    if (fail) report_failure(status, front);
+  }
 }
 
-// panel step kb, part 1: row tiles below the diagonal tile  X <- X * L_kk^-T
+// first diagonal tile of every big front of a level
+__global__ void __launch_bounds__(256) big_potrf0_kernel(const BigDesc* descs, double* arena, DevStatus* status) {
+  const BigDesc d = descs[blockIdx.x];
+  __shared__ double Ls[T][T + 1], Xs[T][T + 1], Tm[T][T + 1];
+  double* A = arena + d.off;
+  const int n = d.N, w = min(T, d.F);
+  for (int e = threadIdx.x; e < T * T; e += 256) {
+    const int r = e % T, c = e / T;
+    Ls[r][c] = (r < w && c <= r) ? A[r + (i64)c * n] : 0.0;
+  }
+  __syncthreads();
+  diag_tile_factor(A, n, d.F, 0, w, Ls, Xs, Tm, status, d.front);
+}
+
+// panel step kb, part 1: rows below the diagonal tile  X <- X * L_kk^-T, as a tile product with the
+// explicit inverse parked in the diagonal tile's upper triangle.  One block per 32 rows.
 __global__ void __launch_bounds__(256) big_trsm_kernel(const BigDesc* descs, int kb, double* arena) {
   const BigDesc d = descs[blockIdx.y];
   const int n = d.N, F = d.F, c0 = kb * T;
@@ -739,39 +833,30 @@ __global__ void __launch_bounds__(256) big_trsm_kernel(const BigDesc* descs, int
   if (r0 >= n) return;
   const int h = min(T, n - r0);
   double* A = arena + d.off;
-  __shared__ double D[T][T + 1], Li[T][T + 1], X[T][T + 1];
+  __shared__ double Li[T][T + 1], X[T][T + 1];
   const int tid = threadIdx.x;
   for (int e = tid; e < w * w; e += 256) {
-    const int r = e % w, c = e / w;
-    D[r][c] = (r >= c) ? A[(c0 + r) + (i64)(c0 + c) * n] : 0.0;
+    const int k = e % w, c = e / w;  // Li[c][k] = (L^-1)[c][k], k <= c
+    double v = 0.0;
+    if (k < c) v = A[(c0 + k) + (i64)(c0 + c) * n];
+    else if (k == c) v = 1.0 / A[(c0 + c) + (i64)(c0 + c) * n];
+    Li[c][k] = v;
   }
   for (int e = tid; e < h * w; e += 256) {
     const int r = e % h, c = e / h;
     X[r][c] = A[(r0 + r) + (i64)(c0 + c) * n];
   }
   __syncthreads();
-  lds_tile_potrf(D, w);
-  // Li = D^-1 (lower): thread c solves D y = e_c
-  if (tid < w) {
-    const int c = tid;
-    for (int r = 0; r < w; ++r) Li[r][c] = 0;
-    for (int r = c; r < w; ++r) {
-      double s = (r == c) ? 1.0 : 0.0;
-      for (int k = c; k < r; ++k) s -= D[r][k] * Li[k][c];
-      Li[r][c] = s / D[r][r];
-    }
-  }
-  __syncthreads();
   for (int e = tid; e < h * w; e += 256) {
     const int r = e % h, c = e / h;
-    double s = 0;
-    for (int k = 0; k <= c; ++k) s += X[r][k] * Li[c][k];
-    A[(r0 + r) + (i64)(c0 + c) * n] = s;
+    double acc = 0;
+    for (int k = 0; k <= c; ++k) acc += X[r][k] * Li[c][k];
+    A[(r0 + r) + (i64)(c0 + c) * n] = acc;
   }
 }
 
-// panel step kb, part 2: trailing update C[i,j] -= P_i P_j' over lower tile pairs, plus one extra
-// block per front that factors the diagonal tile for good and checks the pivots.
+// panel step kb, part 2: trailing update C[i,j] -= P_i P_j' over lower tile pairs.  The block of pair
+// (0,0) then factors the NEXT diagonal tile (look-ahead), so each diagonal tile is factored once.
 __global__ void __launch_bounds__(256) big_syrk_kernel(const BigDesc* descs, int kb, double* arena, DevStatus* status) {
   const BigDesc d = descs[blockIdx.y];
   const int n = d.N, F = d.F, c0 = kb * T;
@@ -781,38 +866,10 @@ __global__ void __launch_bounds__(256) big_syrk_kernel(const BigDesc* descs, int
   const int ntile = (n - base + T - 1) / T;
   const int npairs = ntile * (ntile + 1) / 2;
   const int t = blockIdx.x;
+  if (t >= npairs) return;
   double* A = arena + d.off;
   const int tid = threadIdx.x;
-  __shared__ double Pi[T][T + 1], Pj[T][T + 1];
-  if (t == npairs) {
-    for (int e = tid; e < w * w; e += 256) {
-      const int r = e % w, c = e / w;
-      Pi[r][c] = (r >= c) ? A[(c0 + r) + (i64)(c0 + c) * n] : 0.0;
-    }
-    __syncthreads();
-    int fail = lds_tile_potrf(Pi, w);
-    for (int e = tid; e < w * w; e += 256) {
-      const int r = e % w, c = e / w;
-      if (r >= c) A[(c0 + r) + (i64)(c0 + c) * n] = Pi[r][c];
-    }
-    if (tid == 0) {
-      if (base == F) {  // last panel: conditioning test on the last two pivots (cholesky.cpp:145-158)
-        const double p1 = Pi[w - 1][w - 1];
-        int e1, e2;
-        (void)frexp(p1, &e1);
-        if (F >= 2) {
-          const double p2 = (w >= 2) ? Pi[w - 2][w - 2] : A[(F - 2) + (i64)(F - 2) * n];
-          (void)frexp(p2, &e2);
-          if (!(e2 - e1 < 12)) fail = 1;
-        } else if (!(e1 > -12)) {
-          fail = 1;
-        }
-      }
-      if (fail) report_failure(status, d.front);
-    }
-    return;
-  }
-  if (t > npairs) return;
+  __shared__ double Pi[T][T + 1], Pj[T][T + 1], Pk[T][T + 1];
   int i = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
   while ((i + 1) * (i + 2) / 2 <= t) ++i;
   while (i * (i + 1) / 2 > t) --i;
@@ -828,20 +885,40 @@ __global__ void __launch_bounds__(256) big_syrk_kernel(const BigDesc* descs, int
     Pj[r][c] = A[(rj + r) + (i64)(c0 + c) * n];
   }
   __syncthreads();
-  for (int e = tid; e < hi * hj; e += 256) {
+  double outv[4];
+  int cnt = 0;
+  for (int e = tid; e < hi * hj; e += 256, ++cnt) {
     const int r = e % hi, c = e / hi;
-    if (i == j && r < c) continue;
-    double s = 0;
-    for (int k = 0; k < w; ++k) s += Pi[r][k] * Pj[c][k];
-    A[(ri + r) + (i64)(rj + c) * n] -= s;
+    double acc = 0;
+    for (int k = 0; k < w; ++k) acc += Pi[r][k] * Pj[c][k];
+    double v = 0.0;
+    if (!(i == j && r < c)) {
+      v = A[(ri + r) + (i64)(rj + c) * n] - acc;
+      A[(ri + r) + (i64)(rj + c) * n] = v;
+    }
+    outv[cnt & 3] = v;
   }
+  if (t == 0 && base < F) {
+    // look-ahead: this block owns the next diagonal tile; keep its new values in LDS and factor it
+    __syncthreads();
+    cnt = 0;
+    for (int e = tid; e < T * T; e += 256) Pi[e % T][e / T] = 0.0;
+    __syncthreads();
+    for (int e = tid; e < hi * hj; e += 256, ++cnt) Pi[e % hi][e / hi] = outv[cnt & 3];
+    __syncthreads();
+    diag_tile_factor(A, n, F, base, min(T, F - base), Pi, Pj, Pk, status, d.front);
+  }
+}
+
+void launch_big_potrf0(const BigDesc* descs, int count, double* arena, DevStatus* status, hipStream_t st) {
+  if (count) big_potrf0_kernel<<<count, 256, 0, st>>>(descs, arena, status);
 }
 
 void launch_big_step(const DevSymbolic& S, const BigDesc* descs, int count, int kb, int max_row_tiles, int max_pairs,
                      double* arena, DevStatus* status, hipStream_t st) {
   if (!count) return;
   if (max_row_tiles > 0) big_trsm_kernel<<<dim3(max_row_tiles, count), 256, 0, st>>>(descs, kb, arena);
-  big_syrk_kernel<<<dim3(max_pairs + 1, count), 256, 0, st>>>(descs, kb, arena, status);
+  if (max_pairs > 0) big_syrk_kernel<<<dim3(max_pairs, count), 256, 0, st>>>(descs, kb, arena, status);
 }
 
 // Schur complement of a big front -> atomically added into its big parent
@@ -957,6 +1034,7 @@ void launch_dense_partial(double* a, int n, int nf, DevStatus* status, hipStream
   hipMemcpyAsync(d, &h, sizeof(BigDesc), hipMemcpyHostToDevice, st);
   DevSymbolic S{};
   const int steps = (nf + T - 1) / T;
+  launch_big_potrf0(d, 1, a, status, st);
   for (int kb = 0; kb < steps; ++kb) {
     const int c0 = kb * T, w = (nf - c0 < T) ? nf - c0 : T, base = c0 + w;
     const int nt = (n - base + T - 1) / T;

@@ -444,6 +444,7 @@ void dev_factorize(gsx_context* c, double lambda) {
     const BigLevel& B = c->big_level[l];
     if (B.count) {
       if (c->profiling) timer_begin(c, PH_FACTOR_BIG);
+      launch_big_potrf0(c->d_big.p + B.begin, B.count, c->d_arena.p, c->d_status.p, c->stream);
       for (int kb = 0; kb < B.steps; ++kb)
         launch_big_step(c->DS, c->d_big.p + B.begin, B.count, kb, B.row_tiles[kb], B.pairs[kb], c->d_arena.p,
                         c->d_status.p, c->stream);
