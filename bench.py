@@ -54,17 +54,23 @@ def make_problem(name, seed):
     return datasets.synth_manhattan_pose2(100000, seed=seed), "nd"
 
 
-def front_split(be, arrays, small_max_n=140):
+def front_split(be, arrays, small_max_n=140, leaf_max_f=16):
     """Algorithmic bytes / flops of the factorization split by kernel class."""
     parent, fronts = be.get_tree()
     dims = arrays.var_dims
-    out = dict(small_bytes=0.0, big_bytes=0.0, small_flops=0.0, big_flops=0.0, n_small=0, n_big=0, lpanel_bytes=0.0)
-    for fv, sv in fronts:
+    has_child = np.zeros(len(fronts), bool)
+    for p in parent:
+        if p >= 0:
+            has_child[p] = True
+    out = dict(lpanel_bytes=0.0)
+    for k in ("leaf", "small", "big"):
+        out.update({k + "_bytes": 0.0, k + "_flops": 0.0, "n_" + k: 0})
+    for i, (fv, sv) in enumerate(fronts):
         f = float(dims[fv].sum())
         s1 = float(dims[sv].sum()) + 1.0
         n = f + s1
         fl = f ** 3 / 3 + f * f * s1 + f * s1 * s1
-        k = "small" if n <= small_max_n else "big"
+        k = "big" if n > small_max_n else ("leaf" if (not has_child[i] and f <= leaf_max_f) else "small")
         out[k + "_bytes"] += 8.0 * n * n
         out[k + "_flops"] += fl
         out["n_" + k] += 1
@@ -133,21 +139,25 @@ def main():
         step()
     small_ms, small_n = be.kernel_time("factor_small")
     big_ms, big_n = be.kernel_time("factor_big")
+    leaf_ms, leaf_n = be.kernel_time("factor_leaf")
     st_prof = be.stats()
     be.set_profiling(0)
     split = front_split(be, arrays)
     nfac = max(st_prof["n_factorize"], 1)
     phases = {k: st_prof[k] / nfac for k in ("ms_linearize", "ms_assemble_hessian", "ms_factorize", "ms_backsolve",
                                              "ms_linear_error", "ms_retract", "ms_error")}
-    tot_small, tot_big = small_ms * small_n / nfac, big_ms * big_n / nfac
-    if tot_small >= tot_big:
+    tot_small, tot_big, tot_leaf = small_ms * small_n / nfac, big_ms * big_n / nfac, leaf_ms * leaf_n / nfac
+    if max(tot_small, tot_leaf) >= tot_big:
         # fused assemble + eliminate of the small cliques: HBM-bound (8 (f+s+1)^2 per front,
         # read + written once)
-        per_launch_bytes = split["small_bytes"] * nfac / max(small_n, 1)
-        achieved = per_launch_bytes / (small_ms * 1e-3) / 1e9 if small_ms > 0 else 0.0
-        roofline = dict(kernel="front_small_kernel", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=None, launches_per_factorization=small_n / nfac,
-                        avg_launch_ms=small_ms, algorithmic_bytes_per_launch=per_launch_bytes)
+        which = "leaf" if tot_leaf >= tot_small else "small"
+        k_ms, k_n = (leaf_ms, leaf_n) if which == "leaf" else (small_ms, small_n)
+        per_launch_bytes = split[which + "_bytes"] * nfac / max(k_n, 1)
+        achieved = per_launch_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        roofline = dict(kernel="front_%s_kernel" % which, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS,
+                        unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None,
+                        launches_per_factorization=k_n / nfac, avg_launch_ms=k_ms,
+                        algorithmic_bytes_per_launch=per_launch_bytes)
     else:
         per_launch_flops = split["big_flops"] * nfac / max(big_n, 1)
         achieved = per_launch_flops / (big_ms * 1e-3) / 1e12 if big_ms > 0 else 0.0
@@ -164,7 +174,7 @@ def main():
                    "lambda": lam, "replicas": world},
         "ms_per_linear_solve": ms_solve,
         "phases_ms": phases,
-        "factor_small_ms": tot_small, "factor_big_ms": tot_big,
+        "factor_leaf_ms": tot_leaf, "factor_small_ms": tot_small, "factor_big_ms": tot_big,
         "symbolic": {k: st[k] for k in ("n_fronts", "n_levels", "max_front_dim", "max_front_rows", "n_small_fronts",
                                         "n_big_fronts", "factor_flops", "front_bytes", "lpanel_bytes",
                                         "jacobian_bytes", "hessian_bytes", "total_dim")},

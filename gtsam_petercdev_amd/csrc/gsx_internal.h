@@ -12,6 +12,8 @@ namespace gsx {
 // global-memory path.  n = frontal + separator + 1 (rhs) scalar rows.
 constexpr int kSmallMaxN = 140;     // 140^2 * 8 B = 156.8 KB <= 160 KB LDS
 constexpr int kTile = 32;           // tile edge of the blocked big-front path
+constexpr int kGatherChunk = 96;    // sources per gather segment (one wave)
+constexpr int kLeafMaxF = 16;      // leaf cliques with at most this many frontal scalars use the panel-only kernel
 
 struct HostProblem {
   int n_vars = 0, n_factors = 0;
@@ -58,7 +60,22 @@ struct Symbolic {
   std::vector<int> sched;            // front ids
   std::vector<int> lvl_ptr;          // level -> range in sched (size n_levels+1)
   std::vector<int> lvl_small_end;    // level -> end of the small (LDS) fronts inside the level range
+  std::vector<int> lvl_leaf_end;     // level 0 only: end of the leaf-kernel fronts (no children, F <= kLeafMaxF)
   int n_levels = 0;
+  // deterministic extend-add into BIG parents: one task per destination block (parent var pair),
+  // with the list of source blocks (child Schur-complement blocks) in child order
+  std::vector<int64_t> gt_dst;       // task -> arena offset of the destination block (top-left entry)
+  std::vector<int> gt_ld, gt_dims;   // destination leading dimension; dB | dA << 8 | diag << 16
+  std::vector<int64_t> gt_ptr;       // task -> range in the source arrays (size n_tasks + 1)
+  std::vector<int> gs_child, gs_loc; // source: child front id, offset of the block inside the child's front
+  std::vector<int> gt_lvl_ptr;       // level of the PARENT -> task range (size n_levels + 1)
+  // segments of the source lists (one wave each) and the multi-segment tasks that need a combine pass
+  std::vector<int> gseg_task, gseg_slot;          // segment -> task, scratch slot (-1: adds straight to dst)
+  std::vector<int64_t> gseg_begin, gseg_end;      // segment -> source range
+  std::vector<int> gseg_lvl_ptr;                  // level -> segment range
+  std::vector<int> gm_task, gm_slot, gm_nslots;   // multi-segment task -> first slot, number of slots
+  std::vector<int> gm_lvl_ptr;                    // level -> multi-task range
+  int g_max_slots = 0;                            // scratch slots needed (x 128 doubles), reused per level
   // stats
   double flops = 0, front_bytes = 0, lpanel_bytes = 0;
   int64_t max_F = 0, max_rows = 0, n_small = 0, n_big = 0;

@@ -73,8 +73,15 @@ void launch_big_init(const DevProblem& P, const DevSymbolic& S, const BigDesc* d
 void launch_big_potrf0(const BigDesc* descs, int count, double* arena, DevStatus* status, hipStream_t st);
 void launch_big_step(const DevSymbolic& S, const BigDesc* descs, int count, int kb, int max_row_tiles,
                      int max_pairs, double* arena, DevStatus* status, hipStream_t st);
-void launch_big_scatter(const DevSymbolic& S, const BigDesc* descs, int count, int max_s1, double* arena,
-                        hipStream_t st);
+void launch_front_leaf(const DevProblem& P, const DevSymbolic& S, const int* ids, int count, int max_panel, int threads,
+                       const double* H, const double* damp, const double* scalars, double* arena, DevStatus* status,
+                       hipStream_t st);
+struct GatherArgs {
+  const i64 *gt_dst, *gs_off, *seg_begin, *seg_end;
+  const int *gt_ld, *gt_dims, *gs_ld, *seg_task, *seg_slot, *gm_task, *gm_slot, *gm_nslots;
+  double* scratch;  // slots x 128 doubles
+};
+void launch_big_gather(const GatherArgs& G, int seg0, int nseg, int m0, int nm, double* arena, hipStream_t st);
 void launch_backsolve(const DevSymbolic& S, const int* ids, int count, int threads, int max_n, const double* arena,
                       double* delta, DevStatus* status, hipStream_t st);
 void launch_set_scalar(double* scalars, int slot, double v, hipStream_t st);

@@ -593,9 +593,8 @@ __device__ inline void report_failure(DevStatus* status, int front) {
 //   2. extend-add of the children's Schur complements, in child order        [updateHessian of child factors]
 //   3. partial Cholesky                                                      [choleskyPartial]
 //   4. L panel -> arena (kept for back-substitution); Schur complement -> arena (pulled by a small
-//      parent) or atomically added into a big parent's front.
+//      parent, gathered by a big one).
 // ---------------------------------------------------------------------------------------------
-__device__ int g_debug_no_push = 0;  // timing experiments only (GSX_DEBUG_NO_PUSH=1): skips the atomic push
 __global__ void front_small_kernel(DevProblem P, DevSymbolic S, const int* ids, const double* H, const double* damp,
                                    const double* scalars, double* arena, DevStatus* status) {
   extern __shared__ double L[];
@@ -641,20 +640,10 @@ __global__ void front_small_kernel(DevProblem P, DevSymbolic S, const int* ids, 
   double* A = arena + off;
   for (int c = wave; c < F; c += nw)
     for (int r = c + lane; r < n; r += 64) A[r + (i64)c * n] = L[r + c * n];
-  const int parent = S.fr_parent[f];
+  // Schur complement -> own arena square (a small parent pulls it, a big parent gathers it)
   const int s1 = n - F;
-  if (parent >= 0 && S.fr_N[parent] > kSmallMaxN && !g_debug_no_push) {
-    const int* pm = S.cmap + S.cmap_ptr[f];
-    const int pn = S.fr_N[parent];
-    double* PA = arena + S.fr_off[parent];
-    for (int col = wave; col < s1; col += nw) {
-      const i64 pc = (i64)pm[col] * pn;
-      for (int r = col + lane; r < s1; r += 64) unsafeAtomicAdd(&PA[pm[r] + pc], L[(F + r) + (F + col) * n]);
-    }
-  } else {
-    for (int col = wave; col < s1; col += nw)
-      for (int r = col + lane; r < s1; r += 64) A[(F + r) + (i64)(F + col) * n] = L[(F + r) + (F + col) * n];
-  }
+  for (int col = wave; col < s1; col += nw)
+    for (int r = col + lane; r < s1; r += 64) A[(F + r) + (i64)(F + col) * n] = L[(F + r) + (F + col) * n];
 }
 
 void launch_front_small(const DevProblem& P, const DevSymbolic& S, const int* ids, int count, int max_n, int threads,
@@ -663,15 +652,174 @@ void launch_front_small(const DevProblem& P, const DevSymbolic& S, const int* id
   static bool attr = false;
   if (!attr) {
     hipFuncSetAttribute((const void*)front_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (const char* e = getenv("GSX_DEBUG_NO_PUSH")) {
-      int v = atoi(e);
-      hipMemcpyToSymbol(HIP_SYMBOL(g_debug_no_push), &v, sizeof(int));
-    }
     attr = true;
   }
   if (count)
     front_small_kernel<<<count, threads, (size_t)max_n * max_n * sizeof(double), st>>>(P, S, ids, H, damp, scalars,
                                                                                          arena, status);
+}
+
+// ---------------------------------------------------------------------------------------------
+// front_leaf: cliques WITHOUT children and with few frontal scalars (every BAL landmark, most
+// pose-graph leaves).  Only the n x F panel [A; B; g'] lives in LDS: it is filled from the H panels
+// (+ lambda D), factored in place ([L11; L21; d']), written out for back-substitution, and the Schur
+// complement -L21 L21' is formed on the fly as an outer product straight into the arena — no n x n
+// matrix in LDS, no zeroing of it, no trailing-update sweeps (the reference allocates and sweeps the full
+// (F+S+1)^2 augmented Hessian per landmark: HessianFactor.cpp:240-253, cholesky.cpp:108-143).
+// ---------------------------------------------------------------------------------------------
+__global__ void front_leaf_kernel(DevProblem P, DevSymbolic S, const int* ids, const double* H, const double* damp,
+                                  const double* scalars, double* arena, DevStatus* status) {
+  extern __shared__ double Pn[];  // n x F, column-major, ld = n
+  const int f = ids[blockIdx.x];
+  const int n = S.fr_N[f], F = S.fr_F[f];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+  const double lambda = scalars[SC_LAMBDA];
+  for (int e = tid; e < n * F; e += nt) Pn[e] = 0;
+  __syncthreads();
+  const int nfv = S.fr_nfv[f];
+  const int* fv = S.fvars + S.fr_fvar_ptr[f];
+  for (int k = 0; k < nfv; ++k) {
+    const int v = fv[k];
+    const int dA = P.var_dim[v], rows = S.h_rows[v], c0 = S.h_loc[v];
+    const double* hp = H + S.h_off[v];
+    const int* hm = S.hmap + S.hmap_ptr[v];
+    const int toff = P.var_tan_off[v];
+    for (int e = tid; e < rows * dA; e += nt) {
+      const int r = e % rows, j = e / rows;
+      double x = hp[e];
+      if (r == j) x += lambda * damp[toff + j];
+      Pn[hm[r] + (c0 + j) * n] = x;
+    }
+  }
+  __syncthreads();
+  int fail = 0;
+  for (int j = 0; j < F; ++j) {
+    const double p = Pn[j + j * n];
+    if (!(p > 0)) fail = 1;
+    const double s = (p > 0) ? sqrt(p) : 1.0;
+    const double inv = 1.0 / s;
+    __syncthreads();
+    for (int r = j + tid; r < n; r += nt) Pn[r + j * n] = (r == j) ? s : Pn[r + j * n] * inv;
+    __syncthreads();
+    for (int c = j + 1 + wave; c < F; c += nw) {
+      const double lc = Pn[c + j * n];
+      for (int r = c + lane; r < n; r += 64) Pn[r + c * n] -= Pn[r + j * n] * lc;
+    }
+    __syncthreads();
+  }
+  if (F >= 2) {  // conditioning test on the last two pivots — cholesky.cpp:145-158
+    int e2, e1;
+    (void)frexp(Pn[(F - 2) + (F - 2) * n], &e2);
+    (void)frexp(Pn[(F - 1) + (F - 1) * n], &e1);
+    if (!(e2 - e1 < 12)) fail = 1;
+  } else {
+    int e1;
+    (void)frexp(Pn[0], &e1);
+    if (!(e1 > -12)) fail = 1;
+  }
+  if (fail && tid == 0) report_failure(status, f);
+  double* A = arena + S.fr_off[f];
+  for (int c = wave; c < F; c += nw)
+    for (int r = c + lane; r < n; r += 64) A[r + (i64)c * n] = Pn[r + c * n];
+  const int s1 = n - F;
+  for (int col = wave; col < s1; col += nw) {
+    double* out = A + (i64)(F + col) * n + F;
+    for (int r = col + lane; r < s1; r += 64) {
+      double acc = 0;
+      for (int k = 0; k < F; ++k) acc += Pn[F + r + k * n] * Pn[F + col + k * n];
+      out[r] = -acc;
+    }
+  }
+}
+
+void launch_front_leaf(const DevProblem& P, const DevSymbolic& S, const int* ids, int count, int max_panel, int threads,
+                       const double* H, const double* damp, const double* scalars, double* arena, DevStatus* status,
+                       hipStream_t st) {
+  if (count)
+    front_leaf_kernel<<<count, threads, (size_t)max_panel * sizeof(double), st>>>(P, S, ids, H, damp, scalars, arena,
+                                                                                   status);
+}
+
+// ---------------------------------------------------------------------------------------------
+// big_gather: deterministic extend-add into big parents.  A task = one destination block (a pair of
+// parent variables) with the list, in child order, of the matching blocks of the children's Schur
+// complements (built once by the symbolic analysis).  Lists are cut into segments of <= 96 sources,
+// one wave each (two block entries per lane, four loads in flight).  A single-segment task adds its
+// sum straight into the pre-initialised front; a multi-segment task parks partial sums in scratch
+// slots that the combine pass adds in slot order.  No atomics: bitwise reproducible.
+// (HessianFactor::updateHessian of the children's remaining factors,
+//  gtsam/linear/HessianFactor.cpp:349-373, turned into a gather.)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) big_gather_seg_kernel(GatherArgs G, int seg0, int nseg, double* arena) {
+  const int lane = threadIdx.x & 63;
+  const int sw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (sw >= nseg) return;
+  const int sg = seg0 + sw;
+  const int t = G.seg_task[sg], slot = G.seg_slot[sg];
+  const int dims = G.gt_dims[t], dB = dims & 255, dA = (dims >> 8) & 255, diag = dims >> 16;
+  const int ld = G.gt_ld[t], ne = dB * dA;
+  double* dst = arena + G.gt_dst[t];
+  const i64 s0 = G.seg_begin[sg], s1 = G.seg_end[sg];
+  for (int eb = 0; eb < ne; eb += 128) {
+    const int ea = eb + lane, ebb = eb + 64 + lane;
+    const int ia = ea % dB, ja = ea / dB, ib = ebb % dB, jb = ebb / dB;
+    const bool act_a = (ea < ne) && !(diag && ia < ja), act_b = (ebb < ne) && !(diag && ib < jb);
+    double acc_a = 0, acc_b = 0;
+    i64 s = s0;
+    for (; s + 2 <= s1; s += 2) {
+      const i64 o0 = G.gs_off[s], o1 = G.gs_off[s + 1];
+      const i64 l0 = G.gs_ld[s], l1 = G.gs_ld[s + 1];
+      double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+      if (act_a) {
+        a0 = arena[o0 + ia + ja * l0];
+        a1 = arena[o1 + ia + ja * l1];
+      }
+      if (act_b) {
+        b0 = arena[o0 + ib + jb * l0];
+        b1 = arena[o1 + ib + jb * l1];
+      }
+      acc_a += a0;
+      acc_a += a1;
+      acc_b += b0;
+      acc_b += b1;
+    }
+    for (; s < s1; ++s) {
+      const i64 o0 = G.gs_off[s], l0 = G.gs_ld[s];
+      if (act_a) acc_a += arena[o0 + ia + ja * l0];
+      if (act_b) acc_b += arena[o0 + ib + jb * l0];
+    }
+    if (slot < 0) {
+      if (act_a) dst[ia + (i64)ja * ld] += acc_a;
+      if (act_b) dst[ib + (i64)jb * ld] += acc_b;
+    } else {  // ne <= 128 guaranteed for split tasks
+      G.scratch[(i64)slot * 128 + lane] = acc_a;
+      G.scratch[(i64)slot * 128 + 64 + lane] = acc_b;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) big_gather_combine_kernel(GatherArgs G, int m0, int nm, double* arena) {
+  const int lane = threadIdx.x & 63;
+  const int mw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (mw >= nm) return;
+  const int t = G.gm_task[m0 + mw], slot0 = G.gm_slot[m0 + mw], ns = G.gm_nslots[m0 + mw];
+  const int dims = G.gt_dims[t], dB = dims & 255, dA = (dims >> 8) & 255, diag = dims >> 16;
+  const int ld = G.gt_ld[t], ne = dB * dA;
+  double* dst = arena + G.gt_dst[t];
+  for (int half = 0; half < 2; ++half) {
+    const int e = half * 64 + lane;
+    const int i = e % dB, j = e / dB;
+    if (e >= ne || (diag && i < j)) continue;
+    double acc = 0;
+    for (int k = 0; k < ns; ++k) acc += G.scratch[(i64)(slot0 + k) * 128 + e];
+    dst[i + (i64)j * ld] += acc;
+  }
+}
+
+void launch_big_gather(const GatherArgs& G, int seg0, int nseg, int m0, int nm, double* arena, hipStream_t st) {
+  if (nseg > 0) big_gather_seg_kernel<<<(nseg + 3) / 4, 256, 0, st>>>(G, seg0, nseg, arena);
+  if (nm > 0) big_gather_combine_kernel<<<(nm + 3) / 4, 256, 0, st>>>(G, m0, nm, arena);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -919,29 +1067,6 @@ void launch_big_step(const DevSymbolic& S, const BigDesc* descs, int count, int 
   if (!count) return;
   if (max_row_tiles > 0) big_trsm_kernel<<<dim3(max_row_tiles, count), 256, 0, st>>>(descs, kb, arena);
   if (max_pairs > 0) big_syrk_kernel<<<dim3(max_pairs, count), 256, 0, st>>>(descs, kb, arena, status);
-}
-
-// Schur complement of a big front -> atomically added into its big parent
-__global__ void __launch_bounds__(256) big_scatter_kernel(DevSymbolic S, const BigDesc* descs, double* arena) {
-  const BigDesc d = descs[blockIdx.y];
-  if (d.parent < 0 || S.fr_N[d.parent] <= kSmallMaxN) return;
-  const int n = d.N, F = d.F, s1 = n - F;
-  const int* pm = S.cmap + S.cmap_ptr[d.front];
-  const int pn = S.fr_N[d.parent];
-  double* PA = arena + S.fr_off[d.parent];
-  const double* A = arena + d.off;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int col = blockIdx.x * 4 + wave; col < s1; col += gridDim.x * 4) {
-    const i64 pc = (i64)pm[col] * pn;
-    for (int r = col + lane; r < s1; r += 64) unsafeAtomicAdd(&PA[pm[r] + pc], A[(F + r) + (i64)(F + col) * n]);
-  }
-}
-void launch_big_scatter(const DevSymbolic& S, const BigDesc* descs, int count, int max_s1, double* arena,
-                        hipStream_t st) {
-  if (!count) return;
-  int bx = (max_s1 + 3) / 4;
-  bx = bx < 1 ? 1 : (bx > 1024 ? 1024 : bx);
-  big_scatter_kernel<<<dim3(bx, count), 256, 0, st>>>(S, descs, arena);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -55,6 +55,7 @@ struct DevBuf {
 
 struct SmallLaunch {
   int begin, count, max_n, threads;
+  int max_panel = 0;  // leaf launches: largest n*F of the group (LDS doubles)
 };
 struct BigLevel {
   int begin = 0, count = 0, steps = 0, max_s1 = 0;
@@ -62,9 +63,9 @@ struct BigLevel {
 };
 
 enum Phase { PH_LINEARIZE, PH_ASSEMBLE_H, PH_FACTORIZE, PH_BACKSOLVE, PH_LINERR, PH_RETRACT, PH_ERROR,
-             PH_FACTOR_SMALL, PH_FACTOR_BIG, PH_COUNT };
+             PH_FACTOR_SMALL, PH_FACTOR_BIG, PH_FACTOR_LEAF, PH_COUNT };
 const char* kPhaseNames[PH_COUNT] = {"linearize", "assemble_hessian", "factorize", "backsolve", "linear_error",
-                                     "retract", "error", "factor_small", "factor_big"};
+                                     "retract", "error", "factor_small", "factor_big", "factor_leaf"};
 
 struct Timer {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, pool;
@@ -100,6 +101,11 @@ struct gsx_context {
   DevSymbolic DS{};
   // schedule
   std::vector<std::vector<SmallLaunch>> small_launch;  // per level
+  std::vector<std::vector<SmallLaunch>> leaf_launch;   // per level (panel-only leaf kernel)
+  DevBuf<i64> d_gt_dst, d_gs_off, d_seg_begin, d_seg_end;  // gather tasks / segments for big parents
+  DevBuf<int> d_gt_ld, d_gt_dims, d_gs_ld, d_seg_task, d_seg_slot, d_gm_task, d_gm_slot, d_gm_nslots;
+  DevBuf<double> d_gscratch;
+  GatherArgs GA{};
   std::vector<BigLevel> big_level;
   std::vector<BigDesc> big_descs;
   int big_max_n = 0, big_max_nfv = 0;
@@ -334,8 +340,22 @@ gsx_status upload_symbolic(gsx_context* c) {
   c->big_level.assign(S.n_levels, BigLevel());
   c->big_descs.clear();
   c->big_max_n = c->big_max_nfv = 0;
+  c->leaf_launch.assign(S.n_levels, {});
   for (int l = 0; l < S.n_levels; ++l) {
     int i = S.lvl_ptr[l];
+    // leaf-kernel fronts: sorted by (F, N); a launch = same F, panel size within 1.5x
+    const int le = S.lvl_leaf_end[l];
+    while (i < le) {
+      const int F0 = S.F[S.sched[i]], n0 = std::max(S.N[S.sched[i]], 8);
+      int j = i, maxp = 0, maxn = 0;
+      while (j < le && S.F[S.sched[j]] == F0 && S.N[S.sched[j]] * 2 <= n0 * 3) {
+        maxp = std::max(maxp, S.N[S.sched[j]] * S.F[S.sched[j]]);
+        maxn = std::max(maxn, S.N[S.sched[j]]);
+        ++j;
+      }
+      c->leaf_launch[l].push_back({i, j - i, maxn, maxn <= 72 ? 64 : (maxn <= 110 ? 128 : 256), maxp});
+      i = j;
+    }
     const int se = S.lvl_small_end[l];
     while (i < se) {
       const int thr = small_threads_for(S.N[S.sched[i]]);
@@ -373,6 +393,32 @@ gsx_status upload_symbolic(gsx_context* c) {
     }
   }
   HIPCHK(c, c->d_big.upload(c->big_descs, st));
+  {
+    // gather sources as absolute arena offsets + leading dimension (no dependent metadata loads in the kernel)
+    std::vector<i64> gs_off(S.gs_child.size());
+    std::vector<int> gs_ld(S.gs_child.size());
+    for (size_t i = 0; i < S.gs_child.size(); ++i) {
+      gs_off[i] = (i64)S.off[S.gs_child[i]] + S.gs_loc[i];
+      gs_ld[i] = S.N[S.gs_child[i]];
+    }
+    HIPCHK(c, c->d_gt_dst.upload(std::vector<i64>(S.gt_dst.begin(), S.gt_dst.end()), st));
+    HIPCHK(c, c->d_gt_ld.upload(S.gt_ld, st));
+    HIPCHK(c, c->d_gt_dims.upload(S.gt_dims, st));
+    HIPCHK(c, c->d_gs_off.upload(gs_off, st));
+    HIPCHK(c, c->d_gs_ld.upload(gs_ld, st));
+    HIPCHK(c, c->d_seg_begin.upload(std::vector<i64>(S.gseg_begin.begin(), S.gseg_begin.end()), st));
+    HIPCHK(c, c->d_seg_end.upload(std::vector<i64>(S.gseg_end.begin(), S.gseg_end.end()), st));
+    HIPCHK(c, c->d_seg_task.upload(S.gseg_task, st));
+    HIPCHK(c, c->d_seg_slot.upload(S.gseg_slot, st));
+    HIPCHK(c, c->d_gm_task.upload(S.gm_task, st));
+    HIPCHK(c, c->d_gm_slot.upload(S.gm_slot, st));
+    HIPCHK(c, c->d_gm_nslots.upload(S.gm_nslots, st));
+    HIPCHK(c, c->d_gscratch.alloc((size_t)std::max(S.g_max_slots, 1) * 128));
+    HIPCHK(c, hipStreamSynchronize(st));
+    c->GA = GatherArgs{c->d_gt_dst.p, c->d_gs_off.p, c->d_seg_begin.p, c->d_seg_end.p, c->d_gt_ld.p, c->d_gt_dims.p,
+                       c->d_gs_ld.p, c->d_seg_task.p, c->d_seg_slot.p, c->d_gm_task.p, c->d_gm_slot.p,
+                       c->d_gm_nslots.p, c->d_gscratch.p};
+  }
   DevSymbolic& D = c->DS;
   D.n_fronts = S.n_fronts;
   D.fr_off = c->d_fr_off.p; D.fr_N = c->d_fr_N.p; D.fr_F = c->d_fr_F.p; D.fr_nfv = c->d_fr_nfv.p;
@@ -435,6 +481,12 @@ void dev_factorize(gsx_context* c, double lambda) {
     launch_big_init(c->DP, c->DS, c->d_big.p, (int)c->big_descs.size(), c->big_max_n, c->big_max_nfv, c->d_H.p,
                     c->d_damp.p, c->d_scalars.p, c->d_arena.p, c->stream);
   for (int l = 0; l < S.n_levels; ++l) {
+    for (const SmallLaunch& sl : c->leaf_launch[l]) {
+      if (c->profiling) timer_begin(c, PH_FACTOR_LEAF);
+      launch_front_leaf(c->DP, c->DS, c->d_sched.p + sl.begin, sl.count, sl.max_panel, sl.threads, c->d_H.p,
+                        c->d_damp.p, c->d_scalars.p, c->d_arena.p, c->d_status.p, c->stream);
+      if (c->profiling) timer_end(c, PH_FACTOR_LEAF);
+    }
     for (const SmallLaunch& sl : c->small_launch[l]) {
       if (c->profiling) timer_begin(c, PH_FACTOR_SMALL);
       launch_front_small(c->DP, c->DS, c->d_sched.p + sl.begin, sl.count, sl.max_n, sl.threads, c->d_H.p, c->d_damp.p,
@@ -444,11 +496,13 @@ void dev_factorize(gsx_context* c, double lambda) {
     const BigLevel& B = c->big_level[l];
     if (B.count) {
       if (c->profiling) timer_begin(c, PH_FACTOR_BIG);
+      // children of every earlier level are complete: deterministic extend-add into this level's big fronts
+      launch_big_gather(c->GA, S.gseg_lvl_ptr[l], S.gseg_lvl_ptr[l + 1] - S.gseg_lvl_ptr[l], S.gm_lvl_ptr[l],
+                        S.gm_lvl_ptr[l + 1] - S.gm_lvl_ptr[l], c->d_arena.p, c->stream);
       launch_big_potrf0(c->d_big.p + B.begin, B.count, c->d_arena.p, c->d_status.p, c->stream);
       for (int kb = 0; kb < B.steps; ++kb)
         launch_big_step(c->DS, c->d_big.p + B.begin, B.count, kb, B.row_tiles[kb], B.pairs[kb], c->d_arena.p,
                         c->d_status.p, c->stream);
-      launch_big_scatter(c->DS, c->d_big.p + B.begin, B.count, B.max_s1, c->d_arena.p, c->stream);
       if (c->profiling) timer_end(c, PH_FACTOR_BIG);
     }
   }
@@ -469,6 +523,9 @@ void dev_backsolve(gsx_context* c) {
     }
     for (const SmallLaunch& sl : c->small_launch[l])
       launch_backsolve(c->DS, c->d_sched.p + sl.begin, sl.count, sl.max_n <= 48 ? 64 : 256, sl.max_n, c->d_arena.p,
+                       c->d_delta.p, c->d_status.p, c->stream);
+    for (const SmallLaunch& sl : c->leaf_launch[l])
+      launch_backsolve(c->DS, c->d_sched.p + sl.begin, sl.count, sl.max_n <= 72 ? 64 : 256, sl.max_n, c->d_arena.p,
                        c->d_delta.p, c->d_status.p, c->stream);
   }
   timer_end(c, PH_BACKSOLVE);

@@ -358,23 +358,146 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
       for (int k = S.fvar_ptr[f]; k < S.fvar_ptr[f + 1]; ++k) loc[S.fvars[k]] = -1;
     }
   }
-  // ---- schedule: by level, small (LDS) fronts first sorted by N, then big fronts -------------------------
+  // ---- schedule: by level; inside a level: leaf-kernel fronts, other small (LDS) fronts by N, big fronts ----
+  auto cls = [&](int f) {
+    if (S.N[f] > kSmallMaxN) return 2;
+    if (S.child_ptr[f + 1] == S.child_ptr[f] && S.F[f] <= kLeafMaxF) return 0;
+    return 1;
+  };
   S.sched.resize(nfr);
   std::iota(S.sched.begin(), S.sched.end(), 0);
   std::stable_sort(S.sched.begin(), S.sched.end(), [&](int a, int b) {
     if (S.level[a] != S.level[b]) return S.level[a] < S.level[b];
-    const bool ba = S.N[a] > kSmallMaxN, bb = S.N[b] > kSmallMaxN;
-    if (ba != bb) return !ba;
+    const int ca = cls(a), cb = cls(b);
+    if (ca != cb) return ca < cb;
+    if (ca == 0 && S.F[a] != S.F[b]) return S.F[a] < S.F[b];
     return S.N[a] < S.N[b];
   });
   S.lvl_ptr.assign(S.n_levels + 1, 0);
   S.lvl_small_end.assign(S.n_levels, 0);
+  S.lvl_leaf_end.assign(S.n_levels, 0);
   for (int f = 0; f < nfr; ++f) S.lvl_ptr[S.level[f] + 1]++;
   for (int l = 0; l < S.n_levels; ++l) S.lvl_ptr[l + 1] += S.lvl_ptr[l];
   for (int l = 0; l < S.n_levels; ++l) {
     int e = S.lvl_ptr[l];
-    while (e < S.lvl_ptr[l + 1] && S.N[S.sched[e]] <= kSmallMaxN) ++e;
+    while (e < S.lvl_ptr[l + 1] && cls(S.sched[e]) == 0) ++e;
+    S.lvl_leaf_end[l] = e;
+    while (e < S.lvl_ptr[l + 1] && cls(S.sched[e]) == 1) ++e;
     S.lvl_small_end[l] = e;
+  }
+  // ---- gather tasks for big parents ------------------------------------------------------------------------
+  {
+    struct Contribution {
+      int level;
+      int64_t dst;
+      int ld, dims, child, loc;
+    };
+    std::vector<Contribution> cs;
+    std::vector<int> lo;  // local scalar offsets of the parent's variables
+    for (int p = 0; p < nfr; ++p) {
+      if (S.N[p] <= kSmallMaxN) continue;
+      // parent local offset of each variable
+      std::vector<std::pair<int, int>> ploc;  // (var, offset)
+      int o = 0;
+      for (int k = S.fvar_ptr[p]; k < S.fvar_ptr[p + 1]; ++k) {
+        ploc.push_back({S.fvars[k], o});
+        o += P.dims[S.fvars[k]];
+      }
+      for (int ci = S.child_ptr[p]; ci < S.child_ptr[p + 1]; ++ci) {
+        const int ch = S.children[ci];
+        const int Fc = S.F[ch], Nc = S.N[ch];
+        // child's separator blocks: (parent offset, child offset, dim); the rhs is the last block
+        std::vector<int> poff, coff, dim;
+        int co = 0;
+        size_t pi = 0;
+        for (int k = S.fvar_ptr[ch] + nfv[ch]; k < S.fvar_ptr[ch + 1]; ++k) {
+          const int u = S.fvars[k];
+          while (pi < ploc.size() && ploc[pi].first != u) ++pi;  // both lists are in elimination order
+          if (pi == ploc.size()) {
+            err = "internal: child separator variable missing from big parent";
+            return GSX_E_INVALID;
+          }
+          poff.push_back(ploc[pi].second);
+          coff.push_back(co);
+          dim.push_back(P.dims[u]);
+          co += P.dims[u];
+        }
+        poff.push_back(S.N[p] - 1);
+        coff.push_back(co);
+        dim.push_back(1);
+        const int nb = (int)dim.size();
+        for (int a = 0; a < nb; ++a)
+          for (int b = a; b < nb; ++b) {  // block (row b, col a), b >= a
+            Contribution c;
+            c.level = S.level[p];
+            c.dst = S.off[p] + poff[b] + (int64_t)poff[a] * S.N[p];
+            c.ld = S.N[p];
+            c.dims = dim[b] | (dim[a] << 8) | ((a == b) ? (1 << 16) : 0);
+            c.child = ch;
+            c.loc = (Fc + coff[b]) + (Fc + coff[a]) * Nc;
+            cs.push_back(c);
+          }
+      }
+    }
+    std::stable_sort(cs.begin(), cs.end(), [](const Contribution& x, const Contribution& y) {
+      if (x.level != y.level) return x.level < y.level;
+      return x.dst < y.dst;
+    });
+    S.gt_lvl_ptr.assign(S.n_levels + 1, 0);
+    S.gs_child.resize(cs.size());
+    S.gs_loc.resize(cs.size());
+    for (size_t i = 0; i < cs.size(); ++i) {
+      if (i == 0 || cs[i].dst != cs[i - 1].dst || cs[i].level != cs[i - 1].level) {
+        S.gt_dst.push_back(cs[i].dst);
+        S.gt_ld.push_back(cs[i].ld);
+        S.gt_dims.push_back(cs[i].dims);
+        S.gt_ptr.push_back((int64_t)i);
+        S.gt_lvl_ptr[cs[i].level + 1]++;
+      }
+      S.gs_child[i] = cs[i].child;
+      S.gs_loc[i] = cs[i].loc;
+    }
+    S.gt_ptr.push_back((int64_t)cs.size());
+    for (int l = 0; l < S.n_levels; ++l) S.gt_lvl_ptr[l + 1] += S.gt_lvl_ptr[l];
+    // Segments: a task's source list is cut into chunks of at most kGatherChunk sources, one wave each.
+    // Single-segment tasks add straight into the destination; multi-segment tasks write partial sums
+    // to scratch slots which a second pass adds in slot order (fixed order => deterministic).
+    S.gseg_lvl_ptr.assign(S.n_levels + 1, 0);
+    S.gm_lvl_ptr.assign(S.n_levels + 1, 0);
+    S.g_max_slots = 0;
+    const int ntasks = (int)S.gt_dst.size();
+    int t = 0;
+    for (int l = 0; l < S.n_levels; ++l) {
+      int slots = 0;
+      for (; t < S.gt_lvl_ptr[l + 1]; ++t) {
+        const int64_t b = S.gt_ptr[t], e = S.gt_ptr[t + 1];
+        const int dB = S.gt_dims[t] & 255, dA = (S.gt_dims[t] >> 8) & 255;
+        const int64_t len = e - b;
+        const bool split = len > kGatherChunk && dB * dA <= 128;
+        if (!split) {
+          S.gseg_task.push_back(t);
+          S.gseg_begin.push_back(b);
+          S.gseg_end.push_back(e);
+          S.gseg_slot.push_back(-1);
+        } else {
+          const int nseg = (int)((len + kGatherChunk - 1) / kGatherChunk);
+          S.gm_task.push_back(t);
+          S.gm_slot.push_back(slots);
+          S.gm_nslots.push_back(nseg);
+          for (int k = 0; k < nseg; ++k) {
+            S.gseg_task.push_back(t);
+            S.gseg_begin.push_back(b + (int64_t)k * kGatherChunk);
+            S.gseg_end.push_back(std::min<int64_t>(e, b + (int64_t)(k + 1) * kGatherChunk));
+            S.gseg_slot.push_back(slots + k);
+          }
+          slots += nseg;
+        }
+      }
+      S.gseg_lvl_ptr[l + 1] = (int)S.gseg_task.size();
+      S.gm_lvl_ptr[l + 1] = (int)S.gm_task.size();
+      S.g_max_slots = std::max(S.g_max_slots, slots);
+    }
+    (void)ntasks;
   }
   return GSX_OK;
 }

@@ -283,7 +283,7 @@ gsx_status gsx_synchronize(gsx_handle h);
 gsx_status gsx_set_profiling(gsx_handle h, int32_t level);
 /* average duration (ms) of the named kernel class over launches since the last
  * gsx_reset_stats, measured with HIP events on the handle's stream; names:
- * "linearize", "assemble_hessian", "factor_small", "factor_big", "backsolve",
+ * "linearize", "assemble_hessian", "factor_leaf", "factor_small", "factor_big", "backsolve",
  * "linear_error", "retract", "error". *launches (may be NULL) = count. */
 gsx_status gsx_kernel_time(gsx_handle h, const char* name, double* avg_ms, int64_t* launches);
 
