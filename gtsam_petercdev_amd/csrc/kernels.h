@@ -17,6 +17,12 @@ struct DevProblem {
   const double *meas, *noise;
 };
 
+// One H-assembly term: panel[dst + i, j] += sum_r J[r, colB + i] * J[r, colA + j] (32-byte record).
+struct TermRec {
+  i64 jac;
+  int m, colA, colB, dB, dst, pad;
+};
+
 // Symbolic tables on the device.
 struct DevSymbolic {
   int n_fronts;
@@ -29,8 +35,8 @@ struct DevSymbolic {
   const i64 *h_off, *hmap_ptr;
   const int *h_rows, *hmap, *h_loc;
   // H assembly terms
-  const i64 *term_ptr, *t_jac;
-  const int *t_m, *t_colA, *t_colB, *t_dB, *t_dst;
+  const i64* term_ptr;
+  const TermRec* terms;
 };
 
 // status words written by the factorization / back-substitution kernels

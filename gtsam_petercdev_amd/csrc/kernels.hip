@@ -451,17 +451,36 @@ __global__ void assemble_h_kernel(DevProblem P, DevSymbolic S, const int* vars, 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
   double* panel = lds + (size_t)wave * psize;
   for (int e = lane; e < psize; e += 64) panel[e] = 0;
+  // Terms are 32-byte records fetched through the scalar path (wave-uniform index); two terms are in
+  // flight per iteration so that their Jacobian loads overlap (the loop is latency-, not issue-bound).
   const i64 t1 = S.term_ptr[v + 1];
-  for (i64 t = S.term_ptr[v] + wave; t < t1; t += nw) {
-    const double* Jf = jac + S.t_jac[t];
-    const int m = S.t_m[t], colA = S.t_colA[t], colB = S.t_colB[t], dB = S.t_dB[t], dst = S.t_dst[t];
-    for (int e = lane; e < dB * dA; e += 64) {
-      const int i = e % dB, j = e / dB;
-      const double* a = Jf + (colB + i) * m;
-      const double* b = Jf + (colA + j) * m;
-      double acc = 0;
-      for (int r = 0; r < m; ++r) acc += a[r] * b[r];
-      panel[dst + i + j * rows] += acc;
+  const int uw = __builtin_amdgcn_readfirstlane(wave);
+  for (i64 t = S.term_ptr[v] + uw; t < t1; t += 2 * nw) {
+    const TermRec ta = S.terms[t];
+    const bool has_b = t + nw < t1;
+    const TermRec tb = S.terms[has_b ? t + nw : t];
+    const double* Ja = jac + ta.jac;
+    const double* Jb = jac + tb.jac;
+    const int nea = ta.dB * dA, neb = has_b ? tb.dB * dA : 0;
+    for (int e = lane; e < max(nea, neb); e += 64) {
+      double acc_a = 0, acc_b = 0;
+      int ia = 0, ja = 0, ib = 0, jb = 0;
+      if (e < nea) {
+        ia = e % ta.dB;
+        ja = e / ta.dB;
+        const double* a = Ja + (ta.colB + ia) * ta.m;
+        const double* b = Ja + (ta.colA + ja) * ta.m;
+        for (int r = 0; r < ta.m; ++r) acc_a += a[r] * b[r];
+      }
+      if (e < neb) {
+        ib = e % tb.dB;
+        jb = e / tb.dB;
+        const double* a = Jb + (tb.colB + ib) * tb.m;
+        const double* b = Jb + (tb.colA + jb) * tb.m;
+        for (int r = 0; r < tb.m; ++r) acc_b += a[r] * b[r];
+      }
+      if (e < nea) panel[ta.dst + ia + ja * rows] += acc_a;
+      if (e < neb) panel[tb.dst + ib + jb * rows] += acc_b;
     }
   }
   __syncthreads();
@@ -482,8 +501,9 @@ __global__ void assemble_h_global_kernel(DevProblem P, DevSymbolic S, const int*
   __syncthreads();
   const i64 t1 = S.term_ptr[v + 1];
   for (i64 t = S.term_ptr[v]; t < t1; ++t) {
-    const double* Jf = jac + S.t_jac[t];
-    const int m = S.t_m[t], colA = S.t_colA[t], colB = S.t_colB[t], dB = S.t_dB[t], dst = S.t_dst[t];
+    const TermRec tr = S.terms[t];
+    const double* Jf = jac + tr.jac;
+    const int m = tr.m, colA = tr.colA, colB = tr.colB, dB = tr.dB, dst = tr.dst;
     for (int e = lane; e < dB * dA; e += 64) {
       const int i = e % dB, j = e / dB;
       double acc = 0;
@@ -767,22 +787,30 @@ __global__ void __launch_bounds__(256) big_gather_seg_kernel(GatherArgs G, int s
     const bool act_a = (ea < ne) && !(diag && ia < ja), act_b = (ebb < ne) && !(diag && ib < jb);
     double acc_a = 0, acc_b = 0;
     i64 s = s0;
-    for (; s + 2 <= s1; s += 2) {
-      const i64 o0 = G.gs_off[s], o1 = G.gs_off[s + 1];
-      const i64 l0 = G.gs_ld[s], l1 = G.gs_ld[s + 1];
-      double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+    for (; s + 4 <= s1; s += 4) {  // 4 sources x 2 entries: up to 8 loads in flight, summed in list order
+      const i64 o0 = G.gs_off[s], o1 = G.gs_off[s + 1], o2 = G.gs_off[s + 2], o3 = G.gs_off[s + 3];
+      const i64 l0 = G.gs_ld[s], l1 = G.gs_ld[s + 1], l2 = G.gs_ld[s + 2], l3 = G.gs_ld[s + 3];
+      double a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
       if (act_a) {
         a0 = arena[o0 + ia + ja * l0];
         a1 = arena[o1 + ia + ja * l1];
+        a2 = arena[o2 + ia + ja * l2];
+        a3 = arena[o3 + ia + ja * l3];
       }
       if (act_b) {
         b0 = arena[o0 + ib + jb * l0];
         b1 = arena[o1 + ib + jb * l1];
+        b2 = arena[o2 + ib + jb * l2];
+        b3 = arena[o3 + ib + jb * l3];
       }
       acc_a += a0;
       acc_a += a1;
+      acc_a += a2;
+      acc_a += a3;
       acc_b += b0;
       acc_b += b1;
+      acc_b += b2;
+      acc_b += b3;
     }
     for (; s < s1; ++s) {
       const i64 o0 = G.gs_off[s], l0 = G.gs_ld[s];
@@ -957,6 +985,8 @@ __device__ __forceinline__ void diag_tile_factor(double* A, int n, int F, int c0
 }
 
 // first diagonal tile of every big front of a level
+// (a single-wave, register-resident v_readlane formulation was measured too: 33 us per tile against 25 us for
+//  this one — hipcc pads every VALU->v_readlane hazard with s_nop and spills the broadcast SGPRs)
 __global__ void __launch_bounds__(256) big_potrf0_kernel(const BigDesc* descs, double* arena, DevStatus* status) {
   const BigDesc d = descs[blockIdx.x];
   __shared__ double Ls[T][T + 1], Xs[T][T + 1], Tm[T][T + 1];

@@ -94,9 +94,10 @@ struct gsx_context {
   int type_count[6] = {0, 0, 0, 0, 0, 0};
   DevProblem DP{};
   // device symbolic
-  DevBuf<i64> d_fr_off, d_cmap_ptr, d_gidx_ptr, d_h_off, d_hmap_ptr, d_term_ptr, d_t_jac;
+  DevBuf<i64> d_fr_off, d_cmap_ptr, d_gidx_ptr, d_h_off, d_hmap_ptr, d_term_ptr;
+  DevBuf<TermRec> d_terms;
   DevBuf<int> d_fr_N, d_fr_F, d_fr_nfv, d_fr_fvar_ptr, d_fvars, d_fr_parent, d_fr_child_ptr, d_children, d_cmap,
-      d_gidx, d_h_rows, d_hmap, d_h_loc, d_t_m, d_t_colA, d_t_colB, d_t_dB, d_t_dst, d_sched, d_hvars;
+      d_gidx, d_h_rows, d_hmap, d_h_loc, d_sched, d_hvars;
   DevBuf<BigDesc> d_big;
   DevSymbolic DS{};
   // schedule
@@ -289,12 +290,13 @@ gsx_status upload_symbolic(gsx_context* c) {
   HIPCHK(c, c->d_hmap.upload(S.hmap, st));
   HIPCHK(c, c->d_h_loc.upload(S.h_loc, st));
   HIPCHK(c, c->d_term_ptr.upload(std::vector<i64>(S.term_ptr.begin(), S.term_ptr.end()), st));
-  HIPCHK(c, c->d_t_jac.upload(std::vector<i64>(S.t_jac.begin(), S.t_jac.end()), st));
-  HIPCHK(c, c->d_t_m.upload(S.t_m, st));
-  HIPCHK(c, c->d_t_colA.upload(S.t_colA, st));
-  HIPCHK(c, c->d_t_colB.upload(S.t_colB, st));
-  HIPCHK(c, c->d_t_dB.upload(S.t_dB, st));
-  HIPCHK(c, c->d_t_dst.upload(S.t_dst, st));
+  {
+    std::vector<TermRec> terms(S.t_jac.size());
+    for (size_t i = 0; i < terms.size(); ++i)
+      terms[i] = TermRec{(i64)S.t_jac[i], S.t_m[i], S.t_colA[i], S.t_colB[i], S.t_dB[i], S.t_dst[i], 0};
+    HIPCHK(c, c->d_terms.upload(terms, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+  }
   HIPCHK(c, c->d_sched.upload(S.sched, st));
   HIPCHK(c, c->d_H.alloc(std::max<int64_t>(S.h_size, 1)));
   HIPCHK(c, c->d_arena.alloc(std::max<int64_t>(S.arena_size, 1)));
@@ -427,8 +429,7 @@ gsx_status upload_symbolic(gsx_context* c) {
   D.cmap_ptr = c->d_cmap_ptr.p; D.gidx_ptr = c->d_gidx_ptr.p; D.cmap = c->d_cmap.p; D.gidx = c->d_gidx.p;
   D.h_off = c->d_h_off.p; D.hmap_ptr = c->d_hmap_ptr.p; D.h_rows = c->d_h_rows.p; D.hmap = c->d_hmap.p;
   D.h_loc = c->d_h_loc.p;
-  D.term_ptr = c->d_term_ptr.p; D.t_jac = c->d_t_jac.p; D.t_m = c->d_t_m.p; D.t_colA = c->d_t_colA.p;
-  D.t_colB = c->d_t_colB.p; D.t_dB = c->d_t_dB.p; D.t_dst = c->d_t_dst.p;
+  D.term_ptr = c->d_term_ptr.p; D.terms = c->d_terms.p;
   HIPCHK(c, hipStreamSynchronize(st));
   c->h_ready = false;
   c->solved = false;
