@@ -895,25 +895,33 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {  // src
   return __hiloint2double(hi, lo);
 }
 
-// Factor the diagonal tile (c0, w) of a big front ONCE, with a 256-thread workgroup.
+// Factor the diagonal tile (c0, w) of a big front ONCE, with an NT-thread workgroup.
 //   Ls (row-major, ld T+1) holds the tile on entry (lower triangle meaningful) and L on exit;
-//   Xs receives L^-1 (recursive doubling: X21 = -X22 (L21 X11), 5 levels of small parallel products);
+//   Xs receives L^-1 (recursive doubling: X21 = -X22 (L21 X11), log2(T) levels of small parallel products);
 //   the front gets L in the lower triangle and (L^-1)' in the strictly upper triangle of the tile, so
-//   that the panel solve and the back-substitution are plain tile products; pivots are checked with
-//   choleskyPartial's failure semantics (gtsam/base/cholesky.cpp:145-158).
-// Potrf: every thread keeps its 4 tile entries in registers; per pivot the only shared traffic is the
-// current column (double-buffered in LDS) => ONE barrier, one LDS round trip and one rsqrt per pivot
+//   that the panel solve is a plain tile product; pivots are checked with choleskyPartial's failure
+//   semantics (gtsam/base/cholesky.cpp:145-158).
+// Potrf: every thread keeps its Q = T*T/NT tile entries in registers; per pivot the only shared traffic is
+// the current column (double-buffered in LDS) => ONE barrier, one LDS round trip and one rsqrt per pivot
 // (a lone wave issues ~1 instruction / 5 cycles on MI355X, so the chain is kept this short on purpose).
-__device__ __forceinline__ void diag_tile_factor(double* A, int n, int F, int c0, int w, double (*Ls)[T + 1],
-                                                 double (*Xs)[T + 1], double (*Tm)[T + 1], DevStatus* status,
-                                                 int front) {
+#ifndef GSX_BIG_NT
+#define GSX_BIG_NT 1024
+#endif
+constexpr int NT = GSX_BIG_NT;    // threads of the big-front kernels
+constexpr int CG = NT / T;        // column groups
+constexpr int Q = T / CG;         // tile entries per thread
+typedef double (*TilePtr)[T + 1];
+constexpr size_t kTileBytes = sizeof(double) * T * (T + 1);
+
+__device__ __forceinline__ void diag_tile_factor(double* A, int n, int F, int c0, int w, TilePtr Ls, TilePtr Xs,
+                                                 TilePtr Tm, DevStatus* status, int front) {
   __shared__ double colb[2][T];
   const int tid = threadIdx.x;
-  const int r = tid & (T - 1), cbase = tid >> 5;  // entries (r, cbase + 8 q), q = 0..3
-  double v[4];
+  const int r = tid % T, cbase = tid / T;  // entries (r, cbase + CG q), q = 0..Q-1
+  double v[Q];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int c = cbase + 8 * q;
+  for (int q = 0; q < Q; ++q) {
+    const int c = cbase + CG * q;
     v[q] = (r >= c && r < w) ? Ls[r][c] : 0.0;
   }
   if (cbase == 0) colb[0][r] = v[0];
@@ -927,8 +935,8 @@ __device__ __forceinline__ void diag_tile_factor(double* A, int n, int F, int c0
     const double inv = (p > 0) ? rsqrt(p) : 1.0;
     const double lr = (r > j) ? cur[r] * inv : 0.0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = cbase + 8 * q;
+    for (int q = 0; q < Q; ++q) {
+      const int c = cbase + CG * q;
       if (c == j) {
         v[q] = (r == j) ? p * inv : lr;  // final L[r][j]
       } else if (c > j && r >= c) {
@@ -939,22 +947,22 @@ __device__ __forceinline__ void diag_tile_factor(double* A, int n, int F, int c0
   }
   __syncthreads();
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int c = cbase + 8 * q;
+  for (int q = 0; q < Q; ++q) {
+    const int c = cbase + CG * q;
     Ls[r][c] = (r >= c) ? v[q] : 0.0;
     Xs[r][c] = (r == c && r < w) ? 1.0 / v[q] : 0.0;
   }
   __syncthreads();
   for (int b = 1; b < T; b <<= 1) {
     const int bb = b * b, total = (T / (2 * b)) * bb;
-    for (int e = tid; e < total; e += 256) {
+    for (int e = tid; e < total; e += NT) {
       const int pair = e / bb, loc = e - pair * bb, i = loc % b, jx = loc / b, s0 = pair * 2 * b;
       double acc = 0;
       for (int k = jx; k < b; ++k) acc += Ls[s0 + b + i][s0 + k] * Xs[s0 + k][s0 + jx];
       Tm[s0 + b + i][s0 + jx] = acc;
     }
     __syncthreads();
-    for (int e = tid; e < total; e += 256) {
+    for (int e = tid; e < total; e += NT) {
       const int pair = e / bb, loc = e - pair * bb, i = loc % b, jx = loc / b, s0 = pair * 2 * b;
       double acc = 0;
       for (int k = 0; k <= i; ++k) acc += Xs[s0 + b + i][s0 + b + k] * Tm[s0 + b + k][s0 + jx];
@@ -963,7 +971,7 @@ __device__ __forceinline__ void diag_tile_factor(double* A, int n, int F, int c0
     __syncthreads();
   }
   // write back: L in the lower triangle (incl. diagonal), (L^-1)' in the strictly upper triangle
-  for (int e = tid; e < w * w; e += 256) {
+  for (int e = tid; e < w * w; e += NT) {
     const int rr = e % w, cc = e / w;
     A[(c0 + rr) + (i64)(c0 + cc) * n] = (rr >= cc) ? Ls[rr][cc] : Xs[cc][rr];
   }
@@ -985,14 +993,15 @@ __device__ __forceinline__ void diag_tile_factor(double* A, int n, int F, int c0
 }
 
 // first diagonal tile of every big front of a level
-// (a single-wave, register-resident v_readlane formulation was measured too: 33 us per tile against 25 us for
-//  this one — hipcc pads every VALU->v_readlane hazard with s_nop and spills the broadcast SGPRs)
-__global__ void __launch_bounds__(256) big_potrf0_kernel(const BigDesc* descs, double* arena, DevStatus* status) {
+// (a single-wave, register-resident v_readlane formulation was measured too: slower — hipcc pads every
+//  VALU->v_readlane hazard with s_nop and spills the broadcast SGPRs)
+__global__ void __launch_bounds__(NT) big_potrf0_kernel(const BigDesc* descs, double* arena, DevStatus* status) {
+  extern __shared__ double dyn_lds[];
+  TilePtr Ls = (TilePtr)dyn_lds, Xs = (TilePtr)(dyn_lds + T * (T + 1)), Tm = (TilePtr)(dyn_lds + 2 * T * (T + 1));
   const BigDesc d = descs[blockIdx.x];
-  __shared__ double Ls[T][T + 1], Xs[T][T + 1], Tm[T][T + 1];
   double* A = arena + d.off;
   const int n = d.N, w = min(T, d.F);
-  for (int e = threadIdx.x; e < T * T; e += 256) {
+  for (int e = threadIdx.x; e < T * T; e += NT) {
     const int r = e % T, c = e / T;
     Ls[r][c] = (r < w && c <= r) ? A[r + (i64)c * n] : 0.0;
   }
@@ -1001,8 +1010,10 @@ __global__ void __launch_bounds__(256) big_potrf0_kernel(const BigDesc* descs, d
 }
 
 // panel step kb, part 1: rows below the diagonal tile  X <- X * L_kk^-T, as a tile product with the
-// explicit inverse parked in the diagonal tile's upper triangle.  One block per 32 rows.
-__global__ void __launch_bounds__(256) big_trsm_kernel(const BigDesc* descs, int kb, double* arena) {
+// explicit inverse parked in the diagonal tile's upper triangle.  One block per T rows.
+__global__ void __launch_bounds__(NT) big_trsm_kernel(const BigDesc* descs, int kb, double* arena) {
+  extern __shared__ double dyn_lds[];
+  TilePtr Li = (TilePtr)dyn_lds, X = (TilePtr)(dyn_lds + T * (T + 1));
   const BigDesc d = descs[blockIdx.y];
   const int n = d.N, F = d.F, c0 = kb * T;
   if (c0 >= F) return;
@@ -1011,21 +1022,20 @@ __global__ void __launch_bounds__(256) big_trsm_kernel(const BigDesc* descs, int
   if (r0 >= n) return;
   const int h = min(T, n - r0);
   double* A = arena + d.off;
-  __shared__ double Li[T][T + 1], X[T][T + 1];
   const int tid = threadIdx.x;
-  for (int e = tid; e < w * w; e += 256) {
+  for (int e = tid; e < w * w; e += NT) {
     const int k = e % w, c = e / w;  // Li[c][k] = (L^-1)[c][k], k <= c
     double v = 0.0;
     if (k < c) v = A[(c0 + k) + (i64)(c0 + c) * n];
     else if (k == c) v = 1.0 / A[(c0 + c) + (i64)(c0 + c) * n];
     Li[c][k] = v;
   }
-  for (int e = tid; e < h * w; e += 256) {
+  for (int e = tid; e < h * w; e += NT) {
     const int r = e % h, c = e / h;
     X[r][c] = A[(r0 + r) + (i64)(c0 + c) * n];
   }
   __syncthreads();
-  for (int e = tid; e < h * w; e += 256) {
+  for (int e = tid; e < h * w; e += NT) {
     const int r = e % h, c = e / h;
     double acc = 0;
     for (int k = 0; k <= c; ++k) acc += X[r][k] * Li[c][k];
@@ -1035,7 +1045,9 @@ __global__ void __launch_bounds__(256) big_trsm_kernel(const BigDesc* descs, int
 
 // panel step kb, part 2: trailing update C[i,j] -= P_i P_j' over lower tile pairs.  The block of pair
 // (0,0) then factors the NEXT diagonal tile (look-ahead), so each diagonal tile is factored once.
-__global__ void __launch_bounds__(256) big_syrk_kernel(const BigDesc* descs, int kb, double* arena, DevStatus* status) {
+__global__ void __launch_bounds__(NT) big_syrk_kernel(const BigDesc* descs, int kb, double* arena, DevStatus* status) {
+  extern __shared__ double dyn_lds[];
+  TilePtr Pi = (TilePtr)dyn_lds, Pj = (TilePtr)(dyn_lds + T * (T + 1)), Pk = (TilePtr)(dyn_lds + 2 * T * (T + 1));
   const BigDesc d = descs[blockIdx.y];
   const int n = d.N, F = d.F, c0 = kb * T;
   if (c0 >= F) return;
@@ -1047,25 +1059,24 @@ __global__ void __launch_bounds__(256) big_syrk_kernel(const BigDesc* descs, int
   if (t >= npairs) return;
   double* A = arena + d.off;
   const int tid = threadIdx.x;
-  __shared__ double Pi[T][T + 1], Pj[T][T + 1], Pk[T][T + 1];
   int i = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
   while ((i + 1) * (i + 2) / 2 <= t) ++i;
   while (i * (i + 1) / 2 > t) --i;
   const int j = t - i * (i + 1) / 2;
   const int ri = base + i * T, rj = base + j * T;
   const int hi = min(T, n - ri), hj = min(T, n - rj);
-  for (int e = tid; e < hi * w; e += 256) {
+  for (int e = tid; e < hi * w; e += NT) {
     const int r = e % hi, c = e / hi;
     Pi[r][c] = A[(ri + r) + (i64)(c0 + c) * n];
   }
-  for (int e = tid; e < hj * w; e += 256) {
+  for (int e = tid; e < hj * w; e += NT) {
     const int r = e % hj, c = e / hj;
     Pj[r][c] = A[(rj + r) + (i64)(c0 + c) * n];
   }
   __syncthreads();
-  double outv[4];
+  double outv[Q];
   int cnt = 0;
-  for (int e = tid; e < hi * hj; e += 256, ++cnt) {
+  for (int e = tid; e < hi * hj; e += NT, ++cnt) {
     const int r = e % hi, c = e / hi;
     double acc = 0;
     for (int k = 0; k < w; ++k) acc += Pi[r][k] * Pj[c][k];
@@ -1074,39 +1085,59 @@ __global__ void __launch_bounds__(256) big_syrk_kernel(const BigDesc* descs, int
       v = A[(ri + r) + (i64)(rj + c) * n] - acc;
       A[(ri + r) + (i64)(rj + c) * n] = v;
     }
-    outv[cnt & 3] = v;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+      if (q == cnt) outv[q] = v;
   }
   if (t == 0 && base < F) {
     // look-ahead: this block owns the next diagonal tile; keep its new values in LDS and factor it
     __syncthreads();
-    cnt = 0;
-    for (int e = tid; e < T * T; e += 256) Pi[e % T][e / T] = 0.0;
+    for (int e = tid; e < T * T; e += NT) Pi[e % T][e / T] = 0.0;
     __syncthreads();
-    for (int e = tid; e < hi * hj; e += 256, ++cnt) Pi[e % hi][e / hi] = outv[cnt & 3];
+    cnt = 0;
+    for (int e = tid; e < hi * hj; e += NT, ++cnt) {
+      double v = 0.0;
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+        if (q == cnt) v = outv[q];
+      Pi[e % hi][e / hi] = v;
+    }
     __syncthreads();
     diag_tile_factor(A, n, F, base, min(T, F - base), Pi, Pj, Pk, status, d.front);
   }
 }
 
+static void big_kernels_attr() {
+  static bool done = false;
+  if (done) return;
+  hipFuncSetAttribute((const void*)big_potrf0_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (int)kTileBytes);
+  hipFuncSetAttribute((const void*)big_trsm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)kTileBytes);
+  hipFuncSetAttribute((const void*)big_syrk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (int)kTileBytes);
+  done = true;
+}
+
 void launch_big_potrf0(const BigDesc* descs, int count, double* arena, DevStatus* status, hipStream_t st) {
-  if (count) big_potrf0_kernel<<<count, 256, 0, st>>>(descs, arena, status);
+  big_kernels_attr();
+  if (count) big_potrf0_kernel<<<count, NT, 3 * kTileBytes, st>>>(descs, arena, status);
 }
 
 void launch_big_step(const DevSymbolic& S, const BigDesc* descs, int count, int kb, int max_row_tiles, int max_pairs,
                      double* arena, DevStatus* status, hipStream_t st) {
   if (!count) return;
-  if (max_row_tiles > 0) big_trsm_kernel<<<dim3(max_row_tiles, count), 256, 0, st>>>(descs, kb, arena);
-  if (max_pairs > 0) big_syrk_kernel<<<dim3(max_pairs, count), 256, 0, st>>>(descs, kb, arena, status);
+  big_kernels_attr();
+  if (max_row_tiles > 0) big_trsm_kernel<<<dim3(max_row_tiles, count), NT, 2 * kTileBytes, st>>>(descs, kb, arena);
+  if (max_pairs > 0) big_syrk_kernel<<<dim3(max_pairs, count), NT, 3 * kTileBytes, st>>>(descs, kb, arena, status);
 }
 
 // ---------------------------------------------------------------------------------------------
 // back-substitution of one clique per workgroup (OptimizeClique, gtsam/linear/linearAlgorithms-inst.h:49-117):
 //   L11' x_F = d - L21' x_S, blocked by 32 columns from the last panel to the first.
 // ---------------------------------------------------------------------------------------------
+constexpr int TB = 32;  // panel width of the back-substitution (independent of the factorization tile)
 __global__ void backsolve_kernel(DevSymbolic S, const int* ids, const double* arena, double* delta, DevStatus* status) {
   extern __shared__ double xs[];  // n-1 solution entries of this front (frontal + separator)
-  __shared__ double tile[T][T + 1];
-  __shared__ double y[T];
+  __shared__ double tile[TB][TB + 1];
+  __shared__ double y[TB];
   const int f = ids[blockIdx.x];
   const int n = S.fr_N[f], F = S.fr_F[f];
   const double* A = arena + S.fr_off[f];
@@ -1115,28 +1146,55 @@ __global__ void backsolve_kernel(DevSymbolic S, const int* ids, const double* ar
   const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
   for (int r = F + tid; r < n - 1; r += nt) xs[r] = delta[gi[r]];
   __syncthreads();
-  const int nblk = (F + T - 1) / T;
+  // big fronts carry (L^-1)' of every 32x32 diagonal tile in that tile's strictly upper triangle
+  // (diag_tile_factor; kTile == TB): the tile solve is then a 32-term dot product per lane instead of
+  // a 32-step serial substitution with divisions.
+  const bool has_inv = (n > kSmallMaxN) && (T == TB);
+  const int nblk = (F + TB - 1) / TB;
   for (int kb = nblk - 1; kb >= 0; --kb) {
-    const int c0 = kb * T, w = min(T, F - c0);
-    for (int c = wave; c < w; c += nw) {
-      const double* col = A + (i64)(c0 + c) * n;
-      double acc = 0;
-      for (int r = c0 + w + lane; r < n - 1; r += 64) acc += col[r] * xs[r];
-      acc = wave_sum(acc);
-      if (lane == 0) y[c] = col[n - 1] - acc;
+    const int c0 = kb * TB, w = min(TB, F - c0);
+    for (int c = 2 * wave; c < w; c += 2 * nw) {  // two columns per wave: independent loads and reductions
+      const double* col0 = A + (i64)(c0 + c) * n;
+      const bool two = c + 1 < w;
+      const double* col1 = two ? col0 + n : col0;
+      double acc0 = 0, acc1 = 0;
+      for (int r = c0 + w + lane; r < n - 1; r += 64) {
+        const double x = xs[r];
+        acc0 += col0[r] * x;
+        acc1 += col1[r] * x;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        acc0 += __shfl_down(acc0, o, 64);
+        acc1 += __shfl_down(acc1, o, 64);
+      }
+      if (lane == 0) {
+        y[c] = col0[n - 1] - acc0;
+        if (two) y[c + 1] = col1[n - 1] - acc1;
+      }
     }
     for (int e = tid; e < w * w; e += nt) {
       const int r = e % w, c = e / w;
-      if (r >= c) tile[r][c] = A[(c0 + r) + (i64)(c0 + c) * n];
+      if (has_inv || r >= c) tile[r][c] = A[(c0 + r) + (i64)(c0 + c) * n];
     }
     __syncthreads();
     if (wave == 0) {
-      // solve tile' x = y backwards; lane r holds y_r
-      double yr = (lane < w) ? y[lane] : 0.0;
-      for (int c = w - 1; c >= 0; --c) {
-        const double xc = __shfl(yr, c, 64) / tile[c][c];
-        if (lane == c) yr = xc;
-        else if (lane < c) yr -= tile[c][lane] * xc;
+      double yr;
+      if (has_inv) {
+        // x = (L^-1)' y:  x[c] = y[c] / L[c][c] + sum_{r > c} (L^-1)[r][c] y[r],  (L^-1)[r][c] = tile[c][r]
+        yr = 0;
+        if (lane < w) {
+          yr = y[lane] / tile[lane][lane];
+          for (int r = lane + 1; r < w; ++r) yr += tile[lane][r] * y[r];
+        }
+      } else {
+        // solve tile' x = y backwards; lane r holds y_r
+        yr = (lane < w) ? y[lane] : 0.0;
+        for (int c = w - 1; c >= 0; --c) {
+          const double xc = __shfl(yr, c, 64) / tile[c][c];
+          if (lane == c) yr = xc;
+          else if (lane < c) yr -= tile[c][lane] * xc;
+        }
       }
       if (lane < w) {
         xs[c0 + lane] = yr;
