@@ -28,6 +28,8 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
         o = os.path.join(CSRC, os.path.splitext(s)[0] + ".o")
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
                "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value", "-c", os.path.join(CSRC, s), "-o", o]
+        if os.environ.get("GSX_STAMP") and s.endswith(".hip"):
+            cmd.insert(1, "-DGSX_STAMP")
         if os.environ.get("GSX_BIG_NT") and s.endswith(".hip"):
             cmd.insert(1, "-DGSX_BIG_NT=" + os.environ["GSX_BIG_NT"])
         if s.endswith(".cpp"):

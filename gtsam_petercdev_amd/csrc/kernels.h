@@ -23,6 +23,16 @@ struct TermRec {
   int m, colA, colB, dB, dst, pad;
 };
 
+// Packed per-variable / per-child records (32 bytes, fetched through the scalar path).
+struct VarRec {
+  i64 h_off, hmap_off;
+  int dA, rows, loc, toff;
+};
+struct ChildRec {
+  i64 src0, cmap_off;   // arena offset of the child's Schur complement (top-left), offset of its row map
+  int nc, s1, pad0, pad1;
+};
+
 // Symbolic tables on the device.
 struct DevSymbolic {
   int n_fronts;
@@ -37,6 +47,8 @@ struct DevSymbolic {
   // H assembly terms
   const i64* term_ptr;
   const TermRec* terms;
+  const VarRec* var_recs;
+  const ChildRec* child_recs;
 };
 
 // status words written by the factorization / back-substitution kernels

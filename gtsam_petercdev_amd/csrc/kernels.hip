@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <climits>
+#include <cstdio>
 #include <cstdlib>
 
 #include "device_geometry.h"
@@ -569,24 +570,107 @@ void launch_set_scalar(double* scalars, int slot, double v, hipStream_t st) {
 // columns 0..F-1 become [L11; L21] (incl. the rhs row), the trailing block C -= L21 L21'.
 // All threads of the block take part.  Returns (in every thread) 0 ok / 1 failed.
 // ---------------------------------------------------------------------------------------------
-__device__ inline int lds_partial_cholesky(double* L, int n, int F) {
+#ifdef GSX_STAMP
+__device__ unsigned long long g_stamp[8];
+#define STAMP_BEGIN unsigned long long st0__ = __builtin_amdgcn_s_memtime();
+#define STAMP_ADD(slot)                                                      \
+  {                                                                          \
+    unsigned long long t__ = __builtin_amdgcn_s_memtime();                   \
+    if (threadIdx.x == 0 && blockIdx.x == 0) g_stamp[slot] += t__ - st0__;   \
+    st0__ = t__;                                                             \
+  }
+#else
+#define STAMP_BEGIN
+#define STAMP_ADD(slot)
+#endif
+typedef double v4d __attribute__((ext_vector_type(4)));
+template <int PB>
+__device__ inline int lds_partial_cholesky_t(double* L, int n, int F) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
   int fail = 0;
-  for (int j = 0; j < F; ++j) {
-    const double p = L[j + j * n];
-    if (!(p > 0)) fail = 1;  // Eigen::LLT reports NumericalIssue on a non-positive pivot
-    const double s = (p > 0) ? sqrt(p) : 1.0;
-    const double inv = 1.0 / s;
-    __syncthreads();
-    if (tid == 0) L[j + j * n] = s;
-    for (int r = j + 1 + tid; r < n; r += nt) L[r + j * n] *= inv;
-    __syncthreads();
-    for (int c = j + 1 + wave; c < n; c += nw) {
-      const double lc = L[c + j * n];
-      for (int r = c + lane; r < n; r += 64) L[r + c * n] -= L[r + j * n] * lc;
+  // Blocked right-looking: panels of PB columns are factored with rank-1 updates confined to the
+  // panel (n x PB entries per pivot instead of n x n), then ONE rank-PB sweep updates the rest of the
+  // matrix — 1/PB of the LDS traffic and of the full-matrix passes of the unblocked form.
+  // Inside a panel thread r keeps ROW r of the panel (PB values) in registers; per pivot the only shared
+  // data is column j restricted to the PB x PB diagonal block, double-buffered in LDS => ONE barrier per
+  // pivot (requires blockDim >= n, which the size classes guarantee).
+  __shared__ double dcol[2][PB];
+  const int row = tid;
+  for (int j0 = 0; j0 < F; j0 += PB) {
+    const int pb = min(PB, F - j0), jend = j0 + pb;
+    STAMP_BEGIN
+    const bool active = row >= j0 && row < n;
+    const int dk = row - j0;  // position inside the diagonal block (valid when 0 <= dk < pb)
+    double a[PB];
+#pragma unroll
+    for (int k = 0; k < PB; ++k) a[k] = (active && k < pb) ? L[row + (j0 + k) * n] : 0.0;
+    if (dk >= 0 && dk < pb) dcol[0][dk] = a[0];
+#pragma unroll
+    for (int jj = 0; jj < PB; ++jj) {
+      if (jj < pb) {
+        __syncthreads();
+        const double* cur = dcol[jj & 1];
+        const double p = cur[jj];
+        if (!(p > 0)) fail = 1;  // Eigen::LLT reports NumericalIssue on a non-positive pivot
+        const double inv = (p > 0) ? rsqrt(p) : 1.0;
+        if (active && dk >= jj) {
+          const double l = (dk == jj) ? p * inv : a[jj] * inv;
+          a[jj] = l;
+#pragma unroll
+          for (int k = jj + 1; k < PB; ++k)
+            if (k < pb && dk >= k) a[k] -= l * (cur[k] * inv);
+          if (jj + 1 < pb && dk > jj && dk < pb) dcol[(jj + 1) & 1][dk] = a[jj + 1 < PB ? jj + 1 : 0];
+        }
+      }
+    }
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < PB; ++k)
+        if (k < pb && dk >= k) L[row + (j0 + k) * n] = a[k];
     }
     __syncthreads();
+    STAMP_ADD(0)
+    // rank-pb trailing update C -= P P' on the FP64 matrix cores: one wave per 16x16 tile of the lower
+    // triangle, v_mfma_f64_16x16x4 (A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
+    // C/D row = (lane>>4) + 4 reg, col = lane&15), two k-steps for the 8-column panel.  Per lane that is
+    // 4 LDS reads of operands + 8 of the C tile for 32 FMA-equivalents (the VALU form needed 18 reads for
+    // 16 FMAs and was bound by the ~100-cycle LDS round trip).
+    {
+      const int m = n - jend, nt16 = (m + 15) >> 4, ntiles = nt16 * (nt16 + 1) / 2;
+      const int li = lane & 15, lk = lane >> 4;
+      for (int t = wave; t < ntiles; t += nw) {
+        int ti = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        while (ti * (ti + 1) / 2 > t) --ti;
+        const int tj = t - ti * (ti + 1) / 2;
+        const int i0 = jend + ti * 16, c0 = jend + tj * 16;
+        const int col = c0 + li;
+        v4d acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int rr = i0 + lk + 4 * q;
+          acc[q] = (rr < n && col < n) ? L[rr + col * n] : 0.0;
+        }
+#pragma unroll
+        for (int kk = 0; kk < PB; kk += 4) {
+          if (kk < pb) {  // wave-uniform
+            const int k = kk + lk;
+            const bool kin = k < pb;
+            const double av = (kin && i0 + li < n) ? -L[(i0 + li) + (j0 + k) * n] : 0.0;
+            const double bv = (kin && c0 + li < n) ? L[(c0 + li) + (j0 + k) * n] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int rr = i0 + lk + 4 * q;
+          if (rr < n && col < n) L[rr + col * n] = acc[q];
+        }
+      }
+    }
+    __syncthreads();
+    STAMP_ADD(1)
   }
   // conditioning test on the last two pivots — cholesky.cpp:145-158
   if (F >= 2) {
@@ -600,6 +684,11 @@ __device__ inline int lds_partial_cholesky(double* L, int n, int F) {
     if (!(e1 > -12)) fail = 1;
   }
   return fail;
+}
+// panel width by frontal size: narrow panels keep the per-pivot register work small for the many cliques
+// with a handful of frontal scalars, wide panels halve the number of trailing sweeps of the larger ones
+__device__ inline int lds_partial_cholesky(double* L, int n, int F) {
+  return (F <= 24) ? lds_partial_cholesky_t<8>(L, n, F) : lds_partial_cholesky_t<16>(L, n, F);
 }
 
 __device__ inline void report_failure(DevStatus* status, int front) {
@@ -626,31 +715,34 @@ __global__ void front_small_kernel(DevProblem P, DevSymbolic S, const int* ids, 
   const double lambda = scalars[SC_LAMBDA];
   for (int e = tid; e < n * n; e += nt) L[e] = 0;
   __syncthreads();
+  // H panels of the frontal variables: one wave per variable (disjoint columns), metadata packed in one
+  // 32-byte record per variable so that the dependent-load chain is record -> data.
+  int* cml = (int*)(L + (size_t)n * n);  // staging of a child's row map (n ints)
   const int nfv = S.fr_nfv[f];
   const int* fv = S.fvars + S.fr_fvar_ptr[f];
-  for (int k = 0; k < nfv; ++k) {
-    const int v = fv[k];
-    const int dA = P.var_dim[v], rows = S.h_rows[v], c0 = S.h_loc[v];
-    const double* hp = H + S.h_off[v];
-    const int* hm = S.hmap + S.hmap_ptr[v];
-    const int toff = P.var_tan_off[v];
-    for (int e = tid; e < rows * dA; e += nt) {
-      const int r = e % rows, j = e / rows;
+  for (int k = wave; k < nfv; k += nw) {
+    const VarRec vr = S.var_recs[fv[k]];
+    const double* hp = H + vr.h_off;
+    const int* hm = S.hmap + vr.hmap_off;
+    for (int e = lane; e < vr.rows * vr.dA; e += 64) {
+      const int r = e % vr.rows, j = e / vr.rows;
       double x = hp[e];
-      if (r == j) x += lambda * damp[toff + j];  // rows 0..dA-1 of the panel are the variable itself
-      L[hm[r] + (c0 + j) * n] = x;
+      if (r == j) x += lambda * damp[vr.toff + j];  // rows 0..dA-1 of the panel are the variable itself
+      L[hm[r] + (vr.loc + j) * n] = x;
     }
   }
   __syncthreads();
+  // extend-add of the children, in child order; the child's row map is staged in LDS first so that the
+  // column loop has no dependent global loads (only the streaming reads of the Schur complement).
   for (int ci = S.fr_child_ptr[f]; ci < S.fr_child_ptr[f + 1]; ++ci) {
-    const int ch = S.children[ci];
-    const int nc = S.fr_N[ch], Fc = S.fr_F[ch], s1 = nc - Fc;
-    const int* cm = S.cmap + S.cmap_ptr[ch];
-    const double* src0 = arena + S.fr_off[ch] + (i64)Fc * nc + Fc;
-    for (int col = wave; col < s1; col += nw) {
-      const int pc = cm[col];
-      const double* src = src0 + (i64)col * nc;
-      for (int r = col + lane; r < s1; r += 64) L[cm[r] + pc * n] += src[r];
+    const ChildRec cr = S.child_recs[ci];
+    for (int r = tid; r < cr.s1; r += nt) cml[r] = S.cmap[cr.cmap_off + r];
+    __syncthreads();
+    const double* src0 = arena + cr.src0;
+    for (int col = wave; col < cr.s1; col += nw) {
+      const int pc = cml[col] * n;
+      const double* src = src0 + (i64)col * cr.nc;
+      for (int r = col + lane; r < cr.s1; r += 64) L[cml[r] + pc] += src[r];
     }
     __syncthreads();
   }
@@ -671,11 +763,11 @@ void launch_front_small(const DevProblem& P, const DevSymbolic& S, const int* id
                         hipStream_t st) {
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute((const void*)front_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)front_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     attr = true;
   }
   if (count)
-    front_small_kernel<<<count, threads, (size_t)max_n * max_n * sizeof(double), st>>>(P, S, ids, H, damp, scalars,
+    front_small_kernel<<<count, threads, ((size_t)max_n * max_n + max_n) * sizeof(double), st>>>(P, S, ids, H, damp, scalars,
                                                                                          arena, status);
 }
 
@@ -742,13 +834,36 @@ __global__ void front_leaf_kernel(DevProblem P, DevSymbolic S, const int* ids, c
   double* A = arena + S.fr_off[f];
   for (int c = wave; c < F; c += nw)
     for (int r = c + lane; r < n; r += 64) A[r + (i64)c * n] = Pn[r + c * n];
+  // Schur complement -L21 L21' as an outer product, thread-per-row: row r's F values stay in registers
+  // (F <= kLeafMaxF), the threads of a row split the columns, two columns in flight per iteration.
   const int s1 = n - F;
-  for (int col = wave; col < s1; col += nw) {
-    double* out = A + (i64)(F + col) * n + F;
-    for (int r = col + lane; r < s1; r += 64) {
-      double acc = 0;
-      for (int k = 0; k < F; ++k) acc += Pn[F + r + k * n] * Pn[F + col + k * n];
-      out[r] = -acc;
+  {
+    const int G = max(1, nt / s1);
+    const int r = tid % s1, g = tid / s1;
+    if (g < G) {
+      double rv[kLeafMaxF];
+#pragma unroll
+      for (int k = 0; k < kLeafMaxF; ++k) rv[k] = (k < F) ? Pn[F + r + k * n] : 0.0;
+      double* out = A + (i64)F * n + F + r;  // entry (F + r, F + col) at out[col * n]
+      int col = g;
+      for (; col + G <= r; col += 2 * G) {
+        double acc0 = 0, acc1 = 0;
+#pragma unroll
+        for (int k = 0; k < kLeafMaxF; ++k)
+          if (k < F) {
+            acc0 += rv[k] * Pn[F + col + k * n];
+            acc1 += rv[k] * Pn[F + col + G + k * n];
+          }
+        out[(i64)col * n] = -acc0;
+        out[(i64)(col + G) * n] = -acc1;
+      }
+      if (col <= r) {
+        double acc0 = 0;
+#pragma unroll
+        for (int k = 0; k < kLeafMaxF; ++k)
+          if (k < F) acc0 += rv[k] * Pn[F + col + k * n];
+        out[(i64)col * n] = -acc0;
+      }
     }
   }
 }
@@ -1235,10 +1350,20 @@ void launch_dense_partial(double* a, int n, int nf, DevStatus* status, hipStream
   if (n <= kSmallMaxN) {
     static bool attr = false;
     if (!attr) {
-      hipFuncSetAttribute((const void*)dense_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute((const void*)dense_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
       attr = true;
     }
-    dense_small_kernel<<<1, 256, (size_t)n * n * sizeof(double), st>>>(a, n, nf, status);
+    dense_small_kernel<<<1, 512, (size_t)n * n * sizeof(double), st>>>(a, n, nf, status);
+#ifdef GSX_STAMP
+    {
+      unsigned long long h[8];
+      hipStreamSynchronize(st);
+      hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamp), sizeof(h));
+      printf("[stamp] n=%d F=%d panel-factor %llu cycles, trailing %llu cycles\n", n, nf, h[0], h[1]);
+      unsigned long long z[8] = {0};
+      hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z));
+    }
+#endif
     return;
   }
   BigDesc h{0, n, nf, 0, -1};

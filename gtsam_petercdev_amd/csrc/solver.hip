@@ -96,6 +96,8 @@ struct gsx_context {
   // device symbolic
   DevBuf<i64> d_fr_off, d_cmap_ptr, d_gidx_ptr, d_h_off, d_hmap_ptr, d_term_ptr;
   DevBuf<TermRec> d_terms;
+  DevBuf<VarRec> d_var_recs;
+  DevBuf<ChildRec> d_child_recs;
   DevBuf<int> d_fr_N, d_fr_F, d_fr_nfv, d_fr_fvar_ptr, d_fvars, d_fr_parent, d_fr_child_ptr, d_children, d_cmap,
       d_gidx, d_h_rows, d_hmap, d_h_loc, d_sched, d_hvars;
   DevBuf<BigDesc> d_big;
@@ -295,6 +297,17 @@ gsx_status upload_symbolic(gsx_context* c) {
     for (size_t i = 0; i < terms.size(); ++i)
       terms[i] = TermRec{(i64)S.t_jac[i], S.t_m[i], S.t_colA[i], S.t_colB[i], S.t_dB[i], S.t_dst[i], 0};
     HIPCHK(c, c->d_terms.upload(terms, st));
+    std::vector<VarRec> vrec(P.n_vars);
+    for (int v = 0; v < P.n_vars; ++v)
+      vrec[v] = VarRec{(i64)S.h_off[v], (i64)S.hmap_ptr[v], P.dims[v], S.h_rows[v], S.h_loc[v], P.tan_off[v]};
+    std::vector<ChildRec> crec(S.children.size());
+    for (size_t i = 0; i < crec.size(); ++i) {
+      const int ch = S.children[i];
+      crec[i] = ChildRec{(i64)S.off[ch] + (i64)S.F[ch] * S.N[ch] + S.F[ch], (i64)S.cmap_ptr[ch], S.N[ch],
+                         S.N[ch] - S.F[ch], 0, 0};
+    }
+    HIPCHK(c, c->d_var_recs.upload(vrec, st));
+    HIPCHK(c, c->d_child_recs.upload(crec, st));
     HIPCHK(c, hipStreamSynchronize(st));
   }
   HIPCHK(c, c->d_sched.upload(S.sched, st));
@@ -430,6 +443,7 @@ gsx_status upload_symbolic(gsx_context* c) {
   D.h_off = c->d_h_off.p; D.hmap_ptr = c->d_hmap_ptr.p; D.h_rows = c->d_h_rows.p; D.hmap = c->d_hmap.p;
   D.h_loc = c->d_h_loc.p;
   D.term_ptr = c->d_term_ptr.p; D.terms = c->d_terms.p;
+  D.var_recs = c->d_var_recs.p; D.child_recs = c->d_child_recs.p;
   HIPCHK(c, hipStreamSynchronize(st));
   c->h_ready = false;
   c->solved = false;
