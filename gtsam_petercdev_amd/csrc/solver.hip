@@ -384,6 +384,32 @@ gsx_status upload_symbolic(gsx_context* c) {
       c->small_launch[l].push_back({i, j - i, maxn, thr});
       i = j;
     }
+    // A launch of few fronts is bound by the latency of ONE front (20-60 us), not by occupancy: merge the
+    // size groups of a level when that costs no residency — all 64-thread groups if they total <= 2048
+    // fronts (48^2 doubles = 18 KB LDS each: 8 per CU), all wider groups if they total <= 256 fronts.
+    {
+      std::vector<SmallLaunch>& G = c->small_launch[l];
+      std::vector<SmallLaunch> merged;
+      size_t k = 0;
+      while (k < G.size()) {
+        const bool narrow = G[k].threads == 64;
+        size_t e = k;
+        int total = 0, maxn = 0, thr = 0;
+        while (e < G.size() && (G[e].threads == 64) == narrow) {
+          total += G[e].count;
+          maxn = std::max(maxn, G[e].max_n);
+          thr = std::max(thr, G[e].threads);
+          ++e;
+        }
+        if (total <= (narrow ? 2048 : 256)) {
+          merged.push_back({G[k].begin, total, maxn, thr});
+        } else {
+          for (size_t q = k; q < e; ++q) merged.push_back(G[q]);
+        }
+        k = e;
+      }
+      G.swap(merged);
+    }
     BigLevel& B = c->big_level[l];
     B.begin = (int)c->big_descs.size();
     for (int k = se; k < S.lvl_ptr[l + 1]; ++k) {
