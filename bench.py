@@ -84,14 +84,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
+    from gtsam_petercdev_amd import _abi as A, _lib, distributed as D
     dist = None
     if world > 1:
-        import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    from gtsam_petercdev_amd import _abi as A, _lib
+        dist = D.init("nccl", torch.device("cuda", local_rank))
 
-    arrays, default_order = make_problem(args.workload, seed=42 + rank)
+    arrays, default_order = make_problem(args.workload, seed=D.replica_seed(42))
     be = _lib.product_backend(arrays, device=local_rank)
     okind = {"schur": A.ORDER_SCHUR, "mindegree": A.ORDER_MINDEGREE, "nd": A.ORDER_ND}[args.ordering or default_order]
     t0 = time.time()
@@ -123,13 +122,8 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    value, ms_step = D.aggregate_throughput(dist, args.steps, elapsed, device="cuda" if dist is not None else "cpu")
     st = be.stats()
-    ms_step = 1e3 * elapsed / args.steps
-    value = world * args.steps / elapsed
     ms_solve = (st["ms_factorize"] + st["ms_backsolve"]) / max(st["n_factorize"], 1)
 
     # ---- per-kernel timing pass (HIP events on the library's stream around every launch) ------------
