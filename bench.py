@@ -7,7 +7,8 @@ Cholesky -> back-substitution -> 2 linear errors -> retract -> nonlinear error. 
 committed, so every step does identical work on data already resident in HBM.
 
   N = 1   workload = BAL Ladybug-1723 shape (1 723 cameras / 156 502 points / 678 718 observations,
-          seeded synthetic: 70 % ring-local + 30 % half-lap revisit co-visibility), Schur ordering.
+          seeded synthetic: 70 % ring-local + 30 % half-lap revisit co-visibility), Schur ordering with
+          nested dissection of the camera graph (BASELINE config 3: "LM + METIS ordering").
   N > 1   one process per GPU (torch.distributed, backend nccl = RCCL), every rank an independent
           seeded replica of the same shape (weak scaling; see DESIGN.md "multi-GPU": the clique-partitioned
           single-problem path is not built yet, so no data-path collective is invented here).
@@ -36,7 +37,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="bal1723", choices=["bal1723", "bal49", "pose3_100k", "pose2_100k"])
-    ap.add_argument("--ordering", default=None, choices=[None, "schur", "mindegree", "nd"])
+    ap.add_argument("--ordering", default=None, choices=[None, "schur", "schur_nd", "mindegree", "nd"])
     ap.add_argument("--lam", type=float, default=1e-5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
@@ -46,9 +47,9 @@ def parse():
 def make_problem(name, seed):
     from gtsam_petercdev_amd import datasets
     if name == "bal1723":
-        return datasets.synth_bal_arrays(1723, 156502, 678718, seed=seed, long_range=0.3), "schur"
+        return datasets.synth_bal_arrays(1723, 156502, 678718, seed=seed, long_range=0.3), "schur_nd"
     if name == "bal49":
-        return datasets.synth_bal_arrays(49, 7776, 31843, seed=seed, long_range=0.3), "schur"
+        return datasets.synth_bal_arrays(49, 7776, 31843, seed=seed, long_range=0.3), "schur_nd"
     if name == "pose3_100k":
         return datasets.synth_manhattan_pose3(100000, seed=seed), "nd"
     return datasets.synth_manhattan_pose2(100000, seed=seed), "nd"
@@ -92,7 +93,8 @@ def main():
 
     arrays, default_order = make_problem(args.workload, seed=D.replica_seed(42))
     be = _lib.product_backend(arrays, device=local_rank)
-    okind = {"schur": A.ORDER_SCHUR, "mindegree": A.ORDER_MINDEGREE, "nd": A.ORDER_ND}[args.ordering or default_order]
+    okind = {"schur": A.ORDER_SCHUR, "schur_nd": A.ORDER_SCHUR_ND, "mindegree": A.ORDER_MINDEGREE,
+             "nd": A.ORDER_ND}[args.ordering or default_order]
     t0 = time.time()
     ordering = be.compute_ordering(okind)
     t_order = time.time() - t0

@@ -7,7 +7,9 @@
 //   MINDEGREE  quotient-graph minimum degree with element absorption (approximate external degree)
 //   ND         nested dissection by BFS level-set separators, min-degree at the leaves
 //   SCHUR      3-D landmarks first, the rest (cameras) by MINDEGREE on the co-visibility graph
+//   SCHUR_ND   same, cameras by ND (the analogue of the reference's METIS choice for BAL)
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 #include <queue>
 #include <set>
@@ -258,7 +260,13 @@ void compute_ordering(const HostProblem& P, int kind, std::vector<int>& order) {
     std::sort(l.begin(), l.end());
     l.erase(std::unique(l.begin(), l.end()), l.end());
   }
-  min_degree(red, P.dims, rest, order);
+  if (kind == GSX_ORDER_SCHUR_ND) {  // nested dissection of the reduced (camera) graph: shallower tree
+    std::vector<int> label(P.n_vars, -1);
+    int next_label = 0;
+    nested_dissection(red, P.dims, rest, label, next_label, 16, order);
+  } else {
+    min_degree(red, P.dims, rest, order);
+  }
 }
 
 }  // namespace gsx

@@ -828,7 +828,7 @@ gsx_status gsx_set_ordering(gsx_handle h, const uint64_t* keys, int32_t n) {
 }
 
 gsx_status gsx_compute_ordering(gsx_handle h, int32_t kind, uint64_t* keys_out) {
-  if (!h || !keys_out || kind < 0 || kind > 3) return GSX_E_INVALID;
+  if (!h || !keys_out || kind < 0 || kind > 4) return GSX_E_INVALID;
   std::vector<int> ord;
   compute_ordering(h->P, kind, ord);
   for (int i = 0; i < h->P.n_vars; ++i) keys_out[i] = h->P.keys[ord[i]];

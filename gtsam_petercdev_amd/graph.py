@@ -563,7 +563,7 @@ class _OptimizerBase:
                 ordering = ordering_fn(self.arrays)
             else:
                 kind = {"COLAMD": A.ORDER_MINDEGREE, "METIS": A.ORDER_ND, "NATURAL": A.ORDER_NATURAL,
-                        "SCHUR": A.ORDER_SCHUR}[orderingType]
+                        "SCHUR": A.ORDER_SCHUR, "SCHUR_ND": A.ORDER_SCHUR_ND}[orderingType]
                 ordering = self.backend.compute_ordering(kind)
         self.ordering = Ordering(int(k) for k in ordering)
         self.backend.set_ordering(self.ordering)

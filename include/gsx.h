@@ -117,8 +117,10 @@ enum {
   GSX_ORDER_NATURAL = 0,    /* ascending key                                      */
   GSX_ORDER_MINDEGREE = 1,  /* own approximate-minimum-degree (host)              */
   GSX_ORDER_ND = 2,         /* own nested dissection (BFS level-set separators)   */
-  GSX_ORDER_SCHUR = 3       /* VECTOR(3) landmarks first, then the rest by
+  GSX_ORDER_SCHUR = 3,      /* VECTOR(3) landmarks first, then the rest by
                                minimum degree on the reduced graph                */
+  GSX_ORDER_SCHUR_ND = 4    /* landmarks first, the rest by nested dissection of
+                               the reduced graph (shallow tree; METIS analogue)   */
 };
 
 /*

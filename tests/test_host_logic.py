@@ -70,7 +70,7 @@ def test_bayes_tree_identical_to_reference_construction(lib, oracle, name):
     arr = PROBLEMS[name]()
     pb = _lib.ProductBackend(arr, host_only=True)
     ob = oracle.oracle_backend(arr)
-    orderings = [pb.compute_ordering(k) for k in (A.ORDER_NATURAL, A.ORDER_MINDEGREE, A.ORDER_ND, A.ORDER_SCHUR)]
+    orderings = [pb.compute_ordering(k) for k in (A.ORDER_NATURAL, A.ORDER_MINDEGREE, A.ORDER_ND, A.ORDER_SCHUR, A.ORDER_SCHUR_ND)]
     if oracle.have_ref_colamd():
         orderings.append(oracle.colamd_ordering(arr))
     for ordering in orderings:
