@@ -196,8 +196,23 @@ static void nested_dissection(const Adj& adj, const std::vector<int>& w, std::ve
     if (best < 0) best = nl / 2;
   }
   std::vector<int> part1(order.begin(), order.begin() + ls[best]);
-  std::vector<int> sep(order.begin() + ls[best], order.begin() + ls[best + 1]);
-  std::vector<int> part2(order.begin() + ls[best + 1], order.end());
+  std::vector<int> sep, part2(order.begin() + ls[best + 1], order.end());
+  {
+    // thin the level-set separator: a vertex of the level without a neighbour in the next level does not
+    // separate anything and goes to part 1 (labels: every vertex of this component carries m3 now)
+    const int far_mark = next_label++;
+    for (int v : part2) label[v] = far_mark;
+    for (int k = ls[best]; k < ls[best + 1]; ++k) {
+      const int v = order[k];
+      bool touches = false;
+      for (int u : adj[v])
+        if (label[u] == far_mark) {
+          touches = true;
+          break;
+        }
+      (touches ? sep : part1).push_back(v);
+    }
+  }
   nested_dissection(adj, w, part1, label, next_label, leaf, out);
   nested_dissection(adj, w, part2, label, next_label, leaf, out);
   // order the separator itself by minimum degree restricted to the separator
