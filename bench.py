@@ -55,7 +55,7 @@ def make_problem(name, seed):
     return datasets.synth_manhattan_pose2(100000, seed=seed), "nd"
 
 
-def front_split(be, arrays, small_max_n=140, leaf_max_f=16):
+def front_split(be, arrays, small_max_n=140, leaf_max_f=16, tile=32):
     """Algorithmic bytes / flops of the factorization split by kernel class."""
     parent, fronts = be.get_tree()
     dims = arrays.var_dims
@@ -63,19 +63,34 @@ def front_split(be, arrays, small_max_n=140, leaf_max_f=16):
     for p in parent:
         if p >= 0:
             has_child[p] = True
-    out = dict(lpanel_bytes=0.0)
+    out = dict(lpanel_bytes=0.0, big_syrk_flops=0.0, big_trsm_flops=0.0, big_potrf_flops=0.0, gather_bytes=0.0)
     for k in ("leaf", "small", "big"):
         out.update({k + "_bytes": 0.0, k + "_flops": 0.0, "n_" + k: 0})
+    N = np.zeros(len(fronts))
     for i, (fv, sv) in enumerate(fronts):
         f = float(dims[fv].sum())
         s1 = float(dims[sv].sum()) + 1.0
         n = f + s1
+        N[i] = n
         fl = f ** 3 / 3 + f * f * s1 + f * s1 * s1
         k = "big" if n > small_max_n else ("leaf" if (not has_child[i] and f <= leaf_max_f) else "small")
         out[k + "_bytes"] += 8.0 * n * n
         out[k + "_flops"] += fl
         out["n_" + k] += 1
         out["lpanel_bytes"] += 8.0 * f * n
+        if k == "big":  # blocked path, 32-column panels: flops of each kernel class
+            c0 = 0.0
+            while c0 < f:
+                w = min(tile, f - c0)
+                m = n - (c0 + w)
+                out["big_potrf_flops"] += w ** 3 / 3 + w ** 3       # tile Cholesky + explicit tile inverse
+                out["big_trsm_flops"] += w * w * m                    # X <- X L^-T (triangular tile product)
+                out["big_syrk_flops"] += w * m * (m + 1)              # C -= P P' on the lower tile pairs
+                c0 += w
+    for i, p in enumerate(parent):
+        if p >= 0 and N[p] > small_max_n:  # Schur complement read by the gather + destination read/modify/write
+            s1 = float(dims[fronts[i][1]].sum()) + 1.0
+            out["gather_bytes"] += 8.0 * s1 * (s1 + 1) / 2 * 3
     return out
 
 
@@ -133,34 +148,45 @@ def main():
     be.reset_stats()
     for _ in range(3):
         step()
-    small_ms, small_n = be.kernel_time("factor_small")
-    big_ms, big_n = be.kernel_time("factor_big")
-    leaf_ms, leaf_n = be.kernel_time("factor_leaf")
     st_prof = be.stats()
-    be.set_profiling(0)
     split = front_split(be, arrays)
     nfac = max(st_prof["n_factorize"], 1)
     phases = {k: st_prof[k] / nfac for k in ("ms_linearize", "ms_assemble_hessian", "ms_factorize", "ms_backsolve",
                                              "ms_linear_error", "ms_retract", "ms_error")}
-    tot_small, tot_big, tot_leaf = small_ms * small_n / nfac, big_ms * big_n / nfac, leaf_ms * leaf_n / nfac
-    if max(tot_small, tot_leaf) >= tot_big:
-        # fused assemble + eliminate of the small cliques: HBM-bound (8 (f+s+1)^2 per front,
-        # read + written once)
-        which = "leaf" if tot_leaf >= tot_small else "small"
-        k_ms, k_n = (leaf_ms, leaf_n) if which == "leaf" else (small_ms, small_n)
-        per_launch_bytes = split[which + "_bytes"] * nfac / max(k_n, 1)
-        achieved = per_launch_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        roofline = dict(kernel="front_%s_kernel" % which, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS,
-                        unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None,
-                        launches_per_factorization=k_n / nfac, avg_launch_ms=k_ms,
-                        algorithmic_bytes_per_launch=per_launch_bytes)
+    # every kernel of the path: (HIP-event name, rocprof kernel name, bound, algorithmic amount per
+    # factorization — bytes for "hbm", flops for "mfma")
+    kernels = [
+        ("factor_leaf", "front_leaf_kernel", "hbm", split["leaf_bytes"]),
+        ("factor_small", "front_small_kernel", "hbm", split["small_bytes"]),
+        ("big_syrk", "big_syrk_kernel", "mfma", split["big_syrk_flops"]),
+        ("big_trsm", "big_trsm_kernel", "mfma", split["big_trsm_flops"]),
+        ("big_potrf0", "big_potrf0_kernel", "mfma", split["big_potrf_flops"]),
+        ("big_gather", "big_gather_seg_kernel(+combine)", "hbm", split["gather_bytes"]),
+        ("assemble_hessian", "assemble_h_kernel(+hessian_diag)", "hbm", st["jacobian_bytes"] + st["hessian_bytes"]),
+        ("backsolve", "backsolve_kernel (all levels)", "hbm", split["lpanel_bytes"]),
+    ]
+    per_kernel = {}
+    for ev, kname, bound, amount in kernels:
+        avg_ms, n = be.kernel_time(ev)
+        tot = avg_ms * n / nfac
+        per_kernel[kname] = dict(ms_per_factorization=tot, launches_per_factorization=n / nfac, avg_launch_ms=avg_ms,
+                                 bound=bound, algorithmic_per_factorization=amount)
+    be.set_profiling(0)
+    dom = max(per_kernel, key=lambda k: per_kernel[k]["ms_per_factorization"])
+    dk = per_kernel[dom]
+    per_launch = dk["algorithmic_per_factorization"] / max(dk["launches_per_factorization"], 1e-9)
+    if dk["bound"] == "hbm":
+        achieved = per_launch / (dk["avg_launch_ms"] * 1e-3) / 1e9 if dk["avg_launch_ms"] > 0 else 0.0
+        peak, unit = HBM_PEAK_GBS, "GB/s"
     else:
-        per_launch_flops = split["big_flops"] * nfac / max(big_n, 1)
-        achieved = per_launch_flops / (big_ms * 1e-3) / 1e12 if big_ms > 0 else 0.0
-        roofline = dict(kernel="big_syrk_kernel+big_trsm_kernel (per level)", bound="mfma", achieved=achieved,
-                        peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / FP64_PEAK_TFLOPS, traffic=None,
-                        launches_per_factorization=big_n / nfac, avg_launch_ms=big_ms,
-                        algorithmic_flops_per_launch=per_launch_flops)
+        achieved = per_launch / (dk["avg_launch_ms"] * 1e-3) / 1e12 if dk["avg_launch_ms"] > 0 else 0.0
+        peak, unit = FP64_PEAK_TFLOPS, "TFLOP/s"
+    roofline = dict(kernel=dom, bound=dk["bound"], achieved=achieved, peak=peak, unit=unit, frac=achieved / peak,
+                    traffic=None, launches_per_factorization=dk["launches_per_factorization"],
+                    avg_launch_ms=dk["avg_launch_ms"], algorithmic_per_launch=per_launch)
+    tot_leaf = per_kernel["front_leaf_kernel"]["ms_per_factorization"]
+    tot_small = per_kernel["front_small_kernel"]["ms_per_factorization"]
+    tot_big = sum(per_kernel[k]["ms_per_factorization"] for k in per_kernel if k.startswith("big_"))
 
     out = {
         "metric": "lm_iterations_per_sec", "value": value, "unit": "LM iterations/s", "n_gpus": world,
@@ -174,7 +200,7 @@ def main():
         "symbolic": {k: st[k] for k in ("n_fronts", "n_levels", "max_front_dim", "max_front_rows", "n_small_fronts",
                                         "n_big_fronts", "factor_flops", "front_bytes", "lpanel_bytes",
                                         "jacobian_bytes", "hessian_bytes", "total_dim")},
-        "front_split": split, "host_ordering_s": t_order, "host_symbolic_s": t_symbolic,
+        "front_split": split, "kernels": per_kernel, "host_ordering_s": t_order, "host_symbolic_s": t_symbolic,
         "roofline": roofline,
     }
     out["config"]["shape"] = {k: (v if not hasattr(v, "tolist") else None) for k, v in arrays.meta.items()

@@ -90,7 +90,7 @@ void launch_big_init(const DevProblem& P, const DevSymbolic& S, const BigDesc* d
                      hipStream_t st);
 void launch_big_potrf0(const BigDesc* descs, int count, double* arena, DevStatus* status, hipStream_t st);
 void launch_big_step(const DevSymbolic& S, const BigDesc* descs, int count, int kb, int max_row_tiles,
-                     int max_pairs, double* arena, DevStatus* status, hipStream_t st);
+                     int max_pairs, double* arena, DevStatus* status, hipStream_t st, int which = 0);
 void launch_front_leaf(const DevProblem& P, const DevSymbolic& S, const int* ids, int count, int max_panel, int threads,
                        const double* H, const double* damp, const double* scalars, double* arena, DevStatus* status,
                        hipStream_t st);

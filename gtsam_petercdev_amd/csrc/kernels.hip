@@ -1237,11 +1237,13 @@ void launch_big_potrf0(const BigDesc* descs, int count, double* arena, DevStatus
 }
 
 void launch_big_step(const DevSymbolic& S, const BigDesc* descs, int count, int kb, int max_row_tiles, int max_pairs,
-                     double* arena, DevStatus* status, hipStream_t st) {
+                     double* arena, DevStatus* status, hipStream_t st, int which) {
   if (!count) return;
   big_kernels_attr();
-  if (max_row_tiles > 0) big_trsm_kernel<<<dim3(max_row_tiles, count), NT, 2 * kTileBytes, st>>>(descs, kb, arena);
-  if (max_pairs > 0) big_syrk_kernel<<<dim3(max_pairs, count), NT, 3 * kTileBytes, st>>>(descs, kb, arena, status);
+  if (max_row_tiles > 0 && which != 2)
+    big_trsm_kernel<<<dim3(max_row_tiles, count), NT, 2 * kTileBytes, st>>>(descs, kb, arena);
+  if (max_pairs > 0 && which != 1)
+    big_syrk_kernel<<<dim3(max_pairs, count), NT, 3 * kTileBytes, st>>>(descs, kb, arena, status);
 }
 
 // ---------------------------------------------------------------------------------------------

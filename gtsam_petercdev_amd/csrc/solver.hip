@@ -63,9 +63,11 @@ struct BigLevel {
 };
 
 enum Phase { PH_LINEARIZE, PH_ASSEMBLE_H, PH_FACTORIZE, PH_BACKSOLVE, PH_LINERR, PH_RETRACT, PH_ERROR,
-             PH_FACTOR_SMALL, PH_FACTOR_BIG, PH_FACTOR_LEAF, PH_COUNT };
+             PH_FACTOR_SMALL, PH_FACTOR_BIG, PH_FACTOR_LEAF, PH_K_SYRK, PH_K_TRSM, PH_K_POTRF0, PH_K_GATHER,
+             PH_K_BACKSOLVE, PH_COUNT };
 const char* kPhaseNames[PH_COUNT] = {"linearize", "assemble_hessian", "factorize", "backsolve", "linear_error",
-                                     "retract", "error", "factor_small", "factor_big", "factor_leaf"};
+                                     "retract", "error", "factor_small", "factor_big", "factor_leaf",
+                                     "big_syrk", "big_trsm", "big_potrf0", "big_gather", "backsolve_launch"};
 
 struct Timer {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, pool;
@@ -538,12 +540,33 @@ void dev_factorize(gsx_context* c, double lambda) {
     if (B.count) {
       if (c->profiling) timer_begin(c, PH_FACTOR_BIG);
       // children of every earlier level are complete: deterministic extend-add into this level's big fronts
+      const bool prof = c->profiling != 0;
+      if (prof) timer_begin(c, PH_K_GATHER);
       launch_big_gather(c->GA, S.gseg_lvl_ptr[l], S.gseg_lvl_ptr[l + 1] - S.gseg_lvl_ptr[l], S.gm_lvl_ptr[l],
                         S.gm_lvl_ptr[l + 1] - S.gm_lvl_ptr[l], c->d_arena.p, c->stream);
+      if (prof) timer_end(c, PH_K_GATHER);
+      if (prof) timer_begin(c, PH_K_POTRF0);
       launch_big_potrf0(c->d_big.p + B.begin, B.count, c->d_arena.p, c->d_status.p, c->stream);
-      for (int kb = 0; kb < B.steps; ++kb)
-        launch_big_step(c->DS, c->d_big.p + B.begin, B.count, kb, B.row_tiles[kb], B.pairs[kb], c->d_arena.p,
-                        c->d_status.p, c->stream);
+      if (prof) timer_end(c, PH_K_POTRF0);
+      for (int kb = 0; kb < B.steps; ++kb) {
+        if (!prof) {
+          launch_big_step(c->DS, c->d_big.p + B.begin, B.count, kb, B.row_tiles[kb], B.pairs[kb], c->d_arena.p,
+                          c->d_status.p, c->stream);
+        } else {  // one HIP-event pair per kernel launch
+          if (B.row_tiles[kb] > 0) {
+            timer_begin(c, PH_K_TRSM);
+            launch_big_step(c->DS, c->d_big.p + B.begin, B.count, kb, B.row_tiles[kb], B.pairs[kb], c->d_arena.p,
+                            c->d_status.p, c->stream, 1);
+            timer_end(c, PH_K_TRSM);
+          }
+          if (B.pairs[kb] > 0) {
+            timer_begin(c, PH_K_SYRK);
+            launch_big_step(c->DS, c->d_big.p + B.begin, B.count, kb, B.row_tiles[kb], B.pairs[kb], c->d_arena.p,
+                            c->d_status.p, c->stream, 2);
+            timer_end(c, PH_K_SYRK);
+          }
+        }
+      }
       if (c->profiling) timer_end(c, PH_FACTOR_BIG);
     }
   }
@@ -559,8 +582,10 @@ void dev_backsolve(gsx_context* c) {
     if (B.count) {
       int maxn = 0;
       for (int k = se; k < S.lvl_ptr[l + 1]; ++k) maxn = std::max(maxn, S.N[S.sched[k]]);
+      if (c->profiling) timer_begin(c, PH_K_BACKSOLVE);
       launch_backsolve(c->DS, c->d_sched.p + se, S.lvl_ptr[l + 1] - se, 1024, maxn, c->d_arena.p, c->d_delta.p,
                        c->d_status.p, c->stream);
+      if (c->profiling) timer_end(c, PH_K_BACKSOLVE);
     }
     for (const SmallLaunch& sl : c->small_launch[l])
       launch_backsolve(c->DS, c->d_sched.p + sl.begin, sl.count, sl.max_n <= 48 ? 64 : 256, sl.max_n, c->d_arena.p,
