@@ -454,12 +454,16 @@ __global__ void assemble_h_kernel(DevProblem P, DevSymbolic S, const int* vars, 
   for (int e = lane; e < psize; e += 64) panel[e] = 0;
   // Terms are 32-byte records fetched through the scalar path (wave-uniform index); two terms are in
   // flight per iteration so that their Jacobian loads overlap (the loop is latency-, not issue-bound).
-  const i64 t1 = S.term_ptr[v + 1];
+  // Each wave takes a CONTIGUOUS chunk of the term list (the diagonal and rhs terms of one factor are
+  // neighbours and share the factor's Jacobian cache lines).
   const int uw = __builtin_amdgcn_readfirstlane(wave);
-  for (i64 t = S.term_ptr[v] + uw; t < t1; t += 2 * nw) {
+  const i64 tb0 = S.term_ptr[v], tn = S.term_ptr[v + 1] - tb0;
+  const i64 chunk = ((tn + nw - 1) / nw + 1) & ~i64(1);
+  const i64 t1 = min(tb0 + tn, tb0 + (uw + 1) * chunk);
+  for (i64 t = tb0 + uw * chunk; t < t1; t += 2) {
     const TermRec ta = S.terms[t];
-    const bool has_b = t + nw < t1;
-    const TermRec tb = S.terms[has_b ? t + nw : t];
+    const bool has_b = t + 1 < t1;
+    const TermRec tb = S.terms[has_b ? t + 1 : t];
     const double* Ja = jac + ta.jac;
     const double* Jb = jac + tb.jac;
     const int nea = ta.dB * dA, neb = has_b ? tb.dB * dA : 0;
