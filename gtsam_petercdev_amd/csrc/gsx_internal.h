@@ -14,6 +14,7 @@ constexpr int kSmallMaxN = 140;     // 140^2 * 8 B = 156.8 KB <= 160 KB LDS
 constexpr int kTile = 32;           // tile edge of the blocked big-front path
 constexpr int kGatherChunk = 48;    // sources per gather segment (one wave)
 constexpr int kLeafMaxF = 16;      // leaf cliques with at most this many frontal scalars use the panel-only kernel
+constexpr int kLeafMaxPanel = 8192; // doubles of LDS (n x F) a lean leaf may use: 64 KB
 
 struct HostProblem {
   int n_vars = 0, n_factors = 0;
@@ -39,6 +40,7 @@ struct Symbolic {
   std::vector<int> F, S, N;          // frontal dim, separator dim, n = F+S+1
   std::vector<int64_t> off;          // arena offset (doubles) of the n x n column-major front
   std::vector<int> level;            // 0 = leaves
+  std::vector<char> cls, lean;       // size class (0 leaf kernel, 1 small, 2 big); lean leaf (no Schur complement stored)
   std::vector<int> child_ptr, children;  // CSR front -> children (in the reference's child order)
   // scalar row maps
   std::vector<int64_t> cmap_ptr;     // front -> offset in cmap of its (S+1) update-row -> parent-row map
@@ -68,6 +70,7 @@ struct Symbolic {
   std::vector<int> gt_ld, gt_dims;   // destination leading dimension; dB | dA << 8 | diag << 16
   std::vector<int64_t> gt_ptr;       // task -> range in the source arrays (size n_tasks + 1)
   std::vector<int> gs_child, gs_loc; // source: child front id, offset of the block inside the child's front
+  std::vector<int> gs_loc2;          // lean child: row of the second factor in its L panel (gs_loc = row of the first); else -1
   std::vector<int> gt_lvl_ptr;       // level of the PARENT -> task range (size n_levels + 1)
   // segments of the source lists (one wave each) and the multi-segment tasks that need a combine pass
   std::vector<int> gseg_task, gseg_slot;          // segment -> task, scratch slot (-1: adds straight to dst)

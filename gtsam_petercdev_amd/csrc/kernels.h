@@ -39,6 +39,7 @@ struct DevSymbolic {
   // fronts
   const i64* fr_off;            // arena offset
   const int *fr_N, *fr_F, *fr_nfv, *fr_fvar_ptr, *fvars, *fr_parent, *fr_child_ptr, *children;
+  const int* fr_lean;           // 1: lean leaf — only its n x F L panel is stored, no Schur complement
   const i64 *cmap_ptr, *gidx_ptr;
   const int *cmap, *gidx;
   // H panels
@@ -94,14 +95,17 @@ void launch_big_step(const DevSymbolic& S, const BigDesc* descs, int count, int 
 void launch_front_leaf(const DevProblem& P, const DevSymbolic& S, const int* ids, int count, int max_panel, int threads,
                        const double* H, const double* damp, const double* scalars, double* arena, DevStatus* status,
                        hipStream_t st);
+// A gather source is either a block of a child's stored Schur complement (gs_ld = child ld, entry (i, j) at
+// gs_off + i + j ld) or, for a lean leaf child, the product form: gs_ld = ld | F << 24 and the block is
+// -W_b W_a' with W_b = rows gs_off.., W_a = rows gs_off2.. of the child's n x F L panel.
 struct GatherArgs {
-  const i64 *gt_dst, *gs_off, *seg_begin, *seg_end;
+  const i64 *gt_dst, *gs_off, *gs_off2, *seg_begin, *seg_end;
   const int *gt_ld, *gt_dims, *gs_ld, *seg_task, *seg_slot, *gm_task, *gm_slot, *gm_nslots;
-  double* scratch;  // slots x 128 doubles
+  double* scratch;  // slots x 256 doubles (a 16 x 16 accumulator tile in matrix-core register layout)
 };
 void launch_big_gather(const GatherArgs& G, int seg0, int nseg, int m0, int nm, double* arena, hipStream_t st);
-void launch_backsolve(const DevSymbolic& S, const int* ids, int count, int threads, int max_n, const double* arena,
-                      double* delta, DevStatus* status, hipStream_t st);
+void launch_backsolve(const DevSymbolic& S, const int* ids, int count, int threads, int max_n, bool big,
+                      const double* arena, double* delta, DevStatus* status, hipStream_t st);
 void launch_set_scalar(double* scalars, int slot, double v, hipStream_t st);
 // dense unit kernel for gsx_cholesky_partial: in-place lower partial Cholesky of an n x n
 // column-major matrix (lower triangle significant)

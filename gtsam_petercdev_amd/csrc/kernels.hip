@@ -838,6 +838,8 @@ __global__ void front_leaf_kernel(DevProblem P, DevSymbolic S, const int* ids, c
   double* A = arena + S.fr_off[f];
   for (int c = wave; c < F; c += nw)
     for (int r = c + lane; r < n; r += 64) A[r + (i64)c * n] = Pn[r + c * n];
+  // a lean leaf stops here: its big parent's gather forms the Schur complement blocks from this panel
+  if (S.fr_lean[f]) return;
   // Schur complement -L21 L21' as an outer product, thread-per-row: row r's F values stay in registers
   // (F <= kLeafMaxF), the threads of a row split the columns, two columns in flight per iteration.
   const int s1 = n - F;
@@ -897,52 +899,95 @@ __global__ void __launch_bounds__(256) big_gather_seg_kernel(GatherArgs G, int s
   const int sg = seg0 + sw;
   const int t = G.seg_task[sg], slot = G.seg_slot[sg];
   const int dims = G.gt_dims[t], dB = dims & 255, dA = (dims >> 8) & 255, diag = dims >> 16;
-  const int ld = G.gt_ld[t], ne = dB * dA;
+  const int ld = G.gt_ld[t];
   double* dst = arena + G.gt_dst[t];
   const i64 s0 = G.seg_begin[sg], s1 = G.seg_end[sg];
+  if (dB <= 16 && dA <= 16) {
+    // The destination block is one 16 x 16 FP64 matrix-core tile (entry (lk + 4q, li) in acc[q]).  Stored
+    // sources are added entry by entry; a lean leaf's source is the rank-F product -W_b W_a' of two row blocks of
+    // its L panel, one v_mfma_f64_16x16x4 per four panel columns — the Schur complement of a landmark is never
+    // written to or read from HBM.  Sources are taken in list (child) order: deterministic.
+    const int li = lane & 15, lk = lane >> 4;
+    const bool rowB = li < dB, colA = li < dA;
+    bool act[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) act[q] = (lk + 4 * q < dB) && colA && !(diag && lk + 4 * q < li);
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    i64 s = s0;
+    while (s < s1) {
+      const int f0 = G.gs_ld[s];
+      // fast path: four lean sources with F <= 4 (BAL landmarks): eight loads in flight, then four MFMAs
+      if (s + 4 <= s1 && (f0 >> 24) > 0 && (f0 >> 24) <= 4) {
+        const int f1 = G.gs_ld[s + 1], f2 = G.gs_ld[s + 2], f3 = G.gs_ld[s + 3];
+        const int F1 = f1 >> 24, F2 = f2 >> 24, F3 = f3 >> 24;
+        if (F1 > 0 && F1 <= 4 && F2 > 0 && F2 <= 4 && F3 > 0 && F3 <= 4) {
+          const int F0 = f0 >> 24;
+          const i64 b0 = G.gs_off[s], b1 = G.gs_off[s + 1], b2 = G.gs_off[s + 2], b3 = G.gs_off[s + 3];
+          const i64 a0 = G.gs_off2[s], a1 = G.gs_off2[s + 1], a2 = G.gs_off2[s + 2], a3 = G.gs_off2[s + 3];
+          const i64 l0 = f0 & 0xFFFFFF, l1 = f1 & 0xFFFFFF, l2 = f2 & 0xFFFFFF, l3 = f3 & 0xFFFFFF;
+          double x0 = 0, x1 = 0, x2 = 0, x3 = 0, y0 = 0, y1 = 0, y2 = 0, y3 = 0;
+          if (rowB) {
+            if (lk < F0) x0 = arena[b0 + li + lk * l0];
+            if (lk < F1) x1 = arena[b1 + li + lk * l1];
+            if (lk < F2) x2 = arena[b2 + li + lk * l2];
+            if (lk < F3) x3 = arena[b3 + li + lk * l3];
+          }
+          if (colA) {
+            if (lk < F0) y0 = arena[a0 + li + lk * l0];
+            if (lk < F1) y1 = arena[a1 + li + lk * l1];
+            if (lk < F2) y2 = arena[a2 + li + lk * l2];
+            if (lk < F3) y3 = arena[a3 + li + lk * l3];
+          }
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-x0, y0, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1, y1, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-x2, y2, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-x3, y3, acc, 0, 0, 0);
+          s += 4;
+          continue;
+        }
+      }
+      const i64 o = G.gs_off[s];
+      const i64 l = f0 & 0xFFFFFF;
+      const int Fc = f0 >> 24;
+      if (Fc == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (act[q]) acc[q] += arena[o + (lk + 4 * q) + li * l];
+      } else {
+        const i64 o2 = G.gs_off2[s];
+        for (int kk = 0; kk < Fc; kk += 4) {
+          const int k = kk + lk;
+          const double x = (k < Fc && rowB) ? arena[o + li + k * l] : 0.0;
+          const double y = (k < Fc && colA) ? arena[o2 + li + k * l] : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-x, y, acc, 0, 0, 0);
+        }
+      }
+      ++s;
+    }
+    if (slot < 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (act[q]) dst[(lk + 4 * q) + (i64)li * ld] += acc[q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) G.scratch[(i64)slot * 256 + q * 64 + lane] = acc[q];
+    }
+    return;
+  }
+  // blocks wider than a matrix-core tile (variables of more than 16 dimensions): stored sources only, never split
+  const int ne = dB * dA;
   for (int eb = 0; eb < ne; eb += 128) {
     const int ea = eb + lane, ebb = eb + 64 + lane;
     const int ia = ea % dB, ja = ea / dB, ib = ebb % dB, jb = ebb / dB;
     const bool act_a = (ea < ne) && !(diag && ia < ja), act_b = (ebb < ne) && !(diag && ib < jb);
     double acc_a = 0, acc_b = 0;
-    i64 s = s0;
-    for (; s + 4 <= s1; s += 4) {  // 4 sources x 2 entries: up to 8 loads in flight, summed in list order
-      const i64 o0 = G.gs_off[s], o1 = G.gs_off[s + 1], o2 = G.gs_off[s + 2], o3 = G.gs_off[s + 3];
-      const i64 l0 = G.gs_ld[s], l1 = G.gs_ld[s + 1], l2 = G.gs_ld[s + 2], l3 = G.gs_ld[s + 3];
-      double a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
-      if (act_a) {
-        a0 = arena[o0 + ia + ja * l0];
-        a1 = arena[o1 + ia + ja * l1];
-        a2 = arena[o2 + ia + ja * l2];
-        a3 = arena[o3 + ia + ja * l3];
-      }
-      if (act_b) {
-        b0 = arena[o0 + ib + jb * l0];
-        b1 = arena[o1 + ib + jb * l1];
-        b2 = arena[o2 + ib + jb * l2];
-        b3 = arena[o3 + ib + jb * l3];
-      }
-      acc_a += a0;
-      acc_a += a1;
-      acc_a += a2;
-      acc_a += a3;
-      acc_b += b0;
-      acc_b += b1;
-      acc_b += b2;
-      acc_b += b3;
-    }
-    for (; s < s1; ++s) {
+    for (i64 s = s0; s < s1; ++s) {
       const i64 o0 = G.gs_off[s], l0 = G.gs_ld[s];
       if (act_a) acc_a += arena[o0 + ia + ja * l0];
       if (act_b) acc_b += arena[o0 + ib + jb * l0];
     }
-    if (slot < 0) {
-      if (act_a) dst[ia + (i64)ja * ld] += acc_a;
-      if (act_b) dst[ib + (i64)jb * ld] += acc_b;
-    } else {  // ne <= 128 guaranteed for split tasks
-      G.scratch[(i64)slot * 128 + lane] = acc_a;
-      G.scratch[(i64)slot * 128 + 64 + lane] = acc_b;
-    }
+    if (act_a) dst[ia + (i64)ja * ld] += acc_a;
+    if (act_b) dst[ib + (i64)jb * ld] += acc_b;
   }
 }
 
@@ -952,15 +997,16 @@ __global__ void __launch_bounds__(256) big_gather_combine_kernel(GatherArgs G, i
   if (mw >= nm) return;
   const int t = G.gm_task[m0 + mw], slot0 = G.gm_slot[m0 + mw], ns = G.gm_nslots[m0 + mw];
   const int dims = G.gt_dims[t], dB = dims & 255, dA = (dims >> 8) & 255, diag = dims >> 16;
-  const int ld = G.gt_ld[t], ne = dB * dA;
+  const int ld = G.gt_ld[t];
   double* dst = arena + G.gt_dst[t];
-  for (int half = 0; half < 2; ++half) {
-    const int e = half * 64 + lane;
-    const int i = e % dB, j = e / dB;
-    if (e >= ne || (diag && i < j)) continue;
+  const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = lk + 4 * q;
+    if (r >= dB || li >= dA || (diag && r < li)) continue;
     double acc = 0;
-    for (int k = 0; k < ns; ++k) acc += G.scratch[(i64)(slot0 + k) * 128 + e];
-    dst[i + (i64)j * ld] += acc;
+    for (int k = 0; k < ns; ++k) acc += G.scratch[(i64)(slot0 + k) * 256 + q * 64 + lane];
+    dst[r + (i64)li * ld] += acc;
   }
 }
 
@@ -1255,7 +1301,8 @@ void launch_big_step(const DevSymbolic& S, const BigDesc* descs, int count, int 
 //   L11' x_F = d - L21' x_S, blocked by 32 columns from the last panel to the first.
 // ---------------------------------------------------------------------------------------------
 constexpr int TB = 32;  // panel width of the back-substitution (independent of the factorization tile)
-__global__ void backsolve_kernel(DevSymbolic S, const int* ids, const double* arena, double* delta, DevStatus* status) {
+__global__ void backsolve_kernel(DevSymbolic S, const int* ids, int big, const double* arena, double* delta,
+                                 DevStatus* status) {
   extern __shared__ double xs[];  // n-1 solution entries of this front (frontal + separator)
   __shared__ double tile[TB][TB + 1];
   __shared__ double y[TB];
@@ -1270,7 +1317,7 @@ __global__ void backsolve_kernel(DevSymbolic S, const int* ids, const double* ar
   // big fronts carry (L^-1)' of every 32x32 diagonal tile in that tile's strictly upper triangle
   // (diag_tile_factor; kTile == TB): the tile solve is then a 32-term dot product per lane instead of
   // a 32-step serial substitution with divisions.
-  const bool has_inv = (n > kSmallMaxN) && (T == TB);
+  const bool has_inv = big && (T == TB);
   const int nblk = (F + TB - 1) / TB;
   for (int kb = nblk - 1; kb >= 0; --kb) {
     const int c0 = kb * TB, w = min(TB, F - c0);
@@ -1326,14 +1373,15 @@ __global__ void backsolve_kernel(DevSymbolic S, const int* ids, const double* ar
     __syncthreads();
   }
 }
-void launch_backsolve(const DevSymbolic& S, const int* ids, int count, int threads, int max_n, const double* arena,
-                      double* delta, DevStatus* status, hipStream_t st) {
+void launch_backsolve(const DevSymbolic& S, const int* ids, int count, int threads, int max_n, bool big,
+                      const double* arena, double* delta, DevStatus* status, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
     hipFuncSetAttribute((const void*)backsolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     attr = true;
   }
-  if (count) backsolve_kernel<<<count, threads, (size_t)max_n * sizeof(double), st>>>(S, ids, arena, delta, status);
+  if (count)
+    backsolve_kernel<<<count, threads, (size_t)max_n * sizeof(double), st>>>(S, ids, big ? 1 : 0, arena, delta, status);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -100,14 +100,14 @@ struct gsx_context {
   DevBuf<TermRec> d_terms;
   DevBuf<VarRec> d_var_recs;
   DevBuf<ChildRec> d_child_recs;
-  DevBuf<int> d_fr_N, d_fr_F, d_fr_nfv, d_fr_fvar_ptr, d_fvars, d_fr_parent, d_fr_child_ptr, d_children, d_cmap,
+  DevBuf<int> d_fr_N, d_fr_F, d_fr_nfv, d_fr_fvar_ptr, d_fvars, d_fr_parent, d_fr_lean, d_fr_child_ptr, d_children, d_cmap,
       d_gidx, d_h_rows, d_hmap, d_h_loc, d_sched, d_hvars;
   DevBuf<BigDesc> d_big;
   DevSymbolic DS{};
   // schedule
   std::vector<std::vector<SmallLaunch>> small_launch;  // per level
   std::vector<std::vector<SmallLaunch>> leaf_launch;   // per level (panel-only leaf kernel)
-  DevBuf<i64> d_gt_dst, d_gs_off, d_seg_begin, d_seg_end;  // gather tasks / segments for big parents
+  DevBuf<i64> d_gt_dst, d_gs_off, d_gs_off2, d_seg_begin, d_seg_end;  // gather tasks / segments for big parents
   DevBuf<int> d_gt_ld, d_gt_dims, d_gs_ld, d_seg_task, d_seg_slot, d_gm_task, d_gm_slot, d_gm_nslots;
   DevBuf<double> d_gscratch;
   GatherArgs GA{};
@@ -282,6 +282,7 @@ gsx_status upload_symbolic(gsx_context* c) {
   HIPCHK(c, c->d_fr_fvar_ptr.upload(S.fvar_ptr, st));
   HIPCHK(c, c->d_fvars.upload(S.fvars, st));
   HIPCHK(c, c->d_fr_parent.upload(S.parent, st));
+  HIPCHK(c, c->d_fr_lean.upload(std::vector<int>(S.lean.begin(), S.lean.end()), st));
   HIPCHK(c, c->d_fr_child_ptr.upload(S.child_ptr, st));
   HIPCHK(c, c->d_children.upload(S.children, st));
   HIPCHK(c, c->d_cmap_ptr.upload(std::vector<i64>(S.cmap_ptr.begin(), S.cmap_ptr.end()), st));
@@ -438,16 +439,23 @@ gsx_status upload_symbolic(gsx_context* c) {
   HIPCHK(c, c->d_big.upload(c->big_descs, st));
   {
     // gather sources as absolute arena offsets + leading dimension (no dependent metadata loads in the kernel)
-    std::vector<i64> gs_off(S.gs_child.size());
+    std::vector<i64> gs_off(S.gs_child.size()), gs_off2(S.gs_child.size());
     std::vector<int> gs_ld(S.gs_child.size());
     for (size_t i = 0; i < S.gs_child.size(); ++i) {
-      gs_off[i] = (i64)S.off[S.gs_child[i]] + S.gs_loc[i];
-      gs_ld[i] = S.N[S.gs_child[i]];
+      const int ch = S.gs_child[i];
+      gs_off[i] = (i64)S.off[ch] + S.gs_loc[i];
+      gs_off2[i] = S.gs_loc2[i] >= 0 ? (i64)S.off[ch] + S.gs_loc2[i] : 0;
+      if (S.N[ch] >= (1 << 24)) {
+        c->err = "front with more than 2^24 rows";
+        return GSX_E_INVALID;
+      }
+      gs_ld[i] = S.N[ch] | (S.gs_loc2[i] >= 0 ? S.F[ch] << 24 : 0);
     }
     HIPCHK(c, c->d_gt_dst.upload(std::vector<i64>(S.gt_dst.begin(), S.gt_dst.end()), st));
     HIPCHK(c, c->d_gt_ld.upload(S.gt_ld, st));
     HIPCHK(c, c->d_gt_dims.upload(S.gt_dims, st));
     HIPCHK(c, c->d_gs_off.upload(gs_off, st));
+    HIPCHK(c, c->d_gs_off2.upload(gs_off2, st));
     HIPCHK(c, c->d_gs_ld.upload(gs_ld, st));
     HIPCHK(c, c->d_seg_begin.upload(std::vector<i64>(S.gseg_begin.begin(), S.gseg_begin.end()), st));
     HIPCHK(c, c->d_seg_end.upload(std::vector<i64>(S.gseg_end.begin(), S.gseg_end.end()), st));
@@ -456,9 +464,9 @@ gsx_status upload_symbolic(gsx_context* c) {
     HIPCHK(c, c->d_gm_task.upload(S.gm_task, st));
     HIPCHK(c, c->d_gm_slot.upload(S.gm_slot, st));
     HIPCHK(c, c->d_gm_nslots.upload(S.gm_nslots, st));
-    HIPCHK(c, c->d_gscratch.alloc((size_t)std::max(S.g_max_slots, 1) * 128));
+    HIPCHK(c, c->d_gscratch.alloc((size_t)std::max(S.g_max_slots, 1) * 256));
     HIPCHK(c, hipStreamSynchronize(st));
-    c->GA = GatherArgs{c->d_gt_dst.p, c->d_gs_off.p, c->d_seg_begin.p, c->d_seg_end.p, c->d_gt_ld.p, c->d_gt_dims.p,
+    c->GA = GatherArgs{c->d_gt_dst.p, c->d_gs_off.p, c->d_gs_off2.p, c->d_seg_begin.p, c->d_seg_end.p, c->d_gt_ld.p, c->d_gt_dims.p,
                        c->d_gs_ld.p, c->d_seg_task.p, c->d_seg_slot.p, c->d_gm_task.p, c->d_gm_slot.p,
                        c->d_gm_nslots.p, c->d_gscratch.p};
   }
@@ -466,6 +474,7 @@ gsx_status upload_symbolic(gsx_context* c) {
   D.n_fronts = S.n_fronts;
   D.fr_off = c->d_fr_off.p; D.fr_N = c->d_fr_N.p; D.fr_F = c->d_fr_F.p; D.fr_nfv = c->d_fr_nfv.p;
   D.fr_fvar_ptr = c->d_fr_fvar_ptr.p; D.fvars = c->d_fvars.p; D.fr_parent = c->d_fr_parent.p;
+  D.fr_lean = c->d_fr_lean.p;
   D.fr_child_ptr = c->d_fr_child_ptr.p; D.children = c->d_children.p;
   D.cmap_ptr = c->d_cmap_ptr.p; D.gidx_ptr = c->d_gidx_ptr.p; D.cmap = c->d_cmap.p; D.gidx = c->d_gidx.p;
   D.h_off = c->d_h_off.p; D.hmap_ptr = c->d_hmap_ptr.p; D.h_rows = c->d_h_rows.p; D.hmap = c->d_hmap.p;
@@ -583,15 +592,15 @@ void dev_backsolve(gsx_context* c) {
       int maxn = 0;
       for (int k = se; k < S.lvl_ptr[l + 1]; ++k) maxn = std::max(maxn, S.N[S.sched[k]]);
       if (c->profiling) timer_begin(c, PH_K_BACKSOLVE);
-      launch_backsolve(c->DS, c->d_sched.p + se, S.lvl_ptr[l + 1] - se, 1024, maxn, c->d_arena.p, c->d_delta.p,
+      launch_backsolve(c->DS, c->d_sched.p + se, S.lvl_ptr[l + 1] - se, 1024, maxn, true, c->d_arena.p, c->d_delta.p,
                        c->d_status.p, c->stream);
       if (c->profiling) timer_end(c, PH_K_BACKSOLVE);
     }
     for (const SmallLaunch& sl : c->small_launch[l])
-      launch_backsolve(c->DS, c->d_sched.p + sl.begin, sl.count, sl.max_n <= 48 ? 64 : 256, sl.max_n, c->d_arena.p,
+      launch_backsolve(c->DS, c->d_sched.p + sl.begin, sl.count, sl.max_n <= 48 ? 64 : 256, sl.max_n, false, c->d_arena.p,
                        c->d_delta.p, c->d_status.p, c->stream);
     for (const SmallLaunch& sl : c->leaf_launch[l])
-      launch_backsolve(c->DS, c->d_sched.p + sl.begin, sl.count, sl.max_n <= 72 ? 64 : 256, sl.max_n, c->d_arena.p,
+      launch_backsolve(c->DS, c->d_sched.p + sl.begin, sl.count, sl.max_n <= 72 ? 64 : 256, sl.max_n, false, c->d_arena.p,
                        c->d_delta.p, c->d_status.p, c->stream);
   }
   timer_end(c, PH_BACKSOLVE);

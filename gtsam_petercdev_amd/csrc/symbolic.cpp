@@ -202,14 +202,33 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     S.S[f] = Sd;
     S.N[f] = F + Sd + 1;
     const int64_t nn = (int64_t)S.N[f] * S.N[f];
-    S.off[f + 1] = S.off[f] + ((nn + 1) & ~int64_t(1));  // 16-byte aligned fronts
     const double s1 = Sd + 1.0;
     S.flops += (double)F * F * F / 3.0 + (double)F * F * s1 + (double)F * s1 * s1;
     S.front_bytes += 8.0 * (double)nn;
     S.lpanel_bytes += 8.0 * (double)F * S.N[f];
     S.max_F = std::max<int64_t>(S.max_F, F);
     S.max_rows = std::max<int64_t>(S.max_rows, F + Sd);
-    if (S.N[f] <= kSmallMaxN) S.n_small++; else S.n_big++;
+  }
+  // Size class of a front: 0 = leaf kernel (no children, few frontal scalars: only the n x F panel lives in LDS),
+  // 1 = small (whole front in LDS), 2 = big (blocked path in HBM).  A leaf is LEAN when its parent is big and every
+  // separator block fits a 16 x 16 matrix-core tile: its Schur complement is never materialised — the parent's
+  // gather forms -L21 L21' block by block from the L panel — so it owns only n x F doubles of the arena and may
+  // have any number of rows.
+  S.lean.assign(nfr, 0);
+  S.cls.assign(nfr, 1);
+  for (int f = 0; f < nfr; ++f) {
+    const bool childless = S.child_ptr[f + 1] == S.child_ptr[f];
+    bool lean = childless && S.F[f] <= kLeafMaxF && S.F[f] > 0 && S.parent[f] >= 0 && S.N[S.parent[f]] > kSmallMaxN &&
+                (int64_t)S.N[f] * S.F[f] <= kLeafMaxPanel;
+    if (lean)
+      for (int k = S.fvar_ptr[f] + nfv[f]; k < S.fvar_ptr[f + 1]; ++k) lean = lean && P.dims[S.fvars[k]] <= 16;
+    S.lean[f] = lean;
+    if (lean) S.cls[f] = 0;
+    else if (S.N[f] > kSmallMaxN) S.cls[f] = 2;
+    else if (childless && S.F[f] <= kLeafMaxF) S.cls[f] = 0;
+    if (S.cls[f] == 2) S.n_big++; else S.n_small++;
+    const int64_t sz = lean ? (int64_t)S.N[f] * S.F[f] : (int64_t)S.N[f] * S.N[f];
+    S.off[f + 1] = S.off[f] + ((sz + 1) & ~int64_t(1));  // 16-byte aligned fronts
   }
   S.arena_size = S.off[nfr];
   for (int f = 0; f < nfr; ++f)  // children have smaller ids
@@ -359,11 +378,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     }
   }
   // ---- schedule: by level; inside a level: leaf-kernel fronts, other small (LDS) fronts by N, big fronts ----
-  auto cls = [&](int f) {
-    if (S.N[f] > kSmallMaxN) return 2;
-    if (S.child_ptr[f + 1] == S.child_ptr[f] && S.F[f] <= kLeafMaxF) return 0;
-    return 1;
-  };
+  auto cls = [&](int f) { return (int)S.cls[f]; };
   S.sched.resize(nfr);
   std::iota(S.sched.begin(), S.sched.end(), 0);
   std::stable_sort(S.sched.begin(), S.sched.end(), [&](int a, int b) {
@@ -390,12 +405,12 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     struct Contribution {
       int level;
       int64_t dst;
-      int ld, dims, child, loc;
+      int ld, dims, child, loc, loc2;   // loc2 >= 0: lean child, product form (rows loc.., rows loc2.. of its L panel)
     };
     std::vector<Contribution> cs;
     std::vector<int> lo;  // local scalar offsets of the parent's variables
     for (int p = 0; p < nfr; ++p) {
-      if (S.N[p] <= kSmallMaxN) continue;
+      if (S.cls[p] != 2) continue;
       // parent local offset of each variable
       std::vector<std::pair<int, int>> ploc;  // (var, offset)
       int o = 0;
@@ -434,7 +449,13 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
             c.ld = S.N[p];
             c.dims = dim[b] | (dim[a] << 8) | ((a == b) ? (1 << 16) : 0);
             c.child = ch;
-            c.loc = (Fc + coff[b]) + (Fc + coff[a]) * Nc;
+            if (S.lean[ch]) {
+              c.loc = Fc + coff[b];
+              c.loc2 = Fc + coff[a];
+            } else {
+              c.loc = (Fc + coff[b]) + (Fc + coff[a]) * Nc;
+              c.loc2 = -1;
+            }
             cs.push_back(c);
           }
       }
@@ -446,6 +467,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     S.gt_lvl_ptr.assign(S.n_levels + 1, 0);
     S.gs_child.resize(cs.size());
     S.gs_loc.resize(cs.size());
+    S.gs_loc2.resize(cs.size());
     for (size_t i = 0; i < cs.size(); ++i) {
       if (i == 0 || cs[i].dst != cs[i - 1].dst || cs[i].level != cs[i - 1].level) {
         S.gt_dst.push_back(cs[i].dst);
@@ -456,6 +478,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
       }
       S.gs_child[i] = cs[i].child;
       S.gs_loc[i] = cs[i].loc;
+      S.gs_loc2[i] = cs[i].loc2;
     }
     S.gt_ptr.push_back((int64_t)cs.size());
     for (int l = 0; l < S.n_levels; ++l) S.gt_lvl_ptr[l + 1] += S.gt_lvl_ptr[l];
@@ -473,7 +496,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
         const int64_t b = S.gt_ptr[t], e = S.gt_ptr[t + 1];
         const int dB = S.gt_dims[t] & 255, dA = (S.gt_dims[t] >> 8) & 255;
         const int64_t len = e - b;
-        const bool split = len > kGatherChunk && dB * dA <= 128;
+        const bool split = len > kGatherChunk && dB <= 16 && dA <= 16;
         if (!split) {
           S.gseg_task.push_back(t);
           S.gseg_begin.push_back(b);
