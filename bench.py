@@ -158,8 +158,7 @@ def main():
     kernels = [
         ("factor_leaf", "front_leaf_kernel", "hbm", split["leaf_bytes"]),
         ("factor_small", "front_small_kernel", "hbm", split["small_bytes"]),
-        ("big_syrk", "big_syrk_kernel", "mfma", split["big_syrk_flops"]),
-        ("big_trsm", "big_trsm_kernel", "mfma", split["big_trsm_flops"]),
+        ("big_syrk", "big_panel_kernel", "mfma", split["big_syrk_flops"] + split["big_trsm_flops"]),
         ("big_potrf0", "big_potrf0_kernel", "mfma", split["big_potrf_flops"]),
         ("big_gather", "big_gather_seg_kernel(+combine)", "hbm", split["gather_bytes"]),
         ("assemble_hessian", "assemble_h_kernel(+hessian_diag)", "hbm", st["jacobian_bytes"] + st["hessian_bytes"]),

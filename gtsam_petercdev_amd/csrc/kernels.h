@@ -64,9 +64,11 @@ struct DevStatus {
 enum { SC_LAMBDA = 0, SC_ERR = 1, SC_LIN0 = 2, SC_LIND = 3, SC_TRIAL_ERR = 4, SC_COUNT = 8 };
 
 struct BigDesc {   // one big front of a level
-  i64 off;
+  i64 off, xoff;             // arena offsets of the n x n front and of its n x F L-panel area
   int N, F, front, parent;   // parent front id (-1 root)
 };
+// a big front owns n x n doubles followed by its n x F L panel (rows below each diagonal tile)
+__host__ __device__ inline i64 big_panel_offset(int n) { return ((i64)n * n + 1) & ~(i64)1; }
 
 // ---- launches (all asynchronous on `st`) ---------------------------------------------------------
 void launch_linearize(const DevProblem& P, const int* const type_lists[6], const int type_counts[6],
@@ -90,8 +92,8 @@ void launch_big_init(const DevProblem& P, const DevSymbolic& S, const BigDesc* d
                      int max_nfv, const double* H, const double* damp, const double* scalars, double* arena,
                      hipStream_t st);
 void launch_big_potrf0(const BigDesc* descs, int count, double* arena, DevStatus* status, hipStream_t st);
-void launch_big_step(const DevSymbolic& S, const BigDesc* descs, int count, int kb, int max_row_tiles,
-                     int max_pairs, double* arena, DevStatus* status, hipStream_t st, int which = 0);
+void launch_big_step(const BigDesc* descs, int count, int kb, int max_pairs, double* arena, DevStatus* status,
+                     hipStream_t st);
 void launch_front_leaf(const DevProblem& P, const DevSymbolic& S, const int* ids, int count, int max_panel, int threads,
                        const double* H, const double* damp, const double* scalars, double* arena, DevStatus* status,
                        hipStream_t st);

@@ -1053,93 +1053,225 @@ void launch_big_init(const DevProblem& P, const DevSymbolic& S, const BigDesc* d
   big_add_h_kernel<<<dim3(max_nfv, count), 128, 0, st>>>(P, S, descs, H, damp, scalars, arena);
 }
 
-__device__ __forceinline__ double readlane_f64(double v, int src_lane) {  // src_lane must be wave-uniform
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_readlane(lo, src_lane);
-  hi = __builtin_amdgcn_readlane(hi, src_lane);
-  return __hiloint2double(hi, lo);
-}
-
-// Factor the diagonal tile (c0, w) of a big front ONCE, with an NT-thread workgroup.
-//   Ls (row-major, ld T+1) holds the tile on entry (lower triangle meaningful) and L on exit;
-//   Xs receives L^-1 (recursive doubling: X21 = -X22 (L21 X11), log2(T) levels of small parallel products);
-//   the front gets L in the lower triangle and (L^-1)' in the strictly upper triangle of the tile, so
-//   that the panel solve is a plain tile product; pivots are checked with choleskyPartial's failure
-//   semantics (gtsam/base/cholesky.cpp:145-158).
-// Potrf: every thread keeps its Q = T*T/NT tile entries in registers; per pivot the only shared traffic is
-// the current column (double-buffered in LDS) => ONE barrier, one LDS round trip and one rsqrt per pivot
-// (a lone wave issues ~1 instruction / 5 cycles on MI355X, so the chain is kept this short on purpose).
-#ifndef GSX_BIG_NT
-#define GSX_BIG_NT 1024
-#endif
-constexpr int NT = GSX_BIG_NT;    // threads of the big-front kernels
-constexpr int CG = NT / T;        // column groups
-constexpr int Q = T / CG;         // tile entries per thread
+// ---- big-front kernels: 256 threads = 4 waves, one per SIMD; every thread owns 4 entries of a 32 x 32 tile in
+// the FP64 matrix-core accumulator layout of its wave's 16 x 16 quadrant:
+//   wave wv: row half qr = wv & 1, column half qc = wv >> 1;  lane: li = lane & 15, lk = lane >> 4
+//   entry q (0..3): row r = 16 qr + li, column c_q = 16 qc + 4 q + lk
+// (the quadrant is computed TRANSPOSED on the matrix cores — D[i = column][j = row] — so that the 16 lanes li run
+//  down a column of the column-major front: 128-byte segments for the tile's global loads and stores).
+constexpr int NT = 256;
+constexpr int KP = 4;             // pivots per barrier in the tile factorization
 typedef double (*TilePtr)[T + 1];
 constexpr size_t kTileBytes = sizeof(double) * T * (T + 1);
 
-__device__ __forceinline__ void diag_tile_factor(double* A, int n, int F, int c0, int w, TilePtr Ls, TilePtr Xs,
-                                                 TilePtr Tm, DevStatus* status, int front) {
-  __shared__ double colb[2][T];
-  const int tid = threadIdx.x;
-  const int r = tid % T, cbase = tid / T;  // entries (r, cbase + CG q), q = 0..Q-1
-  double v[Q];
+struct TileLane {
+  int r, c[4], r0, cq0, li, lk;   // r0 = 16 qr, cq0 = 16 qc
+  __device__ __forceinline__ TileLane() {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    li = lane & 15;
+    lk = lane >> 4;
+    r0 = 16 * (wv & 1);
+    cq0 = 16 * (wv >> 1);
+    r = r0 + li;
 #pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    const int c = cbase + CG * q;
-    v[q] = (r >= c && r < w) ? Ls[r][c] : 0.0;
+    for (int q = 0; q < 4; ++q) c[q] = cq0 + 4 * q + lk;
   }
-  if (cbase == 0) colb[0][r] = v[0];
-  int fail = 0;
-  for (int j = 0; j < w; ++j) {
-    __syncthreads();
-    const double* cur = colb[j & 1];
-    double* nxt = colb[(j + 1) & 1];
-    const double p = cur[j];
-    if (!(p > 0)) fail = 1;
-    const double inv = (p > 0) ? rsqrt(p) : 1.0;
-    const double lr = (r > j) ? cur[r] * inv : 0.0;
+};
+
+// acc[q] = sum_{k < KMAX} Pc[c_q][k] * Pr[r][k]  (both tiles row-major in LDS, zero-padded)
+template <int KMAX>
+__device__ __forceinline__ v4d tile_product(const TileLane& L, TilePtr Pc, TilePtr Pr) {
+  v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      const int c = cbase + CG * q;
-      if (c == j) {
-        v[q] = (r == j) ? p * inv : lr;  // final L[r][j]
-      } else if (c > j && r >= c) {
-        v[q] -= lr * (cur[c] * inv);
-        if (c == j + 1) nxt[r] = v[q];
+  for (int k0 = 0; k0 < KMAX; k0 += 4) {
+    const double a = Pc[L.cq0 + L.li][k0 + L.lk];  // A[i = column][k]
+    const double b = Pr[L.r0 + L.li][k0 + L.lk];   // B[k][j = row]
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// Factor the diagonal tile (c0, w) of a big front ONCE.  The tile arrives in registers (v[q] = entry (r, c_q),
+// zero above the diagonal and beyond w) — straight from the trailing update that produced it.
+//   The front gets L in the tile's lower triangle and (L^-1)' in its strictly upper triangle, so that the panel
+//   solve is a plain tile product, and 1 / L_cc at the diagonal position of the front's L-panel area (Xp);
+//   pivots are checked with choleskyPartial's failure semantics (gtsam/base/cholesky.cpp:145-158).
+// Instruction issue of a lone wave (~1 / 5 cycles), barriers and LDS round trips — not flops — are what a 32 x 32
+// factorization costs, so it runs KP = 4 pivots per stage, two 4-wave barriers each:
+//   A. the KP current columns are in LDS; every thread re-derives the KP x KP pivot block and the KP entries
+//      L[r][j..j+KP) of its own row in registers (KP dependent rsqrt's) and row owners publish them; the wave whose
+//      quadrant lies above the diagonal inverts the pivot block instead;
+//   B. every thread applies the rank-KP update to its four entries from its row's and its columns' published
+//      values, and the owners of the next KP columns publish them.
+// The inverse then takes three levels of recursive doubling X21 = -X22 (L21 X11) (fixed-length zero-padded dots).
+template <int B>
+__device__ __forceinline__ void inverse_doubling_level(TilePtr Ls, TilePtr Xs, TilePtr Tm) {
+  constexpr int total = (T / (2 * B)) * B * B;
+  const int e = threadIdx.x;
+  const int pair = e / (B * B), loc = e % (B * B), i = loc % B, jx = loc / B, s0 = pair * 2 * B;
+  if (e < total) {
+    double acc = 0;
+#pragma unroll
+    for (int k = 0; k < B; ++k) acc += Ls[s0 + B + i][s0 + k] * Xs[s0 + k][s0 + jx];
+    Tm[s0 + B + i][s0 + jx] = acc;
+  }
+  __syncthreads();
+  if (e < total) {
+    double acc = 0;
+#pragma unroll
+    for (int k = 0; k < B; ++k) acc += Xs[s0 + B + i][s0 + B + k] * Tm[s0 + B + k][s0 + jx];
+    Xs[s0 + B + i][s0 + jx] = -acc;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void diag_tile_factor(const TileLane& L, double v[4], double* A, double* Xp, int n, int F,
+                                                 int c0, int w, TilePtr Ls, TilePtr Xs, TilePtr Tm, DevStatus* status,
+                                                 int front) {
+  __shared__ double colb[2][KP][T];  // the KP current columns (updated through the previous stage), double-buffered
+  __shared__ double dinv[T];         // 1 / L_cc
+  STAMP_BEGIN
+  const int tid = threadIdx.x, r = L.r;
+  const int wv = tid >> 6;
+  const int xc = L.cq0 + L.li;  // the column whose L values this lane feeds to the matrix core (its row is r)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (L.c[q] < KP) colb[0][L.c[q]][r] = v[q];
+    Xs[r][L.c[q]] = 0.0;  // the diagonal KP x KP blocks are filled in by the stages
+    Ls[r][L.c[q]] = 0.0;  // L columns are filled in by the stages as they become final
+  }
+  if (tid < T) dinv[tid] = 0.0;
+  v4d acc = {v[0], v[1], v[2], v[3]};
+  const bool row_owner = L.cq0 == 0 && L.lk == 0;  // one lane per tile row (waves 0 and 1)
+  int fail = 0;
+  for (int j = 0, stage = 0; j < w; j += KP, ++stage) {
+    __syncthreads();
+    const double(*cur)[T] = colb[stage & 1];
+    double(*nxt)[T] = colb[(stage + 1) & 1];
+    // The pivot block is eliminated in root-free (L D L') form: u = unnormalised entries, d_k the pivots,
+    // rk = 1 / d_k.  A dependent FP64 operation costs a lone wave ~40 cycles and a transcendental ~90, so the
+    // chain from one pivot to the next is kept at  d_k -> rcp -> 3 FMAs -> 1 FMA -> d_{k+1};  the reciprocal
+    // square roots that scale the OUTPUT (L = u / sqrt(d)) are off that chain.
+    double am[KP][KP], u[KP][KP], wg[KP][KP], dk[KP], rk[KP], ur[KP], uc[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+      ur[k] = cur[k][r];
+      uc[k] = cur[k][xc];
+#pragma unroll
+      for (int m = k; m < KP; ++m) am[m][k] = cur[k][j + m];
+    }
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+      // wg[k][t] = u[k][t] / d_t, t < k
+#pragma unroll
+      for (int t = 0; t < k; ++t) wg[k][t] = u[k][t] * rk[t];
+      double d = am[k][k];
+#pragma unroll
+      for (int t = 0; t + 1 < k; ++t) d -= u[k][t] * wg[k][t];
+      if (k > 0) d = fma(-(u[k][k - 1] * u[k][k - 1]), rk[k - 1], d);  // the only use of rk[k-1] on the chain
+      const bool live = j + k < w;  // uniform: columns beyond the tile width do not exist
+      if (live && !(d > 0)) fail = 1;
+      dk[k] = d;
+      {
+        const double y0 = __builtin_amdgcn_rcp(d);
+        const double e = fma(-d, y0, 1.0);
+        const double t2 = fma(e, e, e);
+        const double y = fma(y0, t2, y0);  // y0 (1 + e + e^2): cubic convergence
+        rk[k] = (live && d > 0) ? y : (live ? 1.0 : 0.0);
+      }
+#pragma unroll
+      for (int m = k + 1; m < KP; ++m) {
+        double x = am[m][k];
+#pragma unroll
+        for (int t = 0; t < k; ++t) x -= u[m][t] * wg[k][t];
+        u[m][k] = x;
+      }
+#pragma unroll
+      for (int t = 0; t < k; ++t) {
+        ur[k] -= ur[t] * wg[k][t];
+        uc[k] -= uc[t] * wg[k][t];
+      }
+    }
+    // output scaling
+    double pinv[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+      const bool live = j + k < w;
+      const double y0 = __builtin_amdgcn_rsq(dk[k]);
+      const double e = fma(-dk[k] * y0, y0, 1.0);
+      const double y = fma(y0 * e, fma(e, 0.375, 0.5), y0);  // y0 (1 + e/2 + 3 e^2 / 8)
+      pinv[k] = (live && dk[k] > 0) ? y : (live ? 1.0 : 0.0);
+    }
+    if (wv == 2 && L.li < KP && L.lk < KP) {
+      // (wave 2's quadrant lies above the diagonal) inverse of the pivot block L_jj: P[m][k], m = li, k = lk
+      double piv[KP][KP], P[KP][KP];
+#pragma unroll
+      for (int k = 0; k < KP; ++k)
+#pragma unroll
+        for (int m = k + 1; m < KP; ++m) piv[m][k] = u[m][k] * pinv[k];
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        P[k][k] = pinv[k];
+#pragma unroll
+        for (int m = k + 1; m < KP; ++m) {
+          double sacc = 0.0;
+#pragma unroll
+          for (int t = k; t < m; ++t) sacc += piv[m][t] * P[t][k];
+          P[m][k] = -sacc * pinv[m];
+        }
+      }
+      double out = 0.0;
+#pragma unroll
+      for (int k = 0; k < KP; ++k)
+#pragma unroll
+        for (int m = k; m < KP; ++m)
+          if (L.li == m && L.lk == k) out = P[m][k];
+      Xs[j + L.li][j + L.lk] = out;
+      if (L.li == L.lk) dinv[j + L.li] = out;
+    }
+    // the pivot columns are final: L[r][j+k] = u / sqrt(d), written once per row (zero above the diagonal)
+    if (row_owner) {
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        const double below = ur[k] * pinv[k], diag = dk[k] * pinv[k];
+        Ls[r][j + k] = (r > j + k) ? below : ((r == j + k) ? diag : 0.0);
+      }
+    }
+    // rank-KP update of the wave's quadrant in ONE v_mfma_f64_16x16x4: D[c][r] -= sum_k (u_ck / d_k) u_rk;
+    // rows / columns up to the pivot block contribute zero operands
+    double a = 0.0, bb = 0.0;
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+      a = (L.lk == k) ? uc[k] * rk[k] : a;
+      bb = (L.lk == k) ? ur[k] : bb;
+    }
+    a = (xc >= j + KP) ? -a : 0.0;
+    bb = (r >= j + KP) ? bb : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
+    {
+      // the next KP columns are entry q* of the lanes of the waves whose column half holds them (wave-uniform)
+      const int qs = (j + KP - L.cq0) >> 2;
+      if (j + KP >= L.cq0 && qs < 4) {
+        const double pub = (qs == 0) ? acc[0] : ((qs == 1) ? acc[1] : ((qs == 2) ? acc[2] : acc[3]));
+        nxt[L.lk][r] = pub;
       }
     }
   }
   __syncthreads();
-#pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    const int c = cbase + CG * q;
-    Ls[r][c] = (r >= c) ? v[q] : 0.0;
-    Xs[r][c] = (r == c && r < w) ? 1.0 / v[q] : 0.0;
-  }
-  __syncthreads();
-  for (int b = 1; b < T; b <<= 1) {
-    const int bb = b * b, total = (T / (2 * b)) * bb;
-    for (int e = tid; e < total; e += NT) {
-      const int pair = e / bb, loc = e - pair * bb, i = loc % b, jx = loc / b, s0 = pair * 2 * b;
-      double acc = 0;
-      for (int k = jx; k < b; ++k) acc += Ls[s0 + b + i][s0 + k] * Xs[s0 + k][s0 + jx];
-      Tm[s0 + b + i][s0 + jx] = acc;
-    }
-    __syncthreads();
-    for (int e = tid; e < total; e += NT) {
-      const int pair = e / bb, loc = e - pair * bb, i = loc % b, jx = loc / b, s0 = pair * 2 * b;
-      double acc = 0;
-      for (int k = 0; k <= i; ++k) acc += Xs[s0 + b + i][s0 + b + k] * Tm[s0 + b + k][s0 + jx];
-      Xs[s0 + b + i][s0 + jx] = -acc;
-    }
-    __syncthreads();
-  }
+  STAMP_ADD(2)
+  STAMP_ADD(3)
+  inverse_doubling_level<4>(Ls, Xs, Tm);
+  inverse_doubling_level<8>(Ls, Xs, Tm);
+  inverse_doubling_level<16>(Ls, Xs, Tm);
+  STAMP_ADD(4)
   // write back: L in the lower triangle (incl. diagonal), (L^-1)' in the strictly upper triangle
-  for (int e = tid; e < w * w; e += NT) {
-    const int rr = e % w, cc = e / w;
-    A[(c0 + rr) + (i64)(c0 + cc) * n] = (rr >= cc) ? Ls[rr][cc] : Xs[cc][rr];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int rr = tid % T, cc = tid / T + 8 * q;
+    if (rr < w && cc < w) A[(c0 + rr) + (i64)(c0 + cc) * n] = (rr >= cc) ? Ls[rr][cc] : Xs[cc][rr];
   }
+  if (tid < w) Xp[(c0 + tid) + (i64)(c0 + tid) * n] = dinv[tid];
+  STAMP_ADD(5)
   if (tid == 0) {
     if (c0 + w == F) {  // last panel: conditioning test on the last two pivots
       const double p1 = Ls[w - 1][w - 1];
@@ -1158,61 +1290,35 @@ __device__ __forceinline__ void diag_tile_factor(double* A, int n, int F, int c0
 }
 
 // first diagonal tile of every big front of a level
-// (a single-wave, register-resident v_readlane formulation was measured too: slower — hipcc pads every
-//  VALU->v_readlane hazard with s_nop and spills the broadcast SGPRs)
 __global__ void __launch_bounds__(NT) big_potrf0_kernel(const BigDesc* descs, double* arena, DevStatus* status) {
   extern __shared__ double dyn_lds[];
   TilePtr Ls = (TilePtr)dyn_lds, Xs = (TilePtr)(dyn_lds + T * (T + 1)), Tm = (TilePtr)(dyn_lds + 2 * T * (T + 1));
   const BigDesc d = descs[blockIdx.x];
   double* A = arena + d.off;
   const int n = d.N, w = min(T, d.F);
-  for (int e = threadIdx.x; e < T * T; e += NT) {
-    const int r = e % T, c = e / T;
-    Ls[r][c] = (r < w && c <= r) ? A[r + (i64)c * n] : 0.0;
-  }
-  __syncthreads();
-  diag_tile_factor(A, n, d.F, 0, w, Ls, Xs, Tm, status, d.front);
+  const TileLane L;
+  double v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = (L.r >= L.c[q] && L.r < w) ? A[L.r + (i64)L.c[q] * n] : 0.0;
+  diag_tile_factor(L, v, A, arena + d.xoff, n, d.F, 0, w, Ls, Xs, Tm, status, d.front);
 }
 
-// panel step kb, part 1: rows below the diagonal tile  X <- X * L_kk^-T, as a tile product with the
-// explicit inverse parked in the diagonal tile's upper triangle.  One block per T rows.
-__global__ void __launch_bounds__(NT) big_trsm_kernel(const BigDesc* descs, int kb, double* arena) {
+// Panel step kb of every big front of a level, ONE launch: the block of lower tile pair (i, j)
+//   1. forms the two panel tiles it needs itself, X_i = A_ik L_kk^-T and X_j likewise, as tile products with the
+//      explicit inverse parked in the diagonal tile's upper triangle (a separate triangular-solve launch would
+//      cost more than recomputing them: the chain of panel steps is latency-bound),
+//   2. the diagonal pair (i, i) stores X_i — the final L rows — in the front's L-panel area (d.xoff; the raw panel
+//      stays untouched in the front, so no block races with another block's reads),
+//   3. applies the trailing update C[i,j] -= X_i X_j',
+//   4. pair (0,0) then factors the NEXT diagonal tile (look-ahead) straight from its accumulator registers.
+// All three tile products run on the FP64 matrix cores (v_mfma_f64_16x16x4, one 16 x 16 quadrant per wave): with
+// VALU dot products the kernel was bound by LDS operand reads (2 per FMA).
+__global__ void __launch_bounds__(NT) big_panel_kernel(const BigDesc* descs, int kb, double* arena, DevStatus* status) {
   extern __shared__ double dyn_lds[];
-  TilePtr Li = (TilePtr)dyn_lds, X = (TilePtr)(dyn_lds + T * (T + 1));
-  const BigDesc d = descs[blockIdx.y];
-  const int n = d.N, F = d.F, c0 = kb * T;
-  if (c0 >= F) return;
-  const int w = min(T, F - c0);
-  const int r0 = c0 + w + blockIdx.x * T;
-  if (r0 >= n) return;
-  const int h = min(T, n - r0);
-  double* A = arena + d.off;
-  const int tid = threadIdx.x;
-  for (int e = tid; e < w * w; e += NT) {
-    const int k = e % w, c = e / w;  // Li[c][k] = (L^-1)[c][k], k <= c
-    double v = 0.0;
-    if (k < c) v = A[(c0 + k) + (i64)(c0 + c) * n];
-    else if (k == c) v = 1.0 / A[(c0 + c) + (i64)(c0 + c) * n];
-    Li[c][k] = v;
-  }
-  for (int e = tid; e < h * w; e += NT) {
-    const int r = e % h, c = e / h;
-    X[r][c] = A[(r0 + r) + (i64)(c0 + c) * n];
-  }
-  __syncthreads();
-  for (int e = tid; e < h * w; e += NT) {
-    const int r = e % h, c = e / h;
-    double acc = 0;
-    for (int k = 0; k <= c; ++k) acc += X[r][k] * Li[c][k];
-    A[(r0 + r) + (i64)(c0 + c) * n] = acc;
-  }
-}
-
-// panel step kb, part 2: trailing update C[i,j] -= P_i P_j' over lower tile pairs.  The block of pair
-// (0,0) then factors the NEXT diagonal tile (look-ahead), so each diagonal tile is factored once.
-__global__ void __launch_bounds__(NT) big_syrk_kernel(const BigDesc* descs, int kb, double* arena, DevStatus* status) {
-  extern __shared__ double dyn_lds[];
-  TilePtr Pi = (TilePtr)dyn_lds, Pj = (TilePtr)(dyn_lds + T * (T + 1)), Pk = (TilePtr)(dyn_lds + 2 * T * (T + 1));
+  constexpr int TS = T * (T + 1);
+  TilePtr Ri = (TilePtr)dyn_lds, Rj = (TilePtr)(dyn_lds + TS), Li = (TilePtr)(dyn_lds + 2 * TS),
+          Xi = (TilePtr)(dyn_lds + 3 * TS), Xj = (TilePtr)(dyn_lds + 4 * TS);
+  STAMP_BEGIN
   const BigDesc d = descs[blockIdx.y];
   const int n = d.N, F = d.F, c0 = kb * T;
   if (c0 >= F) return;
@@ -1223,6 +1329,7 @@ __global__ void __launch_bounds__(NT) big_syrk_kernel(const BigDesc* descs, int 
   const int t = blockIdx.x;
   if (t >= npairs) return;
   double* A = arena + d.off;
+  double* X = arena + d.xoff;
   const int tid = threadIdx.x;
   int i = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
   while ((i + 1) * (i + 2) / 2 <= t) ++i;
@@ -1230,45 +1337,79 @@ __global__ void __launch_bounds__(NT) big_syrk_kernel(const BigDesc* descs, int 
   const int j = t - i * (i + 1) / 2;
   const int ri = base + i * T, rj = base + j * T;
   const int hi = min(T, n - ri), hj = min(T, n - rj);
-  for (int e = tid; e < hi * w; e += NT) {
-    const int r = e % hi, c = e / hi;
-    Pi[r][c] = A[(ri + r) + (i64)(c0 + c) * n];
+  const TileLane L;
+  // the C tile entries this thread updates: loads in flight while the panel tiles are formed
+  double cv[4];
+  bool live[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    live[q] = L.r < hi && L.c[q] < hj && !(i == j && L.r < L.c[q]);
+    cv[q] = live[q] ? A[(ri + L.r) + (i64)(rj + L.c[q]) * n] : 0.0;
   }
-  for (int e = tid; e < hj * w; e += NT) {
-    const int r = e % hj, c = e / hj;
-    Pj[r][c] = A[(rj + r) + (i64)(c0 + c) * n];
+  {
+    const int rr = tid % T;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int cc = tid / T + 8 * q;
+      // Li[c][k] = (L_kk^-1)[c][k], k <= c (row rr plays k); zero beyond w
+      double lv = 0.0;
+      if (rr < w && cc < w) {
+        if (rr < cc) lv = A[(c0 + rr) + (i64)(c0 + cc) * n];
+        else if (rr == cc) lv = X[(c0 + cc) + (i64)(c0 + cc) * n];  // 1 / L_cc, left there by the tile factorization
+      }
+      Li[cc][rr] = lv;
+      Ri[rr][cc] = (rr < hi && cc < w) ? A[(ri + rr) + (i64)(c0 + cc) * n] : 0.0;
+      if (i != j) Rj[rr][cc] = (rr < hj && cc < w) ? A[(rj + rr) + (i64)(c0 + cc) * n] : 0.0;
+    }
   }
   __syncthreads();
-  double outv[Q];
-  int cnt = 0;
-  for (int e = tid; e < hi * hj; e += NT, ++cnt) {
-    const int r = e % hi, c = e / hi;
-    double acc = 0;
-    for (int k = 0; k < w; ++k) acc += Pi[r][k] * Pj[c][k];
-    double v = 0.0;
-    if (!(i == j && r < c)) {
-      v = A[(ri + r) + (i64)(rj + c) * n] - acc;
-      A[(ri + r) + (i64)(rj + c) * n] = v;
-    }
+  {
+    // X[r][c] = sum_{k <= c} R[r][k] Linv[c][k]: columns of the first half only need k < 16
+    const bool half = L.cq0 == 0;  // wave-uniform
+    const v4d xi = half ? tile_product<16>(L, Li, Ri) : tile_product<T>(L, Li, Ri);
 #pragma unroll
-    for (int q = 0; q < Q; ++q)
-      if (q == cnt) outv[q] = v;
+    for (int q = 0; q < 4; ++q) {
+      Xi[L.r][L.c[q]] = xi[q];
+      if (i == j && L.r < hi && L.c[q] < w) X[(ri + L.r) + (i64)(c0 + L.c[q]) * n] = xi[q];
+    }
+    if (i != j) {
+      const v4d xj = half ? tile_product<16>(L, Li, Rj) : tile_product<T>(L, Li, Rj);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Xj[L.r][L.c[q]] = xj[q];
+    }
+  }
+  const TilePtr Xjj = (i != j) ? Xj : Xi;
+  __syncthreads();
+  double v[4];
+  {
+    const v4d acc = tile_product<T>(L, Xjj, Xi);  // acc[q] = sum_k Xj[c_q][k] Xi[r][k]
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      v[q] = cv[q] - acc[q];
+      if (live[q]) A[(ri + L.r) + (i64)(rj + L.c[q]) * n] = v[q];
+    }
   }
   if (t == 0 && base < F) {
-    // look-ahead: this block owns the next diagonal tile; keep its new values in LDS and factor it
-    __syncthreads();
-    for (int e = tid; e < T * T; e += NT) Pi[e % T][e / T] = 0.0;
-    __syncthreads();
-    cnt = 0;
-    for (int e = tid; e < hi * hj; e += NT, ++cnt) {
-      double v = 0.0;
+    // look-ahead: this block owns the next diagonal tile and factors it from its registers
+    const int wn = min(T, F - base);
 #pragma unroll
-      for (int q = 0; q < Q; ++q)
-        if (q == cnt) v = outv[q];
-      Pi[e % hi][e / hi] = v;
-    }
-    __syncthreads();
-    diag_tile_factor(A, n, F, base, min(T, F - base), Pi, Pj, Pk, status, d.front);
+    for (int q = 0; q < 4; ++q)
+      if (!(live[q] && L.r < wn && L.c[q] < wn)) v[q] = 0.0;
+    __syncthreads();  // every wave is done reading the panel tiles: Ri / Rj / Li become the factorization's scratch
+    STAMP_ADD(6)
+    diag_tile_factor(L, v, A, X, n, F, base, wn, Ri, Rj, Li, status, d.front);
+  }
+}
+
+// gsx_cholesky_partial's large case: move the L panel back under the diagonal tiles of the matrix
+__global__ void big_copy_panel_kernel(const BigDesc* descs, double* arena) {
+  const BigDesc d = descs[0];
+  double* A = arena + d.off;
+  const double* X = arena + d.xoff;
+  const i64 total = (i64)d.N * d.F;
+  for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (i64)gridDim.x * blockDim.x) {
+    const int r = (int)(e % d.N), c = (int)(e / d.N);
+    if (r >= min((c / T + 1) * T, d.F)) A[r + (i64)c * d.N] = X[r + (i64)c * d.N];
   }
 }
 
@@ -1276,8 +1417,7 @@ static void big_kernels_attr() {
   static bool done = false;
   if (done) return;
   hipFuncSetAttribute((const void*)big_potrf0_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (int)kTileBytes);
-  hipFuncSetAttribute((const void*)big_trsm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)kTileBytes);
-  hipFuncSetAttribute((const void*)big_syrk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (int)kTileBytes);
+  hipFuncSetAttribute((const void*)big_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * (int)kTileBytes);
   done = true;
 }
 
@@ -1286,14 +1426,11 @@ void launch_big_potrf0(const BigDesc* descs, int count, double* arena, DevStatus
   if (count) big_potrf0_kernel<<<count, NT, 3 * kTileBytes, st>>>(descs, arena, status);
 }
 
-void launch_big_step(const DevSymbolic& S, const BigDesc* descs, int count, int kb, int max_row_tiles, int max_pairs,
-                     double* arena, DevStatus* status, hipStream_t st, int which) {
-  if (!count) return;
+void launch_big_step(const BigDesc* descs, int count, int kb, int max_pairs, double* arena, DevStatus* status,
+                     hipStream_t st) {
+  if (!count || max_pairs <= 0) return;
   big_kernels_attr();
-  if (max_row_tiles > 0 && which != 2)
-    big_trsm_kernel<<<dim3(max_row_tiles, count), NT, 2 * kTileBytes, st>>>(descs, kb, arena);
-  if (max_pairs > 0 && which != 1)
-    big_syrk_kernel<<<dim3(max_pairs, count), NT, 3 * kTileBytes, st>>>(descs, kb, arena, status);
+  big_panel_kernel<<<dim3(max_pairs, count), NT, 5 * kTileBytes, st>>>(descs, kb, arena, status);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1309,6 +1446,8 @@ __global__ void backsolve_kernel(DevSymbolic S, const int* ids, int big, const d
   const int f = ids[blockIdx.x];
   const int n = S.fr_N[f], F = S.fr_F[f];
   const double* A = arena + S.fr_off[f];
+  // big fronts keep the rows of L below each diagonal tile in their L-panel area right after the n x n front
+  const double* Lp = big ? A + big_panel_offset(n) : A;
   const int* gi = S.gidx + S.gidx_ptr[f];
   const int tid = threadIdx.x, nt = blockDim.x;
   const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
@@ -1322,7 +1461,7 @@ __global__ void backsolve_kernel(DevSymbolic S, const int* ids, int big, const d
   for (int kb = nblk - 1; kb >= 0; --kb) {
     const int c0 = kb * TB, w = min(TB, F - c0);
     for (int c = 2 * wave; c < w; c += 2 * nw) {  // two columns per wave: independent loads and reductions
-      const double* col0 = A + (i64)(c0 + c) * n;
+      const double* col0 = Lp + (i64)(c0 + c) * n;
       const bool two = c + 1 < w;
       const double* col1 = two ? col0 + n : col0;
       double acc0 = 0, acc1 = 0;
@@ -1352,7 +1491,7 @@ __global__ void backsolve_kernel(DevSymbolic S, const int* ids, int big, const d
         // x = (L^-1)' y:  x[c] = y[c] / L[c][c] + sum_{r > c} (L^-1)[r][c] y[r],  (L^-1)[r][c] = tile[c][r]
         yr = 0;
         if (lane < w) {
-          yr = y[lane] / tile[lane][lane];
+          yr = y[lane] * Lp[(c0 + lane) + (i64)(c0 + lane) * n];  // 1 / L_cc (diag_tile_factor)
           for (int r = lane + 1; r < w; ++r) yr += tile[lane][r] * y[r];
         }
       } else {
@@ -1420,20 +1559,39 @@ void launch_dense_partial(double* a, int n, int nf, DevStatus* status, hipStream
 #endif
     return;
   }
-  BigDesc h{0, n, nf, 0, -1};
+  // the L panel is produced next to the matrix and copied back under the diagonal tiles at the end
+  double* work = nullptr;
+  const i64 xoff = big_panel_offset(n);
+  hipMalloc(&work, (size_t)(xoff + (i64)n * nf) * sizeof(double));
+  hipMemcpyAsync(work, a, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, st);
+  double* const user = a;
+  a = work;
+  BigDesc h{0, xoff, n, nf, 0, -1};
   BigDesc* d = nullptr;
   hipMalloc(&d, sizeof(BigDesc));
   hipMemcpyAsync(d, &h, sizeof(BigDesc), hipMemcpyHostToDevice, st);
-  DevSymbolic S{};
   const int steps = (nf + T - 1) / T;
   launch_big_potrf0(d, 1, a, status, st);
   for (int kb = 0; kb < steps; ++kb) {
     const int c0 = kb * T, w = (nf - c0 < T) ? nf - c0 : T, base = c0 + w;
     const int nt = (n - base + T - 1) / T;
-    launch_big_step(S, d, 1, kb, nt, nt * (nt + 1) / 2, a, status, st);
+    launch_big_step(d, 1, kb, nt * (nt + 1) / 2, a, status, st);
   }
+  big_copy_panel_kernel<<<64, 256, 0, st>>>(d, a);
+  hipMemcpyAsync(user, work, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, st);
   hipStreamSynchronize(st);
+#ifdef GSX_STAMP
+  {
+    unsigned long long h[8];
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamp), sizeof(h));
+    printf("[stamp] big n=%d F=%d tiles=%d: factor %llu inv8 %llu doubling %llu writeback %llu | panel-before-lookahead %llu\n",
+           n, nf, steps, h[2], h[3], h[4], h[5], h[6]);
+    unsigned long long z[8] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z));
+  }
+#endif
   hipFree(d);
+  hipFree(work);
 }
 
 }  // namespace gsx

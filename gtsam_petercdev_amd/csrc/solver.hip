@@ -417,7 +417,8 @@ gsx_status upload_symbolic(gsx_context* c) {
     B.begin = (int)c->big_descs.size();
     for (int k = se; k < S.lvl_ptr[l + 1]; ++k) {
       const int f = S.sched[k];
-      c->big_descs.push_back(BigDesc{(i64)S.off[f], S.N[f], S.F[f], f, S.parent[f]});
+      c->big_descs.push_back(BigDesc{(i64)S.off[f], (i64)S.off[f] + big_panel_offset(S.N[f]), S.N[f], S.F[f], f,
+                                     S.parent[f]});
       B.steps = std::max(B.steps, (S.F[f] + kTile - 1) / kTile);
       B.max_s1 = std::max(B.max_s1, S.N[f] - S.F[f]);
       c->big_max_n = std::max(c->big_max_n, S.N[f]);
@@ -558,23 +559,9 @@ void dev_factorize(gsx_context* c, double lambda) {
       launch_big_potrf0(c->d_big.p + B.begin, B.count, c->d_arena.p, c->d_status.p, c->stream);
       if (prof) timer_end(c, PH_K_POTRF0);
       for (int kb = 0; kb < B.steps; ++kb) {
-        if (!prof) {
-          launch_big_step(c->DS, c->d_big.p + B.begin, B.count, kb, B.row_tiles[kb], B.pairs[kb], c->d_arena.p,
-                          c->d_status.p, c->stream);
-        } else {  // one HIP-event pair per kernel launch
-          if (B.row_tiles[kb] > 0) {
-            timer_begin(c, PH_K_TRSM);
-            launch_big_step(c->DS, c->d_big.p + B.begin, B.count, kb, B.row_tiles[kb], B.pairs[kb], c->d_arena.p,
-                            c->d_status.p, c->stream, 1);
-            timer_end(c, PH_K_TRSM);
-          }
-          if (B.pairs[kb] > 0) {
-            timer_begin(c, PH_K_SYRK);
-            launch_big_step(c->DS, c->d_big.p + B.begin, B.count, kb, B.row_tiles[kb], B.pairs[kb], c->d_arena.p,
-                            c->d_status.p, c->stream, 2);
-            timer_end(c, PH_K_SYRK);
-          }
-        }
+        if (prof) timer_begin(c, PH_K_SYRK);  // one HIP-event pair per kernel launch
+        launch_big_step(c->d_big.p + B.begin, B.count, kb, B.pairs[kb], c->d_arena.p, c->d_status.p, c->stream);
+        if (prof) timer_end(c, PH_K_SYRK);
       }
       if (c->profiling) timer_end(c, PH_FACTOR_BIG);
     }

@@ -227,7 +227,8 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     else if (S.N[f] > kSmallMaxN) S.cls[f] = 2;
     else if (childless && S.F[f] <= kLeafMaxF) S.cls[f] = 0;
     if (S.cls[f] == 2) S.n_big++; else S.n_small++;
-    const int64_t sz = lean ? (int64_t)S.N[f] * S.F[f] : (int64_t)S.N[f] * S.N[f];
+    int64_t sz = lean ? (int64_t)S.N[f] * S.F[f] : (int64_t)S.N[f] * S.N[f];
+    if (S.cls[f] == 2) sz = ((sz + 1) & ~int64_t(1)) + (int64_t)S.N[f] * S.F[f];  // + L-panel area (kernels.h)
     S.off[f + 1] = S.off[f] + ((sz + 1) & ~int64_t(1));  // 16-byte aligned fronts
   }
   S.arena_size = S.off[nfr];
