@@ -12,7 +12,7 @@ namespace gsx {
 // global-memory path.  n = frontal + separator + 1 (rhs) scalar rows.
 constexpr int kSmallMaxN = 140;     // 140^2 * 8 B = 156.8 KB <= 160 KB LDS
 constexpr int kTile = 32;           // tile edge of the blocked big-front path
-constexpr int kGatherChunk = 48;    // sources per gather segment (one wave)
+constexpr int kGatherChunk = 64;    // sources per gather segment: one wave, one source record per lane
 constexpr int kLeafMaxF = 16;      // leaf cliques with at most this many frontal scalars use the panel-only kernel
 constexpr int kLeafMaxPanel = 8192; // doubles of LDS (n x F) a lean leaf may use: 64 KB
 

@@ -97,12 +97,25 @@ void launch_big_step(const BigDesc* descs, int count, int kb, int max_pairs, dou
 void launch_front_leaf(const DevProblem& P, const DevSymbolic& S, const int* ids, int count, int max_panel, int threads,
                        const double* H, const double* damp, const double* scalars, double* arena, DevStatus* status,
                        hipStream_t st);
-// A gather source is either a block of a child's stored Schur complement (gs_ld = child ld, entry (i, j) at
-// gs_off + i + j ld) or, for a lean leaf child, the product form: gs_ld = ld | F << 24 and the block is
-// -W_b W_a' with W_b = rows gs_off.., W_a = rows gs_off2.. of the child's n x F L panel.
+// Deterministic extend-add into big parents (big_gather).
+// A source is either a block of a child's stored Schur complement (F = 0: entry (i, j) at off + i + j ld) or, for a
+// lean leaf child, the product form -W_b W_a' with W_b = rows off.., W_a = rows off + d2.. of the child's n x F L panel.
+struct GatherSrc {   // 16 bytes
+  i64 off;
+  int d2;            // product form: offset of the second row block relative to the first
+  int ldF;           // ld | F << 24
+};
+struct GatherSeg {   // 32 bytes: one wave's work — up to kGatherChunk consecutive sources of one destination block
+  i64 dst;           // arena offset of the destination block (top-left entry)
+  i64 src;           // first source record
+  int n, ld, dims;   // number of sources; destination ld; dB | dA << 8 | diag << 16
+  int slot;          // -1: add straight into dst; else scratch slot of a split task
+};
 struct GatherArgs {
-  const i64 *gt_dst, *gs_off, *gs_off2, *seg_begin, *seg_end;
-  const int *gt_ld, *gt_dims, *gs_ld, *seg_task, *seg_slot, *gm_task, *gm_slot, *gm_nslots;
+  const GatherSeg* segs;
+  const GatherSrc* srcs;
+  const i64* gt_dst;                       // per task (combine pass)
+  const int *gt_ld, *gt_dims, *gm_task, *gm_slot, *gm_nslots;
   double* scratch;  // slots x 256 doubles (a 16 x 16 accumulator tile in matrix-core register layout)
 };
 void launch_big_gather(const GatherArgs& G, int seg0, int nseg, int m0, int nm, double* arena, hipStream_t st);

@@ -892,16 +892,47 @@ void launch_front_leaf(const DevProblem& P, const DevSymbolic& S, const int* ids
 // (HessianFactor::updateHessian of the children's remaining factors,
 //  gtsam/linear/HessianFactor.cpp:349-373, turned into a gather.)
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ i64 readlane_i64(i64 v, int src_lane) {  // src_lane must be wave-uniform
+  int lo = (int)(v & 0xFFFFFFFFll), hi = (int)(v >> 32);
+  lo = __builtin_amdgcn_readlane(lo, src_lane);
+  hi = __builtin_amdgcn_readlane(hi, src_lane);
+  return ((i64)hi << 32) | (unsigned)lo;
+}
+
+// Operands of one group of kLG consecutive sources in product form (F <= 4).  The records sit one per lane (rec_*);
+// the group's bases are broadcast with v_readlane so that the 16 loads per lane go out back to back.
+constexpr int kLG = 4;  // sources per group
+struct LeanGroup {
+  double x[kLG], y[kLG];
+};
+__device__ __forceinline__ void lean_group_load(LeanGroup& g, const double* arena, i64 rec_off, int rec_d2, int rec_ldF,
+                                                int first, int cnt, int li, int lk, bool rowB, bool colA) {
+#pragma unroll
+  for (int i = 0; i < kLG; ++i) {
+    const int src = first + i;  // wave-uniform
+    const i64 off = readlane_i64(rec_off, src & 63);
+    const int d2 = __builtin_amdgcn_readlane(rec_d2, src & 63);
+    const int ldF = __builtin_amdgcn_readlane(rec_ldF, src & 63);
+    const double* pb = arena + off;
+    const unsigned o = (unsigned)li + (unsigned)lk * (unsigned)(ldF & 0xFFFFFF);
+    const bool in = i < cnt && lk < (ldF >> 24);
+    g.x[i] = (rowB && in) ? pb[o] : 0.0;
+    g.y[i] = (colA && in) ? pb[(i64)d2 + o] : 0.0;
+  }
+}
+__device__ __forceinline__ void lean_group_mfma(const LeanGroup& g, v4d& acc) {
+#pragma unroll
+  for (int i = 0; i < kLG; ++i) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-g.x[i], g.y[i], acc, 0, 0, 0);
+}
+
 __global__ void __launch_bounds__(256) big_gather_seg_kernel(GatherArgs G, int seg0, int nseg, double* arena) {
   const int lane = threadIdx.x & 63;
   const int sw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
   if (sw >= nseg) return;
-  const int sg = seg0 + sw;
-  const int t = G.seg_task[sg], slot = G.seg_slot[sg];
-  const int dims = G.gt_dims[t], dB = dims & 255, dA = (dims >> 8) & 255, diag = dims >> 16;
-  const int ld = G.gt_ld[t];
-  double* dst = arena + G.gt_dst[t];
-  const i64 s0 = G.seg_begin[sg], s1 = G.seg_end[sg];
+  const GatherSeg sg = G.segs[seg0 + sw];  // one 32-byte record through the scalar path
+  const int dB = sg.dims & 255, dA = (sg.dims >> 8) & 255, diag = sg.dims >> 16;
+  const int ld = sg.ld, slot = sg.slot, n = sg.n;
+  double* dst = arena + sg.dst;
   if (dB <= 16 && dA <= 16) {
     // The destination block is one 16 x 16 FP64 matrix-core tile (entry (lk + 4q, li) in acc[q]).  Stored
     // sources are added entry by entry; a lean leaf's source is the rank-F product -W_b W_a' of two row blocks of
@@ -913,52 +944,45 @@ __global__ void __launch_bounds__(256) big_gather_seg_kernel(GatherArgs G, int s
 #pragma unroll
     for (int q = 0; q < 4; ++q) act[q] = (lk + 4 * q < dB) && colA && !(diag && lk + 4 * q < li);
     v4d acc = {0.0, 0.0, 0.0, 0.0};
-    i64 s = s0;
-    while (s < s1) {
-      const int f0 = G.gs_ld[s];
-      // fast path: four lean sources with F <= 4 (BAL landmarks): eight loads in flight, then four MFMAs
-      if (s + 4 <= s1 && (f0 >> 24) > 0 && (f0 >> 24) <= 4) {
-        const int f1 = G.gs_ld[s + 1], f2 = G.gs_ld[s + 2], f3 = G.gs_ld[s + 3];
-        const int F1 = f1 >> 24, F2 = f2 >> 24, F3 = f3 >> 24;
-        if (F1 > 0 && F1 <= 4 && F2 > 0 && F2 <= 4 && F3 > 0 && F3 <= 4) {
-          const int F0 = f0 >> 24;
-          const i64 b0 = G.gs_off[s], b1 = G.gs_off[s + 1], b2 = G.gs_off[s + 2], b3 = G.gs_off[s + 3];
-          const i64 a0 = G.gs_off2[s], a1 = G.gs_off2[s + 1], a2 = G.gs_off2[s + 2], a3 = G.gs_off2[s + 3];
-          const i64 l0 = f0 & 0xFFFFFF, l1 = f1 & 0xFFFFFF, l2 = f2 & 0xFFFFFF, l3 = f3 & 0xFFFFFF;
-          double x0 = 0, x1 = 0, x2 = 0, x3 = 0, y0 = 0, y1 = 0, y2 = 0, y3 = 0;
-          if (rowB) {
-            if (lk < F0) x0 = arena[b0 + li + lk * l0];
-            if (lk < F1) x1 = arena[b1 + li + lk * l1];
-            if (lk < F2) x2 = arena[b2 + li + lk * l2];
-            if (lk < F3) x3 = arena[b3 + li + lk * l3];
-          }
-          if (colA) {
-            if (lk < F0) y0 = arena[a0 + li + lk * l0];
-            if (lk < F1) y1 = arena[a1 + li + lk * l1];
-            if (lk < F2) y2 = arena[a2 + li + lk * l2];
-            if (lk < F3) y3 = arena[a3 + li + lk * l3];
-          }
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-x0, y0, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1, y1, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-x2, y2, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-x3, y3, acc, 0, 0, 0);
-          s += 4;
-          continue;
-        }
+    // the destination entries are read now, while the sources are on their way
+    double dv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dv[q] = (slot < 0 && act[q]) ? dst[(lk + 4 * q) + (i64)li * ld] : 0.0;
+    // all (<= 64) source records of the segment with ONE coalesced load, lane l <- record l
+    GatherSrc rec{0, 0, 0};
+    if (lane < n) rec = G.srcs[sg.src + lane];
+    const bool fast_lane = (rec.ldF >> 24) > 0 && (rec.ldF >> 24) <= 4;
+    const unsigned long long fast = __ballot(fast_lane);
+    const unsigned long long valid = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
+    int s = 0;
+    // groups of kLG product-form sources (BAL landmarks): 2 kLG loads per lane back to back, then kLG matrix-core
+    // instructions.  (Most destination blocks have only a handful of sources: the kernel is bound by the chain of
+    // dependent memory round trips per wave times the number of waves in flight, so registers are kept low for
+    // occupancy rather than spent on deeper per-wave pipelining.)
+    while (s < n) {
+      const unsigned long long want = (valid >> s) & ((1ull << kLG) - 1ull);
+      if (((fast >> s) & want) == want) {
+        LeanGroup ga;
+        lean_group_load(ga, arena, rec.off, rec.d2, rec.ldF, s, n - s, li, lk, rowB, colA);
+        lean_group_mfma(ga, acc);
+        s += kLG;
+        continue;
       }
-      const i64 o = G.gs_off[s];
-      const i64 l = f0 & 0xFFFFFF;
-      const int Fc = f0 >> 24;
+      // generic source (stored Schur-complement block, or a product with F > 4)
+      const i64 o = readlane_i64(rec.off, s);
+      const int d2 = __builtin_amdgcn_readlane(rec.d2, s);
+      const int ldF = __builtin_amdgcn_readlane(rec.ldF, s);
+      const i64 l = ldF & 0xFFFFFF;
+      const int Fc = ldF >> 24;
       if (Fc == 0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           if (act[q]) acc[q] += arena[o + (lk + 4 * q) + li * l];
       } else {
-        const i64 o2 = G.gs_off2[s];
         for (int kk = 0; kk < Fc; kk += 4) {
           const int k = kk + lk;
           const double x = (k < Fc && rowB) ? arena[o + li + k * l] : 0.0;
-          const double y = (k < Fc && colA) ? arena[o2 + li + k * l] : 0.0;
+          const double y = (k < Fc && colA) ? arena[o + d2 + li + k * l] : 0.0;
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-x, y, acc, 0, 0, 0);
         }
       }
@@ -967,10 +991,11 @@ __global__ void __launch_bounds__(256) big_gather_seg_kernel(GatherArgs G, int s
     if (slot < 0) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        if (act[q]) dst[(lk + 4 * q) + (i64)li * ld] += acc[q];
+        if (act[q]) dst[(lk + 4 * q) + (i64)li * ld] = dv[q] + acc[q];
     } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) G.scratch[(i64)slot * 256 + q * 64 + lane] = acc[q];
+      for (int q = 0; q < 4; ++q)
+        if (act[q]) G.scratch[(i64)slot * 256 + q * 64 + lane] = acc[q];
     }
     return;
   }
@@ -981,8 +1006,9 @@ __global__ void __launch_bounds__(256) big_gather_seg_kernel(GatherArgs G, int s
     const int ia = ea % dB, ja = ea / dB, ib = ebb % dB, jb = ebb / dB;
     const bool act_a = (ea < ne) && !(diag && ia < ja), act_b = (ebb < ne) && !(diag && ib < jb);
     double acc_a = 0, acc_b = 0;
-    for (i64 s = s0; s < s1; ++s) {
-      const i64 o0 = G.gs_off[s], l0 = G.gs_ld[s];
+    for (int s = 0; s < n; ++s) {
+      const GatherSrc r = G.srcs[sg.src + s];
+      const i64 o0 = r.off, l0 = r.ldF & 0xFFFFFF;
       if (act_a) acc_a += arena[o0 + ia + ja * l0];
       if (act_b) acc_b += arena[o0 + ib + jb * l0];
     }
@@ -1290,6 +1316,7 @@ __device__ __forceinline__ void diag_tile_factor(const TileLane& L, double v[4],
 }
 
 // first diagonal tile of every big front of a level
+// (passing the descriptors of small levels by value as kernel arguments was measured: slower, not faster)
 __global__ void __launch_bounds__(NT) big_potrf0_kernel(const BigDesc* descs, double* arena, DevStatus* status) {
   extern __shared__ double dyn_lds[];
   TilePtr Ls = (TilePtr)dyn_lds, Xs = (TilePtr)(dyn_lds + T * (T + 1)), Tm = (TilePtr)(dyn_lds + 2 * T * (T + 1));

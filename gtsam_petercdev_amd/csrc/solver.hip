@@ -107,8 +107,10 @@ struct gsx_context {
   // schedule
   std::vector<std::vector<SmallLaunch>> small_launch;  // per level
   std::vector<std::vector<SmallLaunch>> leaf_launch;   // per level (panel-only leaf kernel)
-  DevBuf<i64> d_gt_dst, d_gs_off, d_gs_off2, d_seg_begin, d_seg_end;  // gather tasks / segments for big parents
-  DevBuf<int> d_gt_ld, d_gt_dims, d_gs_ld, d_seg_task, d_seg_slot, d_gm_task, d_gm_slot, d_gm_nslots;
+  DevBuf<i64> d_gt_dst;  // gather tasks / segments for big parents
+  DevBuf<GatherSeg> d_gsegs;
+  DevBuf<GatherSrc> d_gsrcs;
+  DevBuf<int> d_gt_ld, d_gt_dims, d_gm_task, d_gm_slot, d_gm_nslots;
   DevBuf<double> d_gscratch;
   GatherArgs GA{};
   std::vector<BigLevel> big_level;
@@ -440,36 +442,35 @@ gsx_status upload_symbolic(gsx_context* c) {
   HIPCHK(c, c->d_big.upload(c->big_descs, st));
   {
     // gather sources as absolute arena offsets + leading dimension (no dependent metadata loads in the kernel)
-    std::vector<i64> gs_off(S.gs_child.size()), gs_off2(S.gs_child.size());
-    std::vector<int> gs_ld(S.gs_child.size());
+    std::vector<GatherSrc> srcs(S.gs_child.size());
     for (size_t i = 0; i < S.gs_child.size(); ++i) {
       const int ch = S.gs_child[i];
-      gs_off[i] = (i64)S.off[ch] + S.gs_loc[i];
-      gs_off2[i] = S.gs_loc2[i] >= 0 ? (i64)S.off[ch] + S.gs_loc2[i] : 0;
       if (S.N[ch] >= (1 << 24)) {
         c->err = "front with more than 2^24 rows";
         return GSX_E_INVALID;
       }
-      gs_ld[i] = S.N[ch] | (S.gs_loc2[i] >= 0 ? S.F[ch] << 24 : 0);
+      const bool lean = S.gs_loc2[i] >= 0;
+      srcs[i] = GatherSrc{(i64)S.off[ch] + S.gs_loc[i], lean ? S.gs_loc2[i] - S.gs_loc[i] : 0,
+                          S.N[ch] | (lean ? S.F[ch] << 24 : 0)};
+    }
+    std::vector<GatherSeg> segs(S.gseg_task.size());
+    for (size_t i = 0; i < segs.size(); ++i) {
+      const int t = S.gseg_task[i];
+      segs[i] = GatherSeg{(i64)S.gt_dst[t], (i64)S.gseg_begin[i], (int)(S.gseg_end[i] - S.gseg_begin[i]), S.gt_ld[t],
+                          S.gt_dims[t], S.gseg_slot[i]};
     }
     HIPCHK(c, c->d_gt_dst.upload(std::vector<i64>(S.gt_dst.begin(), S.gt_dst.end()), st));
     HIPCHK(c, c->d_gt_ld.upload(S.gt_ld, st));
     HIPCHK(c, c->d_gt_dims.upload(S.gt_dims, st));
-    HIPCHK(c, c->d_gs_off.upload(gs_off, st));
-    HIPCHK(c, c->d_gs_off2.upload(gs_off2, st));
-    HIPCHK(c, c->d_gs_ld.upload(gs_ld, st));
-    HIPCHK(c, c->d_seg_begin.upload(std::vector<i64>(S.gseg_begin.begin(), S.gseg_begin.end()), st));
-    HIPCHK(c, c->d_seg_end.upload(std::vector<i64>(S.gseg_end.begin(), S.gseg_end.end()), st));
-    HIPCHK(c, c->d_seg_task.upload(S.gseg_task, st));
-    HIPCHK(c, c->d_seg_slot.upload(S.gseg_slot, st));
+    HIPCHK(c, c->d_gsrcs.upload(srcs, st));
+    HIPCHK(c, c->d_gsegs.upload(segs, st));
     HIPCHK(c, c->d_gm_task.upload(S.gm_task, st));
     HIPCHK(c, c->d_gm_slot.upload(S.gm_slot, st));
     HIPCHK(c, c->d_gm_nslots.upload(S.gm_nslots, st));
     HIPCHK(c, c->d_gscratch.alloc((size_t)std::max(S.g_max_slots, 1) * 256));
     HIPCHK(c, hipStreamSynchronize(st));
-    c->GA = GatherArgs{c->d_gt_dst.p, c->d_gs_off.p, c->d_gs_off2.p, c->d_seg_begin.p, c->d_seg_end.p, c->d_gt_ld.p, c->d_gt_dims.p,
-                       c->d_gs_ld.p, c->d_seg_task.p, c->d_seg_slot.p, c->d_gm_task.p, c->d_gm_slot.p,
-                       c->d_gm_nslots.p, c->d_gscratch.p};
+    c->GA = GatherArgs{c->d_gsegs.p, c->d_gsrcs.p, c->d_gt_dst.p, c->d_gt_ld.p, c->d_gt_dims.p, c->d_gm_task.p,
+                       c->d_gm_slot.p, c->d_gm_nslots.p, c->d_gscratch.p};
   }
   DevSymbolic& D = c->DS;
   D.n_fronts = S.n_fronts;

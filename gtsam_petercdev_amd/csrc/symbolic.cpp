@@ -493,25 +493,27 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     int t = 0;
     for (int l = 0; l < S.n_levels; ++l) {
       int slots = 0;
+      // (shorter chunks for the levels with few sources were measured: slower — more waves, more scratch)
+      const int chunk = kGatherChunk;
       for (; t < S.gt_lvl_ptr[l + 1]; ++t) {
         const int64_t b = S.gt_ptr[t], e = S.gt_ptr[t + 1];
         const int dB = S.gt_dims[t] & 255, dA = (S.gt_dims[t] >> 8) & 255;
         const int64_t len = e - b;
-        const bool split = len > kGatherChunk && dB <= 16 && dA <= 16;
+        const bool split = len > chunk && dB <= 16 && dA <= 16;
         if (!split) {
           S.gseg_task.push_back(t);
           S.gseg_begin.push_back(b);
           S.gseg_end.push_back(e);
           S.gseg_slot.push_back(-1);
         } else {
-          const int nseg = (int)((len + kGatherChunk - 1) / kGatherChunk);
+          const int nseg = (int)((len + chunk - 1) / chunk);
           S.gm_task.push_back(t);
           S.gm_slot.push_back(slots);
           S.gm_nslots.push_back(nseg);
           for (int k = 0; k < nseg; ++k) {
             S.gseg_task.push_back(t);
-            S.gseg_begin.push_back(b + (int64_t)k * kGatherChunk);
-            S.gseg_end.push_back(std::min<int64_t>(e, b + (int64_t)(k + 1) * kGatherChunk));
+            S.gseg_begin.push_back(b + (int64_t)k * chunk);
+            S.gseg_end.push_back(std::min<int64_t>(e, b + (int64_t)(k + 1) * chunk));
             S.gseg_slot.push_back(slots + k);
           }
           slots += nseg;
