@@ -121,6 +121,9 @@ struct GatherArgs {
 void launch_big_gather(const GatherArgs& G, int seg0, int nseg, int m0, int nm, double* arena, hipStream_t st);
 void launch_backsolve(const DevSymbolic& S, const int* ids, int count, int threads, int max_n, bool big,
                       const double* arena, double* delta, DevStatus* status, hipStream_t st);
+// leaf cliques of a level, a wave per clique
+void launch_backsolve_leaf(const DevSymbolic& S, const int* ids, int count, const double* arena, double* delta,
+                           DevStatus* status, hipStream_t st);
 void launch_set_scalar(double* scalars, int slot, double v, hipStream_t st);
 // dense unit kernel for gsx_cholesky_partial: in-place lower partial Cholesky of an n x n
 // column-major matrix (lower triangle significant)

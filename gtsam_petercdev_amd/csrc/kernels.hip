@@ -1079,6 +1079,11 @@ void launch_big_init(const DevProblem& P, const DevSymbolic& S, const BigDesc* d
   big_add_h_kernel<<<dim3(max_nfv, count), 128, 0, st>>>(P, S, descs, H, damp, scalars, arena);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL access
+// (s_waitcnt vmcnt(0)) — which would put the latency of in-flight prefetches and of
+// just-issued stores on the critical path of the latency-bound kernels below.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- big-front kernels: 256 threads = 4 waves, one per SIMD; every thread owns 4 entries of a 32 x 32 tile in
 // the FP64 matrix-core accumulator layout of its wave's 16 x 16 quadrant:
 //   wave wv: row half qr = wv & 1, column half qc = wv >> 1;  lane: li = lane & 15, lk = lane >> 4
@@ -1141,14 +1146,14 @@ __device__ __forceinline__ void inverse_doubling_level(TilePtr Ls, TilePtr Xs, T
     for (int k = 0; k < B; ++k) acc += Ls[s0 + B + i][s0 + k] * Xs[s0 + k][s0 + jx];
     Tm[s0 + B + i][s0 + jx] = acc;
   }
-  __syncthreads();
+  lds_barrier();
   if (e < total) {
     double acc = 0;
 #pragma unroll
     for (int k = 0; k < B; ++k) acc += Xs[s0 + B + i][s0 + B + k] * Tm[s0 + B + k][s0 + jx];
     Xs[s0 + B + i][s0 + jx] = -acc;
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 __device__ __forceinline__ void diag_tile_factor(const TileLane& L, double v[4], double* A, double* Xp, int n, int F,
@@ -1171,7 +1176,7 @@ __device__ __forceinline__ void diag_tile_factor(const TileLane& L, double v[4],
   const bool row_owner = L.cq0 == 0 && L.lk == 0;  // one lane per tile row (waves 0 and 1)
   int fail = 0;
   for (int j = 0, stage = 0; j < w; j += KP, ++stage) {
-    __syncthreads();
+    lds_barrier();
     const double(*cur)[T] = colb[stage & 1];
     double(*nxt)[T] = colb[(stage + 1) & 1];
     // The pivot block is eliminated in root-free (L D L') form: u = unnormalised entries, d_k the pivots,
@@ -1283,7 +1288,7 @@ __device__ __forceinline__ void diag_tile_factor(const TileLane& L, double v[4],
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
   STAMP_ADD(2)
   STAMP_ADD(3)
   inverse_doubling_level<4>(Ls, Xs, Tm);
@@ -1389,7 +1394,7 @@ __global__ void __launch_bounds__(NT) big_panel_kernel(const BigDesc* descs, int
       if (i != j) Rj[rr][cc] = (rr < hj && cc < w) ? A[(rj + rr) + (i64)(c0 + cc) * n] : 0.0;
     }
   }
-  __syncthreads();
+  lds_barrier();
   {
     // X[r][c] = sum_{k <= c} R[r][k] Linv[c][k]: columns of the first half only need k < 16
     const bool half = L.cq0 == 0;  // wave-uniform
@@ -1406,7 +1411,7 @@ __global__ void __launch_bounds__(NT) big_panel_kernel(const BigDesc* descs, int
     }
   }
   const TilePtr Xjj = (i != j) ? Xj : Xi;
-  __syncthreads();
+  lds_barrier();
   double v[4];
   {
     const v4d acc = tile_product<T>(L, Xjj, Xi);  // acc[q] = sum_k Xj[c_q][k] Xi[r][k]
@@ -1422,7 +1427,7 @@ __global__ void __launch_bounds__(NT) big_panel_kernel(const BigDesc* descs, int
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       if (!(live[q] && L.r < wn && L.c[q] < wn)) v[q] = 0.0;
-    __syncthreads();  // every wave is done reading the panel tiles: Ri / Rj / Li become the factorization's scratch
+    lds_barrier();  // every wave is done reading the panel tiles: Ri / Rj / Li become the factorization's scratch
     STAMP_ADD(6)
     diag_tile_factor(L, v, A, X, n, F, base, wn, Ri, Rj, Li, status, d.front);
   }
@@ -1539,6 +1544,68 @@ __global__ void backsolve_kernel(DevSymbolic S, const int* ids, int big, const d
     __syncthreads();
   }
 }
+// (A thread-per-column, right-looking variant for big fronts — separator part first, panel rows prefetched into
+//  registers two panels ahead — was built and measured: 36-65 us per level against 25-39 us for the kernel above.)
+// Leaf cliques (F <= kLeafMaxF: BAL landmarks, pose-graph leaves): one WAVE per clique, four per workgroup, no
+// barriers.  The separator part of the solution is gathered once per lane (rows lane, lane + 64, ...), each frontal
+// column is a wave-wide dot product, and the F x F triangle is solved by substitution on the reduced values.
+__global__ void __launch_bounds__(256) backsolve_leaf_kernel(DevSymbolic S, const int* ids, int count, const double* arena,
+                                                             double* delta, DevStatus* status) {
+  const int lane = threadIdx.x & 63;
+  const int k = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (k >= count) return;
+  const int f = ids[k];
+  const int n = S.fr_N[f], F = S.fr_F[f];
+  const double* A = arena + S.fr_off[f];
+  const int* gi = S.gidx + S.gidx_ptr[f];
+  // y_c = d_c - sum_{r >= F} L[r][c] x_r, c < F
+  double yc[kLeafMaxF];
+#pragma unroll
+  for (int cidx = 0; cidx < kLeafMaxF; ++cidx) yc[cidx] = 0.0;
+  for (int r = F + lane; r < n - 1; r += 64) {
+    const double x = delta[gi[r]];
+#pragma unroll
+    for (int cidx = 0; cidx < kLeafMaxF; ++cidx)
+      if (cidx < F) yc[cidx] += A[r + (i64)cidx * n] * x;
+  }
+#pragma unroll
+  for (int cidx = 0; cidx < kLeafMaxF; ++cidx) {
+    if (cidx < F) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) yc[cidx] += __shfl_xor(yc[cidx], o, 64);
+      yc[cidx] = A[(n - 1) + (i64)cidx * n] - yc[cidx];
+    }
+  }
+  // L11' x = y, backwards (every lane computes the same values; lane 0 stores)
+  double xv[kLeafMaxF];
+#pragma unroll
+  for (int cidx = kLeafMaxF - 1; cidx >= 0; --cidx) {
+    xv[cidx] = 0.0;
+    if (cidx < F) {
+      double acc = yc[cidx];
+#pragma unroll
+      for (int r = cidx + 1; r < kLeafMaxF; ++r)
+        if (r < F) acc -= A[r + (i64)cidx * n] * xv[r];
+      xv[cidx] = acc / A[cidx + (i64)cidx * n];
+    }
+  }
+  if (lane == 0) {
+    int bad = 0;
+#pragma unroll
+    for (int cidx = 0; cidx < kLeafMaxF; ++cidx)
+      if (cidx < F) {
+        delta[gi[cidx]] = xv[cidx];
+        if (!isfinite(xv[cidx])) bad = 1;
+      }
+    if (bad) atomicAdd(&status->n_nonfinite, 1);
+  }
+}
+
+void launch_backsolve_leaf(const DevSymbolic& S, const int* ids, int count, const double* arena, double* delta,
+                           DevStatus* status, hipStream_t st) {
+  if (count) backsolve_leaf_kernel<<<(count + 3) / 4, 256, 0, st>>>(S, ids, count, arena, delta, status);
+}
+
 void launch_backsolve(const DevSymbolic& S, const int* ids, int count, int threads, int max_n, bool big,
                       const double* arena, double* delta, DevStatus* status, hipStream_t st) {
   static bool attr = false;

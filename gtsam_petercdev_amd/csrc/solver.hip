@@ -587,9 +587,10 @@ void dev_backsolve(gsx_context* c) {
     for (const SmallLaunch& sl : c->small_launch[l])
       launch_backsolve(c->DS, c->d_sched.p + sl.begin, sl.count, sl.max_n <= 48 ? 64 : 256, sl.max_n, false, c->d_arena.p,
                        c->d_delta.p, c->d_status.p, c->stream);
-    for (const SmallLaunch& sl : c->leaf_launch[l])
-      launch_backsolve(c->DS, c->d_sched.p + sl.begin, sl.count, sl.max_n <= 72 ? 64 : 256, sl.max_n, false, c->d_arena.p,
-                       c->d_delta.p, c->d_status.p, c->stream);
+    // all leaf-kernel cliques of the level in one launch (a wave each)
+    if (S.lvl_leaf_end[l] > S.lvl_ptr[l])
+      launch_backsolve_leaf(c->DS, c->d_sched.p + S.lvl_ptr[l], S.lvl_leaf_end[l] - S.lvl_ptr[l], c->d_arena.p,
+                            c->d_delta.p, c->d_status.p, c->stream);
   }
   timer_end(c, PH_BACKSOLVE);
 }
