@@ -55,43 +55,64 @@ def make_problem(name, seed):
     return datasets.synth_manhattan_pose2(100000, seed=seed), "nd"
 
 
-def front_split(be, arrays, small_max_n=140, leaf_max_f=16, tile=32):
-    """Algorithmic bytes / flops of the factorization split by kernel class."""
+def front_split(be, arrays, small_max_n=140, leaf_max_f=16, tile=32, leaf_max_panel=8192):
+    """Algorithmic bytes / flops of the factorization split by kernel class (the class rules mirror
+    csrc/symbolic.cpp).  A materialised front moves 8 n^2 bytes; a LEAN leaf (childless, f <= 16, big parent) is the
+    "fused landmark elimination" of §8(d): its Schur complement never exists, so it moves its H panel in and its L
+    panel out (16 n f bytes) and the parent's gather reads that L panel once more."""
     parent, fronts = be.get_tree()
     dims = arrays.var_dims
-    has_child = np.zeros(len(fronts), bool)
+    nfr = len(fronts)
+    has_child = np.zeros(nfr, bool)
     for p in parent:
         if p >= 0:
             has_child[p] = True
-    out = dict(lpanel_bytes=0.0, big_syrk_flops=0.0, big_trsm_flops=0.0, big_potrf_flops=0.0, gather_bytes=0.0)
+    F = np.array([float(dims[fv].sum()) for fv, _ in fronts])
+    S1 = np.array([float(dims[sv].sum()) + 1.0 for _, sv in fronts])
+    N = F + S1
+    sep_ok = np.array([bool(np.all(dims[sv] <= 16)) if len(sv) else True for _, sv in fronts])
+    out = dict(lpanel_bytes=0.0, big_syrk_flops=0.0, big_trsm_flops=0.0, big_potrf_flops=0.0, gather_bytes=0.0,
+               n_lean=0)
     for k in ("leaf", "small", "big"):
         out.update({k + "_bytes": 0.0, k + "_flops": 0.0, "n_" + k: 0})
-    N = np.zeros(len(fronts))
-    for i, (fv, sv) in enumerate(fronts):
-        f = float(dims[fv].sum())
-        s1 = float(dims[sv].sum()) + 1.0
-        n = f + s1
-        N[i] = n
+    lean = np.zeros(nfr, bool)
+    for i in range(nfr):
+        f, s1, n = F[i], S1[i], N[i]
+        p = parent[i]
+        lean[i] = (not has_child[i] and 0 < f <= leaf_max_f and p >= 0 and N[p] > small_max_n and n * f <= leaf_max_panel
+                   and sep_ok[i])
         fl = f ** 3 / 3 + f * f * s1 + f * s1 * s1
-        k = "big" if n > small_max_n else ("leaf" if (not has_child[i] and f <= leaf_max_f) else "small")
-        out[k + "_bytes"] += 8.0 * n * n
+        k = "leaf" if lean[i] else ("big" if n > small_max_n else ("leaf" if (not has_child[i] and f <= leaf_max_f) else "small"))
+        out[k + "_bytes"] += 16.0 * n * f if lean[i] else 8.0 * n * n
         out[k + "_flops"] += fl
         out["n_" + k] += 1
+        out["n_lean"] += int(lean[i])
         out["lpanel_bytes"] += 8.0 * f * n
         if k == "big":  # blocked path, 32-column panels: flops of each kernel class
             c0 = 0.0
             while c0 < f:
                 w = min(tile, f - c0)
                 m = n - (c0 + w)
-                out["big_potrf_flops"] += w ** 3 / 3 + w ** 3       # tile Cholesky + explicit tile inverse
+                out["big_potrf_flops"] += w ** 3 / 3 + w ** 3       # tile factorization + explicit tile inverse
                 out["big_trsm_flops"] += w * w * m                    # X <- X L^-T (triangular tile product)
-                out["big_syrk_flops"] += w * m * (m + 1)              # C -= P P' on the lower tile pairs
+                out["big_syrk_flops"] += w * m * (m + 1)              # C -= X X' on the lower tile pairs
                 c0 += w
+            out["gather_bytes"] += 2 * 8.0 * n * (n + 1) / 2          # destination lower triangle read + written once
     for i, p in enumerate(parent):
-        if p >= 0 and N[p] > small_max_n:  # Schur complement read by the gather + destination read/modify/write
-            s1 = float(dims[fronts[i][1]].sum()) + 1.0
-            out["gather_bytes"] += 8.0 * s1 * (s1 + 1) / 2 * 3
+        if p >= 0 and N[p] > small_max_n:  # what the big parent's gather reads of this child, once
+            out["gather_bytes"] += 8.0 * N[i] * F[i] if lean[i] else 8.0 * S1[i] * (S1[i] + 1) / 2
     return out
+
+
+def pmc_traffic(kernel, workload):
+    """HBM bytes per launch (FETCH_SIZE + WRITE_SIZE) of `kernel` from the committed rocprofv3 --pmc passes of this
+    same command (hardware counters cannot be read from inside the process; tools/pmc_summary.py made the file)."""
+    path = os.path.join(ROOT, "profiles", f"r01_{workload}_pmc_traffic.json")
+    try:
+        k = json.load(open(path))["kernels"][kernel.split("(")[0]]
+        return k["fetch_bytes"] + k["write_bytes"], os.path.relpath(path, ROOT)
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 def main():
@@ -180,8 +201,10 @@ def main():
     else:
         achieved = per_launch / (dk["avg_launch_ms"] * 1e-3) / 1e12 if dk["avg_launch_ms"] > 0 else 0.0
         peak, unit = FP64_PEAK_TFLOPS, "TFLOP/s"
+    traffic, traffic_src = pmc_traffic(dom, args.workload)
     roofline = dict(kernel=dom, bound=dk["bound"], achieved=achieved, peak=peak, unit=unit, frac=achieved / peak,
-                    traffic=None, launches_per_factorization=dk["launches_per_factorization"],
+                    traffic=traffic, traffic_source=traffic_src,
+                    launches_per_factorization=dk["launches_per_factorization"],
                     avg_launch_ms=dk["avg_launch_ms"], algorithmic_per_launch=per_launch)
     tot_leaf = per_kernel["front_leaf_kernel"]["ms_per_factorization"]
     tot_small = per_kernel["front_small_kernel"]["ms_per_factorization"]
