@@ -547,15 +547,24 @@ void dev_factorize(gsx_context* c, double lambda) {
                          c->d_scalars.p, c->d_arena.p, c->d_status.p, c->stream);
       if (c->profiling) timer_end(c, PH_FACTOR_SMALL);
     }
+    if (l == 0 && S.gseg_lvl_ptr[1] > S.gseg_lvl_ptr[0]) {
+      // gather group 0: the product-form contributions of all lean leaves to all big fronts (symbolic.cpp)
+      if (c->profiling) timer_begin(c, PH_K_GATHER);
+      launch_big_gather(c->GA, S.gseg_lvl_ptr[0], S.gseg_lvl_ptr[1] - S.gseg_lvl_ptr[0], S.gm_lvl_ptr[0],
+                        S.gm_lvl_ptr[1] - S.gm_lvl_ptr[0], c->d_arena.p, c->stream);
+      if (c->profiling) timer_end(c, PH_K_GATHER);
+    }
     const BigLevel& B = c->big_level[l];
     if (B.count) {
       if (c->profiling) timer_begin(c, PH_FACTOR_BIG);
       // children of every earlier level are complete: deterministic extend-add into this level's big fronts
       const bool prof = c->profiling != 0;
-      if (prof) timer_begin(c, PH_K_GATHER);
-      launch_big_gather(c->GA, S.gseg_lvl_ptr[l], S.gseg_lvl_ptr[l + 1] - S.gseg_lvl_ptr[l], S.gm_lvl_ptr[l],
-                        S.gm_lvl_ptr[l + 1] - S.gm_lvl_ptr[l], c->d_arena.p, c->stream);
-      if (prof) timer_end(c, PH_K_GATHER);
+      if (l > 0) {  // (group 0 was launched above)
+        if (prof) timer_begin(c, PH_K_GATHER);
+        launch_big_gather(c->GA, S.gseg_lvl_ptr[l], S.gseg_lvl_ptr[l + 1] - S.gseg_lvl_ptr[l], S.gm_lvl_ptr[l],
+                          S.gm_lvl_ptr[l + 1] - S.gm_lvl_ptr[l], c->d_arena.p, c->stream);
+        if (prof) timer_end(c, PH_K_GATHER);
+      }
       if (prof) timer_begin(c, PH_K_POTRF0);
       launch_big_potrf0(c->d_big.p + B.begin, B.count, c->d_arena.p, c->d_status.p, c->stream);
       if (prof) timer_end(c, PH_K_POTRF0);

@@ -451,6 +451,10 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
             c.dims = dim[b] | (dim[a] << 8) | ((a == b) ? (1 << 16) : 0);
             c.child = ch;
             if (S.lean[ch]) {
+              // product-form sources depend on the leaf kernel only: all of them, for every parent level, go into
+              // gather group 0, launched once right after the leaves (throughput-bound), which leaves the
+              // per-level gathers on the latency-bound chain with the few stored complements of big children
+              c.level = 0;
               c.loc = Fc + coff[b];
               c.loc2 = Fc + coff[a];
             } else {
