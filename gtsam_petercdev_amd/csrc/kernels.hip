@@ -37,6 +37,13 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 // total in thread 0 of the block (fixed summation order => deterministic)
+// e = q d + r for a SMALL quotient (q < 1024, e < 2^23): an integer division by a run-time divisor costs ~40
+// instructions on gfx950, and these index splits sit in the inner loops of issue-bound kernels.  rd = 1.0f / d.
+__device__ __forceinline__ void divmod_small(int e, int d, float rd, int& q, int& r) {
+  q = (int)(((float)e + 0.5f) * rd);
+  r = e - q * d;
+}
+
 __device__ __forceinline__ double block_sum(double v) {
   __shared__ double ws[16];
   v = wave_sum(v);
@@ -467,19 +474,18 @@ __global__ void assemble_h_kernel(DevProblem P, DevSymbolic S, const int* vars, 
     const double* Ja = jac + ta.jac;
     const double* Jb = jac + tb.jac;
     const int nea = ta.dB * dA, neb = has_b ? tb.dB * dA : 0;
+    const float rda = 1.0f / (float)ta.dB, rdb = 1.0f / (float)tb.dB;
     for (int e = lane; e < max(nea, neb); e += 64) {
       double acc_a = 0, acc_b = 0;
       int ia = 0, ja = 0, ib = 0, jb = 0;
       if (e < nea) {
-        ia = e % ta.dB;
-        ja = e / ta.dB;
+        divmod_small(e, ta.dB, rda, ja, ia);
         const double* a = Ja + (ta.colB + ia) * ta.m;
         const double* b = Ja + (ta.colA + ja) * ta.m;
         for (int r = 0; r < ta.m; ++r) acc_a += a[r] * b[r];
       }
       if (e < neb) {
-        ib = e % tb.dB;
-        jb = e / tb.dB;
+        divmod_small(e, tb.dB, rdb, jb, ib);
         const double* a = Jb + (tb.colB + ib) * tb.m;
         const double* b = Jb + (tb.colA + jb) * tb.m;
         for (int r = 0; r < tb.m; ++r) acc_b += a[r] * b[r];
@@ -509,8 +515,10 @@ __global__ void assemble_h_global_kernel(DevProblem P, DevSymbolic S, const int*
     const TermRec tr = S.terms[t];
     const double* Jf = jac + tr.jac;
     const int m = tr.m, colA = tr.colA, colB = tr.colB, dB = tr.dB, dst = tr.dst;
+    const float rdB = 1.0f / (float)dB;
     for (int e = lane; e < dB * dA; e += 64) {
-      const int i = e % dB, j = e / dB;
+      int i, j;
+      divmod_small(e, dB, rdB, j, i);
       double acc = 0;
       for (int r = 0; r < m; ++r) acc += Jf[(colB + i) * m + r] * Jf[(colA + j) * m + r];
       panel[dst + i + j * rows] += acc;  // an entry is always owned by the same lane
@@ -728,8 +736,10 @@ __global__ void front_small_kernel(DevProblem P, DevSymbolic S, const int* ids, 
     const VarRec vr = S.var_recs[fv[k]];
     const double* hp = H + vr.h_off;
     const int* hm = S.hmap + vr.hmap_off;
+    const float rrows = 1.0f / (float)vr.rows;
     for (int e = lane; e < vr.rows * vr.dA; e += 64) {
-      const int r = e % vr.rows, j = e / vr.rows;
+      int r, j;
+      divmod_small(e, vr.rows, rrows, j, r);
       double x = hp[e];
       if (r == j) x += lambda * damp[vr.toff + j];  // rows 0..dA-1 of the panel are the variable itself
       L[hm[r] + (vr.loc + j) * n] = x;
@@ -801,8 +811,10 @@ __global__ void front_leaf_kernel(DevProblem P, DevSymbolic S, const int* ids, c
     const double* hp = H + S.h_off[v];
     const int* hm = S.hmap + S.hmap_ptr[v];
     const int toff = P.var_tan_off[v];
+    const float rrows = 1.0f / (float)rows;
     for (int e = tid; e < rows * dA; e += nt) {
-      const int r = e % rows, j = e / rows;
+      int r, j;
+      divmod_small(e, rows, rrows, j, r);
       double x = hp[e];
       if (r == j) x += lambda * damp[toff + j];
       Pn[hm[r] + (c0 + j) * n] = x;
@@ -1062,8 +1074,10 @@ __global__ void big_add_h_kernel(DevProblem P, DevSymbolic S, const BigDesc* des
   const int toff = P.var_tan_off[v];
   const double lambda = scalars[SC_LAMBDA];
   double* A = arena + d.off;
+  const float rrows = 1.0f / (float)rows;
   for (int e = threadIdx.x; e < rows * dA; e += blockDim.x) {
-    const int r = e % rows, j = e / rows;
+    int r, j;
+    divmod_small(e, rows, rrows, j, r);
     double x = hp[e];
     if (r == j) x += lambda * damp[toff + j];
     A[hm[r] + (i64)(c0 + j) * n] = x;
