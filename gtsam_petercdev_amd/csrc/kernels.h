@@ -119,8 +119,8 @@ struct GatherArgs {
   double* scratch;  // slots x 256 doubles (a 16 x 16 accumulator tile in matrix-core register layout)
 };
 void launch_big_gather(const GatherArgs& G, int seg0, int nseg, int m0, int nm, double* arena, hipStream_t st);
-void launch_backsolve(const DevSymbolic& S, const int* ids, int count, int threads, int max_n, bool big,
-                      const double* arena, double* delta, DevStatus* status, hipStream_t st);
+void launch_backsolve(const DevSymbolic& S, const int* ids, int count, int threads, int max_n, const double* arena,
+                      double* delta, DevStatus* status, hipStream_t st);
 // leaf cliques of a level, a wave per clique
 void launch_backsolve_leaf(const DevSymbolic& S, const int* ids, int count, const double* arena, double* delta,
                            DevStatus* status, hipStream_t st);

@@ -1484,14 +1484,14 @@ void launch_big_step(const BigDesc* descs, int count, int kb, int max_pairs, dou
 //   L11' x_F = d - L21' x_S, blocked by 32 columns from the last panel to the first.
 // ---------------------------------------------------------------------------------------------
 constexpr int TB = 32;  // panel width of the back-substitution (independent of the factorization tile)
-__global__ void backsolve_kernel(DevSymbolic S, const int* ids, int big, const double* arena, double* delta,
-                                 DevStatus* status) {
+__global__ void backsolve_kernel(DevSymbolic S, const int* ids, const double* arena, double* delta, DevStatus* status) {
   extern __shared__ double xs[];  // n-1 solution entries of this front (frontal + separator)
   __shared__ double tile[TB][TB + 1];
   __shared__ double y[TB];
   const int f = ids[blockIdx.x];
   const int n = S.fr_N[f], F = S.fr_F[f];
   const double* A = arena + S.fr_off[f];
+  const bool big = n > kSmallMaxN;  // (leaf-kernel cliques, which may be larger, never come here)
   // big fronts keep the rows of L below each diagonal tile in their L-panel area right after the n x n front
   const double* Lp = big ? A + big_panel_offset(n) : A;
   const int* gi = S.gidx + S.gidx_ptr[f];
@@ -1620,15 +1620,15 @@ void launch_backsolve_leaf(const DevSymbolic& S, const int* ids, int count, cons
   if (count) backsolve_leaf_kernel<<<(count + 3) / 4, 256, 0, st>>>(S, ids, count, arena, delta, status);
 }
 
-void launch_backsolve(const DevSymbolic& S, const int* ids, int count, int threads, int max_n, bool big,
-                      const double* arena, double* delta, DevStatus* status, hipStream_t st) {
+void launch_backsolve(const DevSymbolic& S, const int* ids, int count, int threads, int max_n, const double* arena,
+                      double* delta, DevStatus* status, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
     hipFuncSetAttribute((const void*)backsolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     attr = true;
   }
   if (count)
-    backsolve_kernel<<<count, threads, (size_t)max_n * sizeof(double), st>>>(S, ids, big ? 1 : 0, arena, delta, status);
+    backsolve_kernel<<<count, threads, (size_t)max_n * sizeof(double), st>>>(S, ids, arena, delta, status);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -414,6 +414,17 @@ gsx_status upload_symbolic(gsx_context* c) {
         k = e;
       }
       G.swap(merged);
+      // ... and when the whole level has at most 256 small fronts (one workgroup per CU even at the full LDS size) a
+      // single launch: the level then costs the latency of its slowest front once, not once per size group
+      int total = 0, maxn = 0;
+      for (const SmallLaunch& g : G) {
+        total += g.count;
+        maxn = std::max(maxn, g.max_n);
+      }
+      if (G.size() > 1 && total <= 256) {
+        const SmallLaunch one{G[0].begin, total, maxn, std::max(256, small_threads_for(maxn))};
+        G.assign(1, one);
+      }
     }
     BigLevel& B = c->big_level[l];
     B.begin = (int)c->big_descs.size();
@@ -585,17 +596,28 @@ void dev_backsolve(gsx_context* c) {
   for (int l = S.n_levels - 1; l >= 0; --l) {
     const BigLevel& B = c->big_level[l];
     const int se = S.lvl_small_end[l];
-    if (B.count) {
+    const int le = S.lvl_leaf_end[l], n_rest = S.lvl_ptr[l + 1] - le;
+    if (n_rest > 0 && n_rest <= 512 && (B.count == 0 || n_rest > B.count)) {
+      // few fronts: small and big ones of the level in ONE launch (the level costs one kernel latency, not 2-4)
       int maxn = 0;
-      for (int k = se; k < S.lvl_ptr[l + 1]; ++k) maxn = std::max(maxn, S.N[S.sched[k]]);
+      for (int k = le; k < S.lvl_ptr[l + 1]; ++k) maxn = std::max(maxn, S.N[S.sched[k]]);
       if (c->profiling) timer_begin(c, PH_K_BACKSOLVE);
-      launch_backsolve(c->DS, c->d_sched.p + se, S.lvl_ptr[l + 1] - se, 1024, maxn, true, c->d_arena.p, c->d_delta.p,
-                       c->d_status.p, c->stream);
-      if (c->profiling) timer_end(c, PH_K_BACKSOLVE);
-    }
-    for (const SmallLaunch& sl : c->small_launch[l])
-      launch_backsolve(c->DS, c->d_sched.p + sl.begin, sl.count, sl.max_n <= 48 ? 64 : 256, sl.max_n, false, c->d_arena.p,
+      launch_backsolve(c->DS, c->d_sched.p + le, n_rest, B.count ? 1024 : (maxn <= 48 ? 64 : 256), maxn, c->d_arena.p,
                        c->d_delta.p, c->d_status.p, c->stream);
+      if (c->profiling) timer_end(c, PH_K_BACKSOLVE);
+    } else {
+      if (B.count) {
+        int maxn = 0;
+        for (int k = se; k < S.lvl_ptr[l + 1]; ++k) maxn = std::max(maxn, S.N[S.sched[k]]);
+        if (c->profiling) timer_begin(c, PH_K_BACKSOLVE);
+        launch_backsolve(c->DS, c->d_sched.p + se, S.lvl_ptr[l + 1] - se, 1024, maxn, c->d_arena.p, c->d_delta.p,
+                         c->d_status.p, c->stream);
+        if (c->profiling) timer_end(c, PH_K_BACKSOLVE);
+      }
+      for (const SmallLaunch& sl : c->small_launch[l])
+        launch_backsolve(c->DS, c->d_sched.p + sl.begin, sl.count, sl.max_n <= 48 ? 64 : 256, sl.max_n, c->d_arena.p,
+                         c->d_delta.p, c->d_status.p, c->stream);
+    }
     // all leaf-kernel cliques of the level in one launch (a wave each)
     if (S.lvl_leaf_end[l] > S.lvl_ptr[l])
       launch_backsolve_leaf(c->DS, c->d_sched.p + S.lvl_ptr[l], S.lvl_leaf_end[l] - S.lvl_ptr[l], c->d_arena.p,
