@@ -39,9 +39,16 @@ def parse():
     ap.add_argument("--workload", default="bal1723", choices=["bal1723", "bal49", "pose3_100k", "pose2_100k"])
     ap.add_argument("--ordering", default=None, choices=[None, "schur", "schur_nd", "mindegree", "nd"])
     ap.add_argument("--lam", type=float, default=1e-5)
+    ap.add_argument("--amalgamation", default=None, metavar="RELAX,MAXF",
+                    help="relaxed clique amalgamation (gsx_set_amalgamation); default: tuned per workload, 0 = the "
+                         "reference's cliques")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
     return ap.parse_args()
+
+
+# relaxed amalgamation per workload (relax, max merged frontal dim), from tools/sweep_amalgamation.sh on MI355X
+AMALGAMATION = {"bal1723": (0.25, 128), "bal49": (0.25, 128), "pose3_100k": (0.5, 64), "pose2_100k": (1.0, 64)}
 
 
 def make_problem(name, seed):
@@ -134,6 +141,11 @@ def main():
     t0 = time.time()
     ordering = be.compute_ordering(okind)
     t_order = time.time() - t0
+    relax, relax_maxf = AMALGAMATION[args.workload]
+    if args.amalgamation is not None:
+        a, b = args.amalgamation.split(",")
+        relax, relax_maxf = float(a), int(b)
+    be.set_amalgamation(relax, relax_maxf)
     t0 = time.time()
     be.set_ordering(ordering)
     t_symbolic = time.time() - t0
@@ -215,7 +227,7 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": args.workload, "shape": arrays.meta, "ordering": args.ordering or default_order,
-                   "lambda": lam, "replicas": world},
+                   "amalgamation": {"relax": relax, "max_frontal_dim": relax_maxf}, "lambda": lam, "replicas": world},
         "ms_per_linear_solve": ms_solve,
         "phases_ms": phases,
         "factor_leaf_ms": tot_leaf, "factor_small_ms": tot_small, "factor_big_ms": tot_big,

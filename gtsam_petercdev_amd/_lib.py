@@ -41,6 +41,11 @@ class ProductBackend(A.Backend):
         (orderings, symbolic analysis, get_tree, stats) are usable — for tests without a GPU."""
         super().__init__(load(), "gsx_", arrays, device, set_initial=not host_only)
 
+    def set_amalgamation(self, relax: float, max_frontal_dim: int = 128):
+        """Relaxed clique amalgamation for the next set_ordering (include/gsx.h); 0 = the reference's Bayes tree."""
+        self._check(self._fn("set_amalgamation")(self._h, C.c_double(relax), C.c_int32(max_frontal_dim)),
+                    "set_amalgamation")
+
     def stats(self) -> dict:
         s = A.Stats()
         self._check(self._fn("get_stats")(self._h, C.byref(s)), "get_stats")

@@ -30,6 +30,8 @@ struct HostProblem {
 
 // Symbolic factorization for one ordering.
 struct Symbolic {
+  double relax = 0.0;                // relaxed amalgamation threshold (0 = the reference's cliques)
+  int relax_max_f = 128;             // ... and the largest merged frontal dimension
   int n_fronts = 0;
   std::vector<int> order;            // position -> var
   std::vector<int> pos;              // var -> position
@@ -87,6 +89,7 @@ struct Symbolic {
 // host algorithms
 gsx_status lower_problem(const gsx_problem_desc* d, HostProblem& P, std::string& err);
 void compute_ordering(const HostProblem& P, int kind, std::vector<int>& order);
-gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order, Symbolic& S, std::string& err);
+gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order, double relax, int relax_max_f,
+                             Symbolic& S, std::string& err);
 
 }  // namespace gsx

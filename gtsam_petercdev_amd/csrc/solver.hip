@@ -85,6 +85,8 @@ struct gsx_context {
   HostProblem P;
   Symbolic S;
   bool has_symbolic = false;
+  double relax = 0.0;      // relaxed amalgamation (gsx_set_amalgamation); 0 = the reference's cliques
+  int relax_max_f = 128;
   std::vector<int> order;
 
   // device problem
@@ -869,7 +871,7 @@ gsx_status gsx_set_ordering(gsx_handle h, const uint64_t* keys, int32_t n) {
     }
     ord[i] = it->second;
   }
-  gsx_status st = symbolic_analysis(h->P, ord, h->S, h->err);
+  gsx_status st = symbolic_analysis(h->P, ord, h->relax, h->relax_max_f, h->S, h->err);
   if (st != GSX_OK) return st;
   h->order = ord;
   h->has_symbolic = true;
@@ -886,6 +888,13 @@ gsx_status gsx_compute_ordering(gsx_handle h, int32_t kind, uint64_t* keys_out) 
   std::vector<int> ord;
   compute_ordering(h->P, kind, ord);
   for (int i = 0; i < h->P.n_vars; ++i) keys_out[i] = h->P.keys[ord[i]];
+  return GSX_OK;
+}
+
+gsx_status gsx_set_amalgamation(gsx_handle h, double relax, int32_t max_frontal_dim) {
+  if (!h || !(relax >= 0.0) || max_frontal_dim < 1) return GSX_E_INVALID;
+  h->relax = relax;
+  h->relax_max_f = max_frontal_dim;
   return GSX_OK;
 }
 

@@ -16,13 +16,16 @@
 
 namespace gsx {
 
-gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order, Symbolic& S, std::string& err) {
+gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order, double relax, int relax_max_f,
+                             Symbolic& S, std::string& err) {
   const int n = P.n_vars, m = P.n_factors;
   if ((int)order.size() != n) {
     err = "ordering size differs from the number of variables";
     return GSX_E_BAD_ORDERING;
   }
   S = Symbolic();
+  S.relax = relax;
+  S.relax_max_f = relax_max_f;
   S.order = order;
   S.pos.assign(n, -1);
   for (int j = 0; j < n; ++j) {
@@ -111,17 +114,39 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
   // merged[j] = true when node j was merged into its etree parent's cluster.
   std::vector<char> merged(n, 0);
   std::vector<int> nfront_of(n, 1);  // frontal variable count of the cluster topped by node j
+  // relaxed amalgamation (S.relax > 0; off = the reference's Bayes tree exactly): a child cluster is also merged
+  // when the explicit zeros this adds to its columns are at most S.relax x its own L panel and the merged
+  // frontal dimension stays moderate.  Fewer, larger cliques => fewer levels / kernel launches on the
+  // latency-bound chains; the solution is unchanged (zeros are factored as zeros).
+  std::vector<int64_t> fdim_of(n, 0), sdim_of(n, 0);  // scalar frontal / separator dims of the cluster topped by j
+  std::vector<int> ref_nfront_of(n, 1);
   for (int j = 0; j < n; ++j) {
     const size_t myNrParents = st[j].size();
-    size_t myNrFrontals = 1;
+    size_t myNrFrontals = 1;     // all frontal variables gathered so far
+    size_t refNrFrontals = 1;    // ... counting only the reference's merges (its rule is evaluated on its own count,
+                                 //     so that every reference clique survives whole inside a relaxed one)
+    int64_t sp = 0;
+    for (int pj : st[j]) sp += P.dims[order[pj]];
+    int64_t fp = P.dims[order[j]];
     for (int c = ech_ptr[j]; c < ech_ptr[j + 1]; ++c) {
       const int ch = ech[c];
-      if (myNrParents + myNrFrontals == st[ch].size()) {
+      bool take = myNrParents + refNrFrontals == st[ch].size();
+      if (take) refNrFrontals += ref_nfront_of[ch];
+      if (!take && S.relax > 0) {
+        const int64_t fc = fdim_of[ch], sc = sdim_of[ch];
+        const int64_t extra = fc * (fp + sp - sc);
+        take = (double)extra <= S.relax * (double)(fc * (fc + sc + 1)) && fc + fp <= S.relax_max_f;
+      }
+      if (take) {
         myNrFrontals += nfront_of[ch];
+        fp += fdim_of[ch];
         merged[ch] = 1;
       }
     }
     nfront_of[j] = (int)myNrFrontals;
+    ref_nfront_of[j] = (int)refNrFrontals;
+    fdim_of[j] = fp;
+    sdim_of[j] = sp;
   }
   // top node of the cluster containing each node
   std::vector<int> top(n);

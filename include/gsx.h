@@ -215,6 +215,13 @@ int32_t gsx_device_count(void);                    /* 0 when no GPU is visible  
 /* ---- ordering / symbolic analysis (host only; works without a GPU) -------- */
 gsx_status gsx_set_ordering(gsx_handle h, const uint64_t* keys, int32_t n);
 gsx_status gsx_compute_ordering(gsx_handle h, int32_t kind, uint64_t* keys_out);
+/* Relaxed clique amalgamation, applied by the NEXT gsx_set_ordering.  relax = 0 (the default) builds exactly the
+ * reference's Bayes tree: a child cluster is merged into its parent only when that adds no structural zero
+ * (gtsam/inference/JunctionTree-inst.h:120-149).  relax > 0 also merges a child when the explicit zeros padded
+ * into its columns are at most relax x its own conditional's size and the merged frontal dimension stays
+ * <= max_frontal_dim: fewer, larger cliques, i.e. fewer levels and kernel launches on the latency-bound chains of
+ * the elimination tree.  The solution is unchanged (zeros are factored as zeros); only gsx_get_tree differs. */
+gsx_status gsx_set_amalgamation(gsx_handle h, double relax, int32_t max_frontal_dim);
 gsx_status gsx_get_ordering(gsx_handle h, uint64_t* keys_out);
 /* Bayes-tree structure for parity checks: per front the frontal / separator
  * variable indices (CSR) and the parent front (-1 = root).  Pass NULL arrays to

@@ -67,6 +67,45 @@ def test_full_size_step_matches_oracle(gpu, oracle, name):
     assert abs(st["factor_flops"] - tree["flops"]) <= 1e-9 * tree["flops"]
 
 
+BENCH_CONFIGS = {
+    # the configurations bench.py measures: ordering + relaxed amalgamation (bench.py AMALGAMATION)
+    "bal1723": (CASES["bal1723"][0], A.ORDER_SCHUR_ND, 0.25, 128),
+    "pose3_100k": (CASES["pose3_100k"][0], A.ORDER_ND, 0.5, 64),
+    "pose2_100k": (lambda: datasets.synth_manhattan_pose2(100000, seed=42), A.ORDER_ND, 1.0, 64),
+}
+
+
+@pytest.mark.parametrize("name", list(BENCH_CONFIGS))
+def test_bench_configuration_matches_oracle(gpu, oracle, name):
+    """The exact configuration bench.py times — own ordering AND relaxed clique amalgamation — against the oracle,
+    which eliminates the reference's (un-amalgamated) Bayes tree for the same ordering."""
+    build, kind, relax, maxf = BENCH_CONFIGS[name]
+    arr = build()
+    gb = gpu.product_backend(arr)
+    ob = oracle.oracle_backend(arr)
+    ordering = gb.compute_ordering(kind)
+    gb.set_amalgamation(relax, maxf)
+    gb.set_ordering(ordering)
+    ob.set_ordering(ordering)
+    gb.linearize()
+    ob.linearize()
+    for lam, diag in ((1e-5, False), (1e-2, True)):
+        dg = gb.solve(lam, diag)
+        do = ob.solve(lam, diag)
+        assert relerr(dg, do) < 1e-6, (name, lam)    # north star: updates within 1e-6 relative
+        e0g, edg = gb.linear_error()
+        e0o, edo = ob.linear_error()
+        assert abs(e0g - e0o) <= 1e-10 * abs(e0o)
+        assert abs(edg - edo) <= 1e-6 * max(abs(edo), 1e-9 * abs(e0o))
+    tg = gb.retract(None, commit=False)
+    to = ob.retract(None, commit=False)
+    assert abs(tg - to) <= 1e-6 * abs(to)
+    _, tree = ob.timing()
+    assert gb.stats()["n_fronts"] < tree["cliques"]  # amalgamation did happen
+    d2 = gb.solve(1e-2, True)
+    assert np.array_equal(dg, d2)                     # and the path stays bitwise reproducible
+
+
 @pytest.mark.parametrize("name", ["bal1723", "pose3_100k"])
 def test_full_size_properties(gpu, name):
     build, kind = CASES[name]

@@ -167,6 +167,34 @@ def test_step_parity(gpu, oracle, name):
     assert relerr(gb.get_values(), ob.get_values()) < 1e-10
 
 
+@pytest.mark.parametrize("name", list(PROBLEMS))
+@pytest.mark.parametrize("relax,maxf", [(0.25, 128), (1.0, 64), (50.0, 4096)])
+def test_step_parity_with_relaxed_amalgamation(gpu, oracle, name, relax, maxf):
+    """gsx_set_amalgamation: the product eliminates merged cliques (explicit zeros), the oracle the reference's tree;
+    the solution of the damped system must not move."""
+    arr = PROBLEMS[name]
+    gb = gpu.product_backend(arr)
+    ob = oracle.oracle_backend(arr)
+    gb.linearize()
+    ob.linearize()
+    kinds = (A.ORDER_MINDEGREE, A.ORDER_ND) + ((A.ORDER_SCHUR_ND,) if name.startswith("bal") else ())
+    for kind in kinds:
+        ordering = gb.compute_ordering(kind)
+        gb.set_amalgamation(relax, maxf)
+        gb.set_ordering(ordering)
+        ob.set_ordering(ordering)
+        gb.linearize()
+        for lam, diag in ((1e-3, False), (1.0, True)):
+            dg = gb.solve(lam, diag)
+            do = ob.solve(lam, diag)
+            assert relerr(dg, do) < 1e-8, (name, kind, lam, diag)
+            e0g, edg = gb.linear_error()
+            e0o, edo = ob.linear_error()
+            assert abs(e0g - e0o) <= 1e-10 * abs(e0o) and abs(edg - edo) <= 1e-8 * max(abs(edo), 1e-12 * abs(e0o))
+        _, tree = ob.timing()
+        assert gb.stats()["n_fronts"] <= tree["cliques"]
+
+
 @pytest.mark.parametrize("name", ["bal_small", "bal_bigfront", "pose2", "pose3"])
 @pytest.mark.parametrize("preset", ["legacy", "ceres"])
 def test_lm_trajectory_parity(gpu, oracle, name, preset):
@@ -208,6 +236,36 @@ def test_optimizeMultiFrontal2(gpu):
         actual = small_gaussian_factor_graph().optimize(ordering)
         for k, v in CORRECT_DELTA.items():
             assert np.allclose(actual[k], v, atol=1e-9)
+
+
+def test_GaussianBayesTree_chain(gpu):
+    """gtsam/linear/tests/testGaussianBayesTree.cpp:84-129 on the device: tree (x3 x4) <- (x2 x1 : x3), x = (0,1,0,1)."""
+    from tests.test_oracle_golden import chain_graph
+    actual = chain_graph().optimize([2, 1, 3, 4])
+    for k, v in {1: 0.0, 2: 1.0, 3: 0.0, 4: 1.0}.items():
+        assert np.allclose(actual[k], [v], atol=1e-9)
+    arrays = chain_graph().to_arrays(None)
+    arrays.values = np.zeros(4)
+    be = gpu.product_backend(arrays)
+    be.set_ordering([2, 1, 3, 4])
+    parent, fronts = be.get_tree()
+    keys = arrays.var_keys.tolist()
+    cl = {tuple(keys[i] for i in f): c for c, (f, s) in enumerate(fronts)}
+    assert set(cl) == {(3, 4), (2, 1)} and parent[cl[(2, 1)]] == cl[(3, 4)]
+
+
+def test_HessianFactor_hessianDiagonal(gpu):
+    """gtsam/linear/tests/testHessianFactor.cpp:447-477: diagonal of the expected 7x7 information matrix."""
+    from gtsam_petercdev_amd.graph import GaussianFactorGraph, JacobianFactor
+    fg = GaussianFactorGraph()
+    fg.add(JacobianFactor(0, 11.1803399 * np.eye(2), 1, -2.23606798 * np.eye(2), 2, -8.94427191 * np.eye(2),
+                          [2.23606798, -1.56524758], noiseModel.Diagonal.Sigmas([1.0, 1.0])))
+    arrays = fg.to_arrays(None)
+    arrays.values = np.zeros(6)
+    be = gpu.product_backend(arrays)
+    be.set_ordering([0, 1, 2])
+    be.linearize()
+    assert np.allclose(be.hessian_diagonal(), [125.0, 125.0, 5.0, 5.0, 80.0, 80.0], atol=1e-4)
 
 
 def test_solve_gfg_entry_point(gpu):

@@ -88,6 +88,48 @@ def test_bayes_tree_identical_to_reference_construction(lib, oracle, name):
         assert st["max_front_dim"] == tree["max_f"]
 
 
+@pytest.mark.parametrize("name", list(PROBLEMS))
+@pytest.mark.parametrize("relax,maxf", [(0.25, 128), (1.0, 64), (50.0, 4096)])
+def test_relaxed_amalgamation_is_a_coarsening_of_the_reference_tree(lib, name, relax, maxf):
+    """gsx_set_amalgamation(relax > 0): every clique is a union of CONNECTED reference cliques, its separator is the
+    separator of its topmost member, the parent relation is the quotient of the reference tree; relax = 0 restores
+    the reference tree exactly."""
+    arr = PROBLEMS[name]()
+    pb = _lib.ProductBackend(arr, host_only=True)
+    ordering = pb.compute_ordering(A.ORDER_ND)
+    pb.set_ordering(ordering)
+    ref_parent, ref_fronts = pb.get_tree()
+    ref_flops = pb.stats()["factor_flops"]
+    pb.set_amalgamation(relax, maxf)
+    pb.set_ordering(ordering)
+    parent, fronts = pb.get_tree()
+    assert len(fronts) <= len(ref_fronts) and pb.stats()["factor_flops"] >= ref_flops * (1 - 1e-12)
+    var_front = {}
+    for c, (f, s) in enumerate(fronts):
+        for v in f:
+            assert v not in var_front  # the frontal sets partition the variables
+            var_front[int(v)] = c
+    assert len(var_front) == arr.n_vars
+    members = {}
+    for rc, (rf, rs) in enumerate(ref_fronts):
+        owners = {var_front[int(v)] for v in rf}
+        assert len(owners) == 1  # a reference clique is never split
+        members.setdefault(owners.pop(), []).append(rc)
+    for c, rcs in members.items():
+        inside = set(rcs)
+        tops = [rc for rc in rcs if ref_parent[rc] not in inside]
+        assert len(tops) == 1  # connected: exactly one member whose reference parent lies outside
+        top = tops[0]
+        assert sorted(map(int, fronts[c][1])) == sorted(map(int, ref_fronts[top][1]))
+        rp = ref_parent[top]
+        assert parent[c] == (-1 if rp < 0 else var_front[int(ref_fronts[rp][0][0])])
+    pb.set_amalgamation(0.0, 128)
+    pb.set_ordering(ordering)
+    p0, f0 = pb.get_tree()
+    assert [sorted(map(int, f)) for f, _ in f0] == [sorted(map(int, f)) for f, _ in ref_fronts]
+    assert list(p0) == list(ref_parent)
+
+
 def test_ordering_errors(lib):
     arr = PROBLEMS["pose2"]()
     pb = _lib.ProductBackend(arr, host_only=True)

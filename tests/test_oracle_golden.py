@@ -99,6 +99,92 @@ def test_optimizeMultiFrontal2(orc, ordering):
         assert np.allclose(actual[k], v, atol=1e-9)
 
 
+# ---- gtsam/linear/tests/testGaussianBayesTree.cpp -----------------------------------------------------
+def chain_graph():
+    """:36-47 — x1 - x2 - x3 - x4 with a prior on x4, Isotropic sigma 0.5."""
+    noise = noiseModel.Isotropic.Sigma(1, 0.5)
+    one = np.eye(1)
+    fg = GaussianFactorGraph()
+    fg.add(JacobianFactor(2, one, 1, one, [1.0], noise))
+    fg.add(JacobianFactor(2, one, 3, one, [1.0], noise))
+    fg.add(JacobianFactor(3, one, 4, one, [1.0], noise))
+    fg.add(JacobianFactor(4, one, [1.0], noise))
+    return fg
+
+
+def _rows_equal_up_to_sign(a, b, tol=1e-9):
+    """GaussianConditional::equals accepts a conditional whose rows differ by a sign (QR vs Cholesky)."""
+    return all(np.allclose(x, y, atol=tol) or np.allclose(x, -y, atol=tol) for x, y in zip(a, b))
+
+
+def test_GaussianBayesTree_eliminate(orc):
+    """:84-117 — Bayes tree (x3 x4) <- (x2 x1 : x3) with the expected [R S d] of both cliques."""
+    arrays = chain_graph().to_arrays(None)
+    arrays.values = np.zeros(4)
+    be = orc.oracle_backend(arrays)
+    be.set_ordering([2, 1, 3, 4])
+    be.linearize()
+    be.solve(0.0)
+    parent, fronts = be.get_tree()
+    keys = arrays.var_keys.tolist()
+    cl = {tuple(keys[i] for i in f): c for c, (f, s) in enumerate(fronts)}
+    assert set(cl) == {(3, 4), (2, 1)}
+    assert parent[cl[(3, 4)]] == -1 and parent[cl[(2, 1)]] == cl[(3, 4)]
+    assert tuple(keys[i] for i in fronts[cl[(2, 1)]][1]) == (3,)
+    s2 = math.sqrt(2.0)
+    gc1 = np.array([[2.0, 2.0, 2.0], [0.0, 2.0, 2.0]])                      # [R(x3 x4) | d]
+    gc2 = np.array([[-2 * s2, -s2, -s2, -2 * s2], [0.0, -s2, s2, 0.0]])     # [R(x2 x1) | S(x3) | d]
+    assert _rows_equal_up_to_sign(be.conditional(cl[(3, 4)]), gc1)
+    assert _rows_equal_up_to_sign(be.conditional(cl[(2, 1)]), gc2)
+
+
+def test_GaussianBayesTree_optimizeMultiFrontal(orc):
+    """:120-129"""
+    actual = chain_graph().optimize([2, 1, 3, 4], backend_factory=orc.oracle_backend)
+    for k, v in {1: 0.0, 2: 1.0, 3: 0.0, 4: 1.0}.items():
+        assert np.allclose(actual[k], [v], atol=1e-9)
+
+
+# ---- gtsam/linear/tests/testHessianFactor.cpp -----------------------------------------------------------
+def test_HessianFactor_eliminate2(orc):
+    """:377-444 — EliminateCholesky of one combined factor on (x2 | l1 x1): expected R11, S12, d (1e-4)."""
+    sigmas = [0.2, 0.2, 0.1, 0.1]
+    Ax2 = np.array([[-1., 0.], [0., -1.], [1., 0.], [0., 1.]])
+    Al1x1 = np.array([[1., 0., 0., 0.], [0., 1., 0., 0.], [0., 0., -1., 0.], [0., 0., 0., -1.]])
+    b2 = [-0.2, 0.3, 0.2, -0.1]
+    fg = GaussianFactorGraph()
+    fg.add(JacobianFactor(0, Ax2, 1, Al1x1, b2, noiseModel.Diagonal.Sigmas(sigmas)))
+    # the test eliminates x2 only; a prior on (l1 x1) makes the full system solvable and does not touch the
+    # rows of the conditional on x2 (first two rows of the factor of the merged clique)
+    fg.add(JacobianFactor(1, np.eye(4), np.zeros(4)))
+    arrays = fg.to_arrays(None)
+    arrays.values = np.zeros(6)
+    be = orc.oracle_backend(arrays)
+    be.set_ordering([0, 1])
+    be.linearize()
+    be.solve(0.0)
+    parent, fronts = be.get_tree()
+    assert len(fronts) == 1  # {x2} merges into its parent (JunctionTree-inst.h:120-149)
+    cond = be.conditional(0)
+    old_sigma = 0.0894427
+    expected = np.array([[1.0, 0.0, -0.2, 0.0, -0.8, 0.0, 0.2], [0.0, 1.0, 0.0, -0.2, 0.0, -0.8, -0.14]]) / old_sigma
+    assert _rows_equal_up_to_sign(cond[:2], expected, tol=1e-4 / old_sigma * 0.1)
+
+
+def test_HessianFactor_combine_hessianDiagonal(orc):
+    """:447-477, :527-549 — information of a 3-key factor: diagonal of the expected 7x7 matrix."""
+    A0 = 11.1803399 * np.eye(2)
+    A1 = -2.23606798 * np.eye(2)
+    A2 = -8.94427191 * np.eye(2)
+    fg = GaussianFactorGraph()
+    fg.add(JacobianFactor(0, A0, 1, A1, 2, A2, [2.23606798, -1.56524758], noiseModel.Diagonal.Sigmas([1.0, 1.0])))
+    arrays = fg.to_arrays(None)
+    arrays.values = np.zeros(6)
+    be = orc.oracle_backend(arrays)
+    be.linearize()
+    assert np.allclose(be.hessian_diagonal(), [125.0, 125.0, 5.0, 5.0, 80.0, 80.0], atol=1e-4)
+
+
 def nonlinear_smoother(T):
     """tests/smallExample.h:434-462 with simulated2D Prior/Odometry == Prior/Between on Point2."""
     g, v = NonlinearFactorGraph(), Values()
