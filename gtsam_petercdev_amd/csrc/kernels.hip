@@ -37,6 +37,13 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 // total in thread 0 of the block (fixed summation order => deterministic)
+__device__ __forceinline__ i64 readlane_i64(i64 v, int src_lane) {  // src_lane must be wave-uniform
+  int lo = (int)(v & 0xFFFFFFFFll), hi = (int)(v >> 32);
+  lo = __builtin_amdgcn_readlane(lo, src_lane);
+  hi = __builtin_amdgcn_readlane(hi, src_lane);
+  return ((i64)hi << 32) | (unsigned)lo;
+}
+
 // e = q d + r for a SMALL quotient (q < 1024, e < 2^23): an integer division by a run-time divisor costs ~40
 // instructions on gfx950, and these index splits sit in the inner loops of issue-bound kernels.  rd = 1.0f / d.
 __device__ __forceinline__ void divmod_small(int e, int d, float rd, int& q, int& r) {
@@ -459,39 +466,78 @@ __global__ void assemble_h_kernel(DevProblem P, DevSymbolic S, const int* vars, 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
   double* panel = lds + (size_t)wave * psize;
   for (int e = lane; e < psize; e += 64) panel[e] = 0;
-  // Terms are 32-byte records fetched through the scalar path (wave-uniform index); two terms are in
-  // flight per iteration so that their Jacobian loads overlap (the loop is latency-, not issue-bound).
-  // Each wave takes a CONTIGUOUS chunk of the term list (the diagonal and rhs terms of one factor are
-  // neighbours and share the factor's Jacobian cache lines).
+  // Each wave takes a CONTIGUOUS chunk of the term list (the diagonal and rhs terms of one factor are neighbours and
+  // share the factor's Jacobian cache lines).  The loop is bound by DEPENDENT MEMORY ROUND TRIPS: the 32-byte
+  // records of up to 64 terms are fetched with one coalesced load (a record per lane) and broadcast with
+  // v_readlane, and the Jacobian loads of kTG terms — rows 0 and 1 of every term, i.e. everything for the 2-row
+  // SFM factors — are issued back to back before the first FMA.  (The compiler serialised the per-row loads of
+  // the earlier two-term scalar-record form: six round trips per pair of terms.)  Terms are accumulated into the
+  // panel in list order: deterministic.
+  constexpr int kTG = 4;
   const int uw = __builtin_amdgcn_readfirstlane(wave);
   const i64 tb0 = S.term_ptr[v], tn = S.term_ptr[v + 1] - tb0;
   const i64 chunk = ((tn + nw - 1) / nw + 1) & ~i64(1);
   const i64 t1 = min(tb0 + tn, tb0 + (uw + 1) * chunk);
-  for (i64 t = tb0 + uw * chunk; t < t1; t += 2) {
-    const TermRec ta = S.terms[t];
-    const bool has_b = t + 1 < t1;
-    const TermRec tb = S.terms[has_b ? t + 1 : t];
-    const double* Ja = jac + ta.jac;
-    const double* Jb = jac + tb.jac;
-    const int nea = ta.dB * dA, neb = has_b ? tb.dB * dA : 0;
-    const float rda = 1.0f / (float)ta.dB, rdb = 1.0f / (float)tb.dB;
-    for (int e = lane; e < max(nea, neb); e += 64) {
-      double acc_a = 0, acc_b = 0;
-      int ia = 0, ja = 0, ib = 0, jb = 0;
-      if (e < nea) {
-        divmod_small(e, ta.dB, rda, ja, ia);
-        const double* a = Ja + (ta.colB + ia) * ta.m;
-        const double* b = Ja + (ta.colA + ja) * ta.m;
-        for (int r = 0; r < ta.m; ++r) acc_a += a[r] * b[r];
+  for (i64 base = tb0 + uw * chunk; base < t1; base += 64) {
+    const int nblk = (int)min((i64)64, t1 - base);
+    TermRec rec{0, 0, 0, 0, 0, 0, 0};
+    if (lane < nblk) rec = S.terms[base + lane];
+    for (int g = 0; g < nblk; g += kTG) {
+      const double* tj[kTG];
+      int tm[kTG], tA[kTG], tB[kTG], tdB[kTG], tdst[kTG];
+      float trd[kTG];
+      int mmax = 0, nemax = 0;
+#pragma unroll
+      for (int i = 0; i < kTG; ++i) {
+        const int src = min(g + i, 63);  // wave-uniform
+        const bool in = g + i < nblk;
+        tj[i] = jac + readlane_i64(rec.jac, src);
+        tm[i] = in ? __builtin_amdgcn_readlane(rec.m, src) : 0;
+        tA[i] = __builtin_amdgcn_readlane(rec.colA, src);
+        tB[i] = __builtin_amdgcn_readlane(rec.colB, src);
+        tdB[i] = in ? __builtin_amdgcn_readlane(rec.dB, src) : 0;
+        tdst[i] = __builtin_amdgcn_readlane(rec.dst, src);
+        trd[i] = __builtin_amdgcn_rcpf((float)max(tdB[i], 1));
+        mmax = max(mmax, tm[i]);
+        nemax = max(nemax, tdB[i] * dA);
       }
-      if (e < neb) {
-        divmod_small(e, tb.dB, rdb, jb, ib);
-        const double* a = Jb + (tb.colB + ib) * tb.m;
-        const double* b = Jb + (tb.colA + jb) * tb.m;
-        for (int r = 0; r < tb.m; ++r) acc_b += a[r] * b[r];
+      for (int e = lane; e < nemax; e += 64) {
+        double acc[kTG], a0[kTG], b0[kTG], a1[kTG], b1[kTG];
+        const double *pa[kTG], *pb[kTG];
+        bool on[kTG];
+        int ii[kTG], jj[kTG];
+#pragma unroll
+        for (int i = 0; i < kTG; ++i) {
+          on[i] = e < tdB[i] * dA;
+          divmod_small(e, tdB[i], trd[i], jj[i], ii[i]);
+          pa[i] = tj[i] + (tB[i] + ii[i]) * tm[i];
+          pb[i] = tj[i] + (tA[i] + jj[i]) * tm[i];
+        }
+#pragma unroll
+        for (int i = 0; i < kTG; ++i) {
+          const bool r0 = on[i] && tm[i] > 0, r1 = on[i] && tm[i] > 1;
+          a0[i] = r0 ? pa[i][0] : 0.0;
+          b0[i] = r0 ? pb[i][0] : 0.0;
+          a1[i] = r1 ? pa[i][1] : 0.0;
+          b1[i] = r1 ? pb[i][1] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < kTG; ++i) acc[i] = a0[i] * b0[i] + a1[i] * b1[i];
+        for (int r = 2; r < mmax; ++r) {
+          double ar[kTG], br[kTG];
+#pragma unroll
+          for (int i = 0; i < kTG; ++i) {
+            const bool rr = on[i] && r < tm[i];
+            ar[i] = rr ? pa[i][r] : 0.0;
+            br[i] = rr ? pb[i][r] : 0.0;
+          }
+#pragma unroll
+          for (int i = 0; i < kTG; ++i) acc[i] += ar[i] * br[i];
+        }
+#pragma unroll
+        for (int i = 0; i < kTG; ++i)
+          if (on[i]) panel[tdst[i] + ii[i] + jj[i] * rows] += acc[i];
       }
-      if (e < nea) panel[ta.dst + ia + ja * rows] += acc_a;
-      if (e < neb) panel[tb.dst + ib + jb * rows] += acc_b;
     }
   }
   __syncthreads();
@@ -904,13 +950,6 @@ void launch_front_leaf(const DevProblem& P, const DevSymbolic& S, const int* ids
 // (HessianFactor::updateHessian of the children's remaining factors,
 //  gtsam/linear/HessianFactor.cpp:349-373, turned into a gather.)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ i64 readlane_i64(i64 v, int src_lane) {  // src_lane must be wave-uniform
-  int lo = (int)(v & 0xFFFFFFFFll), hi = (int)(v >> 32);
-  lo = __builtin_amdgcn_readlane(lo, src_lane);
-  hi = __builtin_amdgcn_readlane(hi, src_lane);
-  return ((i64)hi << 32) | (unsigned)lo;
-}
-
 // Operands of one group of kLG consecutive sources in product form (F <= 4).  The records sit one per lane (rec_*);
 // the group's bases are broadcast with v_readlane so that the 16 loads per lane go out back to back.
 constexpr int kLG = 4;  // sources per group
