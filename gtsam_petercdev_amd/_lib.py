@@ -3,6 +3,8 @@ library is missing or cannot be loaded every entry point raises."""
 from __future__ import annotations
 
 import ctypes as C
+
+import numpy as np
 import os
 
 from . import _abi as A
@@ -64,6 +66,58 @@ class ProductBackend(A.Backend):
         ms, n = C.c_double(), C.c_int64()
         self._check(self._fn("kernel_time")(self._h, name.encode(), C.byref(ms), C.byref(n)), "kernel_time")
         return ms.value, n.value
+
+
+def _dataset_to_arrays(ds, meta) -> A.ProblemArrays:
+    lib = load()
+    desc = A.ProblemDesc()
+    vals, nvals = C.POINTER(C.c_double)(), C.c_int64()
+    st = lib.gsx_dataset_get(ds, C.byref(desc), C.byref(vals), C.byref(nvals))
+    if st != A.GSX_OK:
+        lib.gsx_dataset_free(ds)
+        raise A.GsxError(st, "gsx_dataset_get", "")
+    nv, nf = desc.n_vars, desc.n_factors
+
+    def arr(ptr, n, dtype):
+        return np.ctypeslib.as_array(ptr, shape=(max(int(n), 1),))[:int(n)].astype(dtype, copy=True)
+    kp = arr(desc.f_key_ptr, nf + 1, np.int32)
+    mp = arr(desc.f_meas_ptr, nf + 1, np.int64)
+    npx = arr(desc.f_noise_ptr, nf + 1, np.int64)
+    out = A.ProblemArrays(
+        var_keys=arr(desc.var_keys, nv, np.uint64), var_types=arr(desc.var_types, nv, np.int32),
+        var_dims=arr(desc.var_dims, nv, np.int32), f_type=arr(desc.f_type, nf, np.int32),
+        f_rows=arr(desc.f_rows, nf, np.int32), f_key_ptr=kp, f_vars=arr(desc.f_vars, kp[-1], np.int32),
+        f_meas_ptr=mp, meas=arr(desc.meas, mp[-1], np.float64), f_noise_kind=arr(desc.f_noise_kind, nf, np.int32),
+        f_noise_ptr=npx, noise=arr(desc.noise, npx[-1], np.float64),
+        values=arr(vals, nvals.value, np.float64), meta=meta)
+    lib.gsx_dataset_free(ds)
+    return out
+
+
+def read_g2o(path: str, is3D: bool = False) -> A.ProblemArrays:
+    """Native g2o reader (gsx_read_g2o, include/gsx.h): graph + anchoring prior + initial values."""
+    lib = load()
+    lib.gsx_read_g2o.restype = C.c_int32
+    lib.gsx_dataset_get.restype = C.c_int32
+    lib.gsx_dataset_free.restype = None
+    ds = C.c_void_p()
+    st = lib.gsx_read_g2o(str(path).encode(), C.c_int32(1 if is3D else 0), C.byref(ds))
+    if st != A.GSX_OK:
+        raise A.GsxError(st, "gsx_read_g2o", str(path))
+    return _dataset_to_arrays(ds, dict(kind="pose3" if is3D else "pose2", source=str(path)))
+
+
+def read_bal(path: str, priors: bool = False) -> A.ProblemArrays:
+    """Native BAL reader (gsx_read_bal, include/gsx.h)."""
+    lib = load()
+    lib.gsx_read_bal.restype = C.c_int32
+    lib.gsx_dataset_get.restype = C.c_int32
+    lib.gsx_dataset_free.restype = None
+    ds = C.c_void_p()
+    st = lib.gsx_read_bal(str(path).encode(), C.c_int32(1 if priors else 0), C.byref(ds))
+    if st != A.GSX_OK:
+        raise A.GsxError(st, "gsx_read_bal", str(path))
+    return _dataset_to_arrays(ds, dict(kind="bal", source=str(path)))
 
 
 def product_backend(arrays: A.ProblemArrays, device: int = 0) -> ProductBackend:

@@ -1,0 +1,329 @@
+// io.cpp — native readers of the on-disk formats either side of the hot path: g2o pose graphs
+// and BAL bundle-adjustment files, lowered straight to a gsx_problem_desc + packed initial Values.  Host only.
+//
+// Behaviour follows the reference's parsers (paths relative to /root/reference/):
+//   g2o 2-D  gtsam/slam/dataset.cpp:216-296,505-633  VERTEX_SE2|VERTEX2 id x y theta;
+//            EDGE_SE2|EDGE2|EDGE|ODOMETRY i j x y theta I11 I12 I13 I22 I23 I33; a vertex that only appears in edges is
+//            created by chaining the odometry (:541-546)
+//   g2o 3-D  gtsam/slam/dataset.cpp:756-863           VERTEX_SE3:QUAT id x y z qx qy qz qw; EDGE_SE3:QUAT i j x y z
+//            qx qy qz qw + 21 upper-triangular information entries in (t, R) order, permuted to GTSAM's (R, t) (:850-856)
+//   noise    noiseModel::Gaussian::Information(I): R = LLT(I).matrixU() (gtsam/linear/NoiseModel.cpp:98-112)
+//   anchor   the prior the reference's examples add on the first pose, appended last
+//            (examples/Pose2SLAMExample_g2o.cpp:65-67, examples/Pose3SLAMExample_g2o.cpp:42-48)
+//   BAL      gtsam/sfm/SfmData.cpp:189-245 (file order, values read as `float`), openGL2gtsam :79-85, measurement (u, -v),
+//            tracks in file order; graph of examples/SFMExample_bal.cpp:55-68 (unit pixel noise, optional priors
+//            Isotropic(9, 0.1) on camera 0 and Isotropic(3, 0.1) on point 0 appended last); keys: cameras 0.., points
+//            Symbol('p', j)
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "gsx_internal.h"
+
+struct gsx_dataset {
+  std::vector<uint64_t> var_keys;
+  std::vector<int32_t> var_types, var_dims, f_type, f_rows, f_key_ptr, f_vars, f_noise_kind;
+  std::vector<int64_t> f_meas_ptr, f_noise_ptr;
+  std::vector<double> meas, noise, values;
+  std::string err;
+};
+
+namespace {
+
+void quat_to_R(double w, double x, double y, double z, double* R) {  // row-major, Eigen's normalised convention
+  const double n = std::sqrt(w * w + x * x + y * y + z * z);
+  w /= n; x /= n; y /= n; z /= n;
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w);     R[2] = 2 * (x * z + y * w);
+  R[3] = 2 * (x * y + z * w);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+  R[6] = 2 * (x * z - y * w);     R[7] = 2 * (y * z + x * w);     R[8] = 1 - 2 * (x * x + y * y);
+}
+
+// upper Cholesky factor R (row-major d x d, R'R = I) of a symmetric positive-definite information matrix
+bool chol_upper(const double* I, int d, double* R) {
+  std::vector<double> L(d * d, 0.0);  // lower, row-major
+  for (int j = 0; j < d; ++j) {
+    double s = I[j * d + j];
+    for (int k = 0; k < j; ++k) s -= L[j * d + k] * L[j * d + k];
+    if (!(s > 0)) return false;
+    const double ljj = std::sqrt(s);
+    L[j * d + j] = ljj;
+    for (int i = j + 1; i < d; ++i) {
+      double t = I[i * d + j];
+      for (int k = 0; k < j; ++k) t -= L[i * d + k] * L[j * d + k];
+      L[i * d + j] = t / ljj;
+    }
+  }
+  for (int r = 0; r < d; ++r)
+    for (int c = 0; c < d; ++c) R[r * d + c] = (c >= r) ? L[c * d + r] : 0.0;
+  return true;
+}
+
+void so3_expmap(const double* w, double* R) {  // gtsam/geometry/SO3.cpp:61-96, row-major
+  const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  double a, b;
+  if (th2 <= 2.220446049250313e-16) {
+    a = 1.0 - th2 / 6.0;
+    b = 0.5 - th2 / 24.0;
+  } else {
+    const double th = std::sqrt(th2), s2 = std::sin(th / 2.0);
+    a = std::sin(th) / th;
+    b = 2.0 * s2 * s2 / th2;
+  }
+  const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+  double WW[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) WW[i * 3 + j] = W[i * 3] * W[j] + W[i * 3 + 1] * W[3 + j] + W[i * 3 + 2] * W[6 + j];
+  for (int i = 0; i < 9; ++i) R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + a * W[i] + b * WW[i];
+}
+
+struct Edge {
+  long long i, j;
+  std::vector<double> z;  // measurement in packed state layout
+  std::vector<double> R;  // d x d upper factor
+};
+
+}  // namespace
+
+extern "C" {
+
+gsx_status gsx_read_g2o(const char* path, int32_t is3d, gsx_dataset** out) {
+  if (!path || !out) return GSX_E_INVALID;
+  std::ifstream in(path);
+  if (!in) return GSX_E_INVALID;
+  const int d = is3d ? 6 : 3, sd = is3d ? 12 : 3;
+  std::map<long long, std::vector<double>> states;
+  std::vector<Edge> edges;
+  std::string line;
+  while (std::getline(in, line)) {
+    std::istringstream ss(line);
+    std::string tag;
+    if (!(ss >> tag)) continue;
+    if (!is3d && (tag == "VERTEX_SE2" || tag == "VERTEX2")) {
+      long long id;
+      double x, y, th;
+      if (!(ss >> id >> x >> y >> th)) return GSX_E_INVALID;
+      states[id] = {x, y, th};
+    } else if (!is3d && (tag == "EDGE_SE2" || tag == "EDGE2" || tag == "EDGE" || tag == "ODOMETRY")) {
+      Edge e;
+      double x, y, th, v[6];
+      if (!(ss >> e.i >> e.j >> x >> y >> th)) return GSX_E_INVALID;
+      for (double& q : v)
+        if (!(ss >> q)) return GSX_E_INVALID;
+      e.z = {x, y, th};
+      const double I[9] = {v[0], v[1], v[2], v[1], v[3], v[4], v[2], v[4], v[5]};
+      e.R.resize(9);
+      if (!chol_upper(I, 3, e.R.data())) return GSX_E_INVALID;
+      edges.push_back(e);
+    } else if (is3d && tag == "VERTEX_SE3:QUAT") {
+      long long id;
+      double x, y, z, qx, qy, qz, qw;
+      if (!(ss >> id >> x >> y >> z >> qx >> qy >> qz >> qw)) return GSX_E_INVALID;
+      std::vector<double> s(12);
+      quat_to_R(qw, qx, qy, qz, s.data());
+      s[9] = x; s[10] = y; s[11] = z;
+      states[id] = s;
+    } else if (is3d && tag == "EDGE_SE3:QUAT") {
+      Edge e;
+      double x, y, z, qx, qy, qz, qw, up[21];
+      if (!(ss >> e.i >> e.j >> x >> y >> z >> qx >> qy >> qz >> qw)) return GSX_E_INVALID;
+      for (double& q : up)
+        if (!(ss >> q)) return GSX_E_INVALID;
+      e.z.resize(12);
+      quat_to_R(qw, qx, qy, qz, e.z.data());
+      e.z[9] = x; e.z[10] = y; e.z[11] = z;
+      double m[36], mg[36];
+      int k = 0;
+      for (int r = 0; r < 6; ++r)
+        for (int c = r; c < 6; ++c) m[r * 6 + c] = m[c * 6 + r] = up[k++];
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+          mg[r * 6 + c] = m[(3 + r) * 6 + (3 + c)];        // R block first
+          mg[(3 + r) * 6 + (3 + c)] = m[r * 6 + c];          // then t
+          mg[r * 6 + (3 + c)] = m[(3 + r) * 6 + c];
+          mg[(3 + r) * 6 + c] = m[r * 6 + (3 + c)];
+        }
+      e.R.resize(36);
+      if (!chol_upper(mg, 6, e.R.data())) return GSX_E_INVALID;
+      edges.push_back(e);
+    }
+  }
+  if (!is3d)
+    for (const Edge& e : edges) {  // chain the odometry for vertices without a VERTEX line
+      if (!states.count(e.i)) states[e.i] = {0.0, 0.0, 0.0};
+      if (!states.count(e.j)) {
+        const std::vector<double>& a = states[e.i];
+        const double c = std::cos(a[2]), s = std::sin(a[2]);
+        states[e.j] = {a[0] + c * e.z[0] - s * e.z[1], a[1] + s * e.z[0] + c * e.z[1], a[2] + e.z[2]};
+      }
+    }
+  if (states.empty()) return GSX_E_INVALID;
+  gsx_dataset* D = new gsx_dataset();
+  std::map<long long, int> index;
+  for (const auto& kv : states) {
+    index[kv.first] = (int)D->var_keys.size();
+    D->var_keys.push_back((uint64_t)kv.first);
+    D->var_types.push_back(is3d ? GSX_VAR_POSE3 : GSX_VAR_POSE2);
+    D->var_dims.push_back(d);
+    D->values.insert(D->values.end(), kv.second.begin(), kv.second.end());
+  }
+  D->f_key_ptr.push_back(0);
+  D->f_meas_ptr.push_back(0);
+  D->f_noise_ptr.push_back(0);
+  for (const Edge& e : edges) {
+    if (!index.count(e.i) || !index.count(e.j)) {
+      delete D;
+      return GSX_E_INVALID;
+    }
+    D->f_type.push_back(GSX_F_BETWEEN);
+    D->f_rows.push_back(d);
+    D->f_vars.push_back(index[e.i]);
+    D->f_vars.push_back(index[e.j]);
+    D->f_key_ptr.push_back((int32_t)D->f_vars.size());
+    D->meas.insert(D->meas.end(), e.z.begin(), e.z.end());
+    D->f_meas_ptr.push_back((int64_t)D->meas.size());
+    D->f_noise_kind.push_back(GSX_NOISE_GAUSSIAN);
+    D->noise.insert(D->noise.end(), e.R.begin(), e.R.end());
+    D->f_noise_ptr.push_back((int64_t)D->noise.size());
+  }
+  // anchoring prior on the first pose, as the reference's example programs add it
+  D->f_type.push_back(GSX_F_PRIOR);
+  D->f_rows.push_back(d);
+  D->f_vars.push_back(0);
+  D->f_key_ptr.push_back((int32_t)D->f_vars.size());
+  D->meas.insert(D->meas.end(), D->values.begin(), D->values.begin() + sd);
+  D->f_meas_ptr.push_back((int64_t)D->meas.size());
+  D->f_noise_kind.push_back(GSX_NOISE_DIAGONAL);
+  if (is3d)
+    for (int k = 0; k < 6; ++k) D->noise.push_back(std::sqrt(k < 3 ? 1e-6 : 1e-4));
+  else
+    for (double var : {1e-6, 1e-6, 1e-8}) D->noise.push_back(std::sqrt(var));
+  D->f_noise_ptr.push_back((int64_t)D->noise.size());
+  *out = D;
+  return GSX_OK;
+}
+
+gsx_status gsx_read_bal(const char* path, int32_t add_priors, gsx_dataset** out) {
+  if (!path || !out) return GSX_E_INVALID;
+  std::ifstream in(path);
+  if (!in) return GSX_E_INVALID;
+  long long nc, np, nobs;
+  if (!(in >> nc >> np >> nobs) || nc <= 0 || np <= 0 || nobs < 0) return GSX_E_INVALID;
+  std::vector<long long> ci(nobs), pj(nobs);
+  std::vector<double> u(nobs), v(nobs);
+  for (long long k = 0; k < nobs; ++k) {
+    double a, b;
+    if (!(in >> ci[k] >> pj[k] >> a >> b)) return GSX_E_INVALID;
+    if (ci[k] < 0 || ci[k] >= nc || pj[k] < 0 || pj[k] >= np) return GSX_E_INVALID;
+    u[k] = (double)(float)a;   // "float u, v;" in the reference's reader
+    v[k] = -(double)(float)b;  // BAL's image y axis points the other way
+  }
+  gsx_dataset* D = new gsx_dataset();
+  const uint64_t pbase = (uint64_t)'p' << 56;
+  for (long long i = 0; i < nc; ++i) {
+    double c[9];
+    for (double& q : c) {
+      double t;
+      if (!(in >> t)) {
+        delete D;
+        return GSX_E_INVALID;
+      }
+      q = (double)(float)t;
+    }
+    double R[9];
+    so3_expmap(c, R);
+    // openGL2gtsam: wRc = R' diag(1,-1,-1), t_w = -R' t
+    double s[17];
+    for (int r = 0; r < 3; ++r)
+      for (int k = 0; k < 3; ++k) s[r * 3 + k] = R[k * 3 + r] * (k == 0 ? 1.0 : -1.0);
+    for (int r = 0; r < 3; ++r) s[9 + r] = -(R[0 * 3 + r] * c[3] + R[1 * 3 + r] * c[4] + R[2 * 3 + r] * c[5]);
+    s[12] = c[6]; s[13] = c[7]; s[14] = c[8]; s[15] = 0.0; s[16] = 0.0;
+    D->var_keys.push_back((uint64_t)i);
+    D->var_types.push_back(GSX_VAR_CAMERA);
+    D->var_dims.push_back(9);
+    D->values.insert(D->values.end(), s, s + 17);
+  }
+  for (long long j = 0; j < np; ++j) {
+    double p[3];
+    for (double& q : p) {
+      double t;
+      if (!(in >> t)) {
+        delete D;
+        return GSX_E_INVALID;
+      }
+      q = (double)(float)t;
+    }
+    D->var_keys.push_back(pbase + (uint64_t)j);
+    D->var_types.push_back(GSX_VAR_VECTOR);
+    D->var_dims.push_back(3);
+    D->values.insert(D->values.end(), p, p + 3);
+  }
+  // factors in track order: observations stably sorted by point (tracks[j].measurements in file order)
+  std::vector<long long> order(nobs);
+  for (long long k = 0; k < nobs; ++k) order[k] = k;
+  std::stable_sort(order.begin(), order.end(), [&](long long a, long long b) { return pj[a] < pj[b]; });
+  D->f_key_ptr.push_back(0);
+  D->f_meas_ptr.push_back(0);
+  D->f_noise_ptr.push_back(0);
+  for (long long k : order) {
+    D->f_type.push_back(GSX_F_SFM);
+    D->f_rows.push_back(2);
+    D->f_vars.push_back((int32_t)ci[k]);
+    D->f_vars.push_back((int32_t)(nc + pj[k]));
+    D->f_key_ptr.push_back((int32_t)D->f_vars.size());
+    D->meas.push_back(u[k]);
+    D->meas.push_back(v[k]);
+    D->f_meas_ptr.push_back((int64_t)D->meas.size());
+    D->f_noise_kind.push_back(GSX_NOISE_UNIT);
+    D->f_noise_ptr.push_back((int64_t)D->noise.size());
+  }
+  if (add_priors) {
+    for (int which = 0; which < 2; ++which) {
+      const int var = which == 0 ? 0 : (int)nc, dim = which == 0 ? 9 : 3, sdim = which == 0 ? 17 : 3;
+      const size_t off = which == 0 ? 0 : (size_t)nc * 17;
+      D->f_type.push_back(GSX_F_PRIOR);
+      D->f_rows.push_back(dim);
+      D->f_vars.push_back(var);
+      D->f_key_ptr.push_back((int32_t)D->f_vars.size());
+      D->meas.insert(D->meas.end(), D->values.begin() + off, D->values.begin() + off + sdim);
+      D->f_meas_ptr.push_back((int64_t)D->meas.size());
+      D->f_noise_kind.push_back(GSX_NOISE_ISOTROPIC);
+      D->noise.push_back(0.1);
+      D->f_noise_ptr.push_back((int64_t)D->noise.size());
+    }
+  }
+  *out = D;
+  return GSX_OK;
+}
+
+gsx_status gsx_dataset_get(const gsx_dataset* D, gsx_problem_desc* desc, const double** values, int64_t* n_values) {
+  if (!D || !desc) return GSX_E_INVALID;
+  static const double zero = 0.0;
+  desc->n_vars = (int32_t)D->var_keys.size();
+  desc->var_keys = D->var_keys.data();
+  desc->var_types = D->var_types.data();
+  desc->var_dims = D->var_dims.data();
+  desc->n_factors = (int32_t)D->f_type.size();
+  desc->f_type = D->f_type.data();
+  desc->f_rows = D->f_rows.data();
+  desc->f_key_ptr = D->f_key_ptr.data();
+  desc->f_vars = D->f_vars.data();
+  desc->f_meas_ptr = D->f_meas_ptr.data();
+  desc->meas = D->meas.empty() ? &zero : D->meas.data();
+  desc->f_noise_kind = D->f_noise_kind.data();
+  desc->f_noise_ptr = D->f_noise_ptr.data();
+  desc->noise = D->noise.empty() ? &zero : D->noise.data();
+  if (values) *values = D->values.data();
+  if (n_values) *n_values = (int64_t)D->values.size();
+  return GSX_OK;
+}
+
+void gsx_dataset_free(gsx_dataset* D) { delete D; }
+
+}  // extern "C"

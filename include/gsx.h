@@ -205,6 +205,24 @@ typedef struct gsx_stats {
   int64_t n_cheirality;          /* SFM factors zeroed by cheirality in the last linearize */
 } gsx_stats;
 
+/* ---- on-disk formats (host only) -------------------------
+ * Native readers of the files the reference's drivers start from, lowered to a
+ * gsx_problem_desc + packed initial Values owned by an opaque gsx_dataset.
+ *   gsx_read_g2o   readG2o / parse3DFactors: gtsam/slam/dataset.cpp:216-296,505-633
+ *                  (2-D), :756-863 (3-D, information permuted from (t,R) to (R,t));
+ *                  noise = Gaussian::Information (gtsam/linear/NoiseModel.cpp:98-112);
+ *                  + the anchoring prior of examples/Pose2SLAMExample_g2o.cpp:65-67 /
+ *                  Pose3SLAMExample_g2o.cpp:42-48, appended last
+ *   gsx_read_bal   SfmData::FromBalFile gtsam/sfm/SfmData.cpp:189-245 + openGL2gtsam
+ *                  :79-85; graph of examples/SFMExample_bal.cpp:55-68 (add_priors != 0
+ *                  appends its two priors)
+ * The pointers handed out by gsx_dataset_get stay valid until gsx_dataset_free. */
+typedef struct gsx_dataset gsx_dataset;
+gsx_status gsx_read_g2o(const char* path, int32_t is3d, gsx_dataset** out);
+gsx_status gsx_read_bal(const char* path, int32_t add_priors, gsx_dataset** out);
+gsx_status gsx_dataset_get(const gsx_dataset* d, gsx_problem_desc* desc, const double** values, int64_t* n_values);
+void gsx_dataset_free(gsx_dataset* d);
+
 /* ---- lifecycle ------------------------------------------------------------ */
 gsx_status gsx_create(const gsx_problem_desc* desc, int32_t device, gsx_handle* out);
 gsx_status gsx_destroy(gsx_handle h);

@@ -322,6 +322,35 @@ def test_MoreOptimization(gpu):
         assert actual.at(k).equals(e, 1e-6)
 
 
+def test_disconnected_graph(gpu):
+    """tests/testNonlinearOptimizer.cpp:485-503 on the device: a forest with two roots."""
+    from tests.test_oracle_golden import disconnected_graph
+    graph, init, expected = disconnected_graph()
+    actual = LevenbergMarquardtOptimizer(graph, init, Ordering([X(1), X(2), X(3)]), LevenbergMarquardtParams()).optimize()
+    for k, e in expected.items():
+        assert actual.at(k).equals(e, 1e-9)
+    # ... and with the library's own ordering (no ordering given)
+    actual = LevenbergMarquardtOptimizer(graph, init).optimize()
+    for k, e in expected.items():
+        assert actual.at(k).equals(e, 1e-9)
+
+
+def test_single_variable_and_tiny_graphs(gpu, oracle):
+    """Smallest inputs: one variable with one prior (a 1-clique tree with an empty separator), and a 2-variable chain."""
+    g = NonlinearFactorGraph()
+    g.addPrior(7, Pose2(1., 2., 0.3), noiseModel.Diagonal.Sigmas([0.1, 0.2, 0.3]))
+    v = Values()
+    v.insert(7, Pose2(0., 0., 0.))
+    arr = g.to_arrays(v)
+    gb, ob = gpu.product_backend(arr), oracle.oracle_backend(arr)
+    for be in (gb, ob):
+        be.set_ordering([7])
+        be.linearize()
+    assert relerr(gb.solve(0.0), ob.solve(0.0)) < 1e-12
+    out = LevenbergMarquardtOptimizer(g, v).optimize()
+    assert out.at(7).equals(Pose2(1., 2., 0.3), 1e-9)
+
+
 def test_indeterminate_system(gpu):
     fg = NonlinearFactorGraph()
     fg.add(BetweenFactor(0, 1, Pose2(1, 0, 0), noiseModel.Isotropic.Sigma(3, 1)))

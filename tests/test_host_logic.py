@@ -207,3 +207,39 @@ def test_pose3example_oracle_gn_converges(oracle, golden_dir):
     # "Pose3SLAMExample_g2o pose3example.txt  64 941.32 -> 19 130.66" (Gauss-Newton, default params)
     assert abs(r["initial_error"] - 64941.32) < 0.01
     assert abs(r["final_error"] - 19130.66) < 0.01
+
+
+# ---- native readers (csrc/io.cpp) against the Python readers on the reference's own data files -------------------
+def _same_arrays(a, b, noise_tol=1e-12):
+    for n in ("var_keys", "var_types", "var_dims", "f_type", "f_rows", "f_key_ptr", "f_vars", "f_meas_ptr",
+              "f_noise_kind", "f_noise_ptr"):
+        assert np.array_equal(getattr(a, n), getattr(b, n)), n
+    assert np.allclose(a.meas, b.meas, rtol=0, atol=1e-15)
+    assert np.allclose(a.noise, b.noise, rtol=noise_tol, atol=1e-15)
+    assert np.allclose(a.values, b.values, rtol=0, atol=1e-15)
+
+
+@pytest.mark.parametrize("name,is3d", [("pose2example.txt", False), ("noisyToyGraph.txt", False),
+                                       ("pose3example.txt", True)])
+def test_native_g2o_reader_matches_python_reader(lib, golden_dir, name, is3d):
+    path = os.path.join(golden_dir, name)
+    _same_arrays(_lib.read_g2o(path, is3d), datasets.read_g2o(path, is3D=is3d))
+
+
+@pytest.mark.parametrize("priors", [False, True])
+def test_native_bal_reader_matches_python_reader(lib, golden_dir, priors):
+    path = os.path.join(golden_dir, "dubrovnik-3-7-pre.txt")
+    py = datasets.bal_arrays(datasets.read_bal(path), priors=priors)
+    _same_arrays(_lib.read_bal(path, priors), py)
+
+
+def test_native_readers_reject_missing_and_malformed_files(lib, tmp_path):
+    with pytest.raises(A.GsxError):
+        _lib.read_g2o(str(tmp_path / "nope.g2o"))
+    bad = tmp_path / "bad.txt"
+    bad.write_text("3 7 12\n0 0 1.0\n")  # truncated BAL
+    with pytest.raises(A.GsxError):
+        _lib.read_bal(str(bad))
+    bad.write_text("EDGE_SE2 0 1 1.0 0.0\n")  # truncated edge
+    with pytest.raises(A.GsxError):
+        _lib.read_g2o(str(bad))

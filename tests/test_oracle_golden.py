@@ -308,6 +308,29 @@ def test_MoreOptimization_diagonal_damping(orc):
     assert np.allclose(delta, expected, rtol=1e-8, atol=1e-10)
 
 
+def disconnected_graph():
+    """tests/testNonlinearOptimizer.cpp:485-503 — two components: (x1 - x2) and x3 alone."""
+    graph = NonlinearFactorGraph()
+    graph.addPrior(X(1), Pose2(0., 0., 0.), noiseModel.Isotropic.Sigma(3, 1))
+    graph.add(BetweenFactor(X(1), X(2), Pose2(1.5, 0., 0.), noiseModel.Isotropic.Sigma(3, 1)))
+    graph.addPrior(X(3), Pose2(3., 0., 0.), noiseModel.Isotropic.Sigma(3, 1))
+    init = Values()
+    for k in (1, 2, 3):
+        init.insert(X(k), Pose2(0., 0., 0.))
+    expected = {X(1): Pose2(0., 0., 0.), X(2): Pose2(1.5, 0., 0.), X(3): Pose2(3.0, 0., 0.)}
+    return graph, init, expected
+
+
+def test_disconnected_graph(orc):
+    """:485-503 — a forest (two Bayes-tree roots) optimizes like any other graph."""
+    graph, init, expected = disconnected_graph()
+    opt = LevenbergMarquardtOptimizer(graph, init, Ordering([X(1), X(2), X(3)]), LevenbergMarquardtParams(),
+                                      backend_factory=orc.oracle_backend)
+    actual = opt.optimize()
+    for k, e in expected.items():
+        assert actual.at(k).equals(e, 1e-9)
+
+
 def test_lm_lambda0_equals_gauss_newton(orc):
     """:60-82 — with lambda = 0 one LM iteration equals one Gauss-Newton iteration."""
     fg = more_optimization_graph()
