@@ -1401,8 +1401,9 @@ __global__ void __launch_bounds__(NT) big_potrf0_kernel(const BigDesc* descs, do
 __global__ void __launch_bounds__(NT) big_panel_kernel(const BigDesc* descs, int kb, double* arena, DevStatus* status) {
   extern __shared__ double dyn_lds[];
   constexpr int TS = T * (T + 1);
-  TilePtr Ri = (TilePtr)dyn_lds, Rj = (TilePtr)(dyn_lds + TS), Li = (TilePtr)(dyn_lds + 2 * TS),
-          Xi = (TilePtr)(dyn_lds + 3 * TS), Xj = (TilePtr)(dyn_lds + 4 * TS);
+  // three tiles of LDS (25 KB: six workgroups per CU): the solved tiles X_i, X_j overwrite the raw ones
+  TilePtr Ri = (TilePtr)dyn_lds, Rj = (TilePtr)(dyn_lds + TS), Li = (TilePtr)(dyn_lds + 2 * TS);
+  const TilePtr Xi = Ri, Xj = Rj;
   STAMP_BEGIN
   const BigDesc d = descs[blockIdx.y];
   const int n = d.N, F = d.F, c0 = kb * T;
@@ -1452,13 +1453,15 @@ __global__ void __launch_bounds__(NT) big_panel_kernel(const BigDesc* descs, int
     // X[r][c] = sum_{k <= c} R[r][k] Linv[c][k]: columns of the first half only need k < 16
     const bool half = L.cq0 == 0;  // wave-uniform
     const v4d xi = half ? tile_product<16>(L, Li, Ri) : tile_product<T>(L, Li, Ri);
+    v4d xj = xi;
+    if (i != j) xj = half ? tile_product<16>(L, Li, Rj) : tile_product<T>(L, Li, Rj);
+    lds_barrier();  // every wave has read the raw tiles
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       Xi[L.r][L.c[q]] = xi[q];
       if (i == j && L.r < hi && L.c[q] < w) X[(ri + L.r) + (i64)(c0 + L.c[q]) * n] = xi[q];
     }
     if (i != j) {
-      const v4d xj = half ? tile_product<16>(L, Li, Rj) : tile_product<T>(L, Li, Rj);
 #pragma unroll
       for (int q = 0; q < 4; ++q) Xj[L.r][L.c[q]] = xj[q];
     }
@@ -1502,7 +1505,7 @@ static void big_kernels_attr() {
   static bool done = false;
   if (done) return;
   hipFuncSetAttribute((const void*)big_potrf0_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (int)kTileBytes);
-  hipFuncSetAttribute((const void*)big_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * (int)kTileBytes);
+  hipFuncSetAttribute((const void*)big_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (int)kTileBytes);
   done = true;
 }
 
@@ -1515,7 +1518,7 @@ void launch_big_step(const BigDesc* descs, int count, int kb, int max_pairs, dou
                      hipStream_t st) {
   if (!count || max_pairs <= 0) return;
   big_kernels_attr();
-  big_panel_kernel<<<dim3(max_pairs, count), NT, 5 * kTileBytes, st>>>(descs, kb, arena, status);
+  big_panel_kernel<<<dim3(max_pairs, count), NT, 3 * kTileBytes, st>>>(descs, kb, arena, status);
 }
 
 // ---------------------------------------------------------------------------------------------
