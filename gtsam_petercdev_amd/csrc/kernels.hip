@@ -473,7 +473,7 @@ __global__ void assemble_h_kernel(DevProblem P, DevSymbolic S, const int* vars, 
   // SFM factors — are issued back to back before the first FMA.  (The compiler serialised the per-row loads of
   // the earlier two-term scalar-record form: six round trips per pair of terms.)  Terms are accumulated into the
   // panel in list order: deterministic.
-  constexpr int kTG = 4;
+  constexpr int kTG = 3;
   const int uw = __builtin_amdgcn_readfirstlane(wave);
   const i64 tb0 = S.term_ptr[v], tn = S.term_ptr[v + 1] - tb0;
   const i64 chunk = ((tn + nw - 1) / nw + 1) & ~i64(1);
@@ -503,23 +503,23 @@ __global__ void assemble_h_kernel(DevProblem P, DevSymbolic S, const int* vars, 
       }
       for (int e = lane; e < nemax; e += 64) {
         double acc[kTG], a0[kTG], b0[kTG], a1[kTG], b1[kTG];
-        const double *pa[kTG], *pb[kTG];
+        unsigned oa[kTG], ob[kTG];  // 32-bit lane offsets from the term's (wave-uniform, scalar) Jacobian base
         bool on[kTG];
         int ii[kTG], jj[kTG];
 #pragma unroll
         for (int i = 0; i < kTG; ++i) {
           on[i] = e < tdB[i] * dA;
           divmod_small(e, tdB[i], trd[i], jj[i], ii[i]);
-          pa[i] = tj[i] + (tB[i] + ii[i]) * tm[i];
-          pb[i] = tj[i] + (tA[i] + jj[i]) * tm[i];
+          oa[i] = (unsigned)((tB[i] + ii[i]) * tm[i]);
+          ob[i] = (unsigned)((tA[i] + jj[i]) * tm[i]);
         }
 #pragma unroll
         for (int i = 0; i < kTG; ++i) {
           const bool r0 = on[i] && tm[i] > 0, r1 = on[i] && tm[i] > 1;
-          a0[i] = r0 ? pa[i][0] : 0.0;
-          b0[i] = r0 ? pb[i][0] : 0.0;
-          a1[i] = r1 ? pa[i][1] : 0.0;
-          b1[i] = r1 ? pb[i][1] : 0.0;
+          a0[i] = r0 ? tj[i][oa[i]] : 0.0;
+          b0[i] = r0 ? tj[i][ob[i]] : 0.0;
+          a1[i] = r1 ? tj[i][oa[i] + 1u] : 0.0;
+          b1[i] = r1 ? tj[i][ob[i] + 1u] : 0.0;
         }
 #pragma unroll
         for (int i = 0; i < kTG; ++i) acc[i] = a0[i] * b0[i] + a1[i] * b1[i];
@@ -528,8 +528,8 @@ __global__ void assemble_h_kernel(DevProblem P, DevSymbolic S, const int* vars, 
 #pragma unroll
           for (int i = 0; i < kTG; ++i) {
             const bool rr = on[i] && r < tm[i];
-            ar[i] = rr ? pa[i][r] : 0.0;
-            br[i] = rr ? pb[i][r] : 0.0;
+            ar[i] = rr ? tj[i][oa[i] + (unsigned)r] : 0.0;
+            br[i] = rr ? tj[i][ob[i] + (unsigned)r] : 0.0;
           }
 #pragma unroll
           for (int i = 0; i < kTG; ++i) acc[i] += ar[i] * br[i];
