@@ -390,6 +390,29 @@ __global__ void __launch_bounds__(256) linear_error_kernel(DevProblem P, const d
   for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < P.n_factors; f += gridDim.x * blockDim.x) {
     const int m = P.f_rows[f], nc = P.f_cols[f];
     const double* J = jac + P.f_jac_off[f];
+    if (m == 2 && (P.f_jac_off[f] & 1) == 0) {
+      // two-row factors (every SFM observation): a column is one 16-byte load — half the memory instructions of a
+      // kernel whose lanes each walk their own 208-byte block
+      const double2* J2 = reinterpret_cast<const double2*>(J);
+      const double2 b = J2[nc - 1];
+      double e0 = -b.x, e1 = -b.y;
+      int col = 0;
+      for (int k = P.f_key_ptr[f]; k < P.f_key_ptr[f + 1]; ++k) {
+        const int v = P.f_vars[k];
+        const double* x = delta + P.var_tan_off[v];
+        const int d = P.var_dim[v];
+        for (int c = 0; c < d; ++c, ++col) {
+          const double2 j = J2[col];
+          e0 += j.x * x[c];
+          e1 += j.y * x[c];
+        }
+      }
+      acc0 += b.x * b.x;
+      accd += e0 * e0;
+      acc0 += b.y * b.y;
+      accd += e1 * e1;
+      continue;
+    }
     for (int r = 0; r < m; ++r) {
       const double b = J[(nc - 1) * m + r];
       double e = -b;
