@@ -509,18 +509,21 @@ __global__ void assemble_h_kernel(DevProblem P, DevSymbolic S, const int* vars, 
       const double* tj[kTG];
       int tm[kTG], tA[kTG], tB[kTG], tdB[kTG], tdst[kTG];
       float trd[kTG];
+      bool tpair[kTG];
       int mmax = 0, nemax = 0;
 #pragma unroll
       for (int i = 0; i < kTG; ++i) {
         const int src = min(g + i, 63);  // wave-uniform
         const bool in = g + i < nblk;
-        tj[i] = jac + readlane_i64(rec.jac, src);
+        const i64 joff = readlane_i64(rec.jac, src);
+        tj[i] = jac + joff;
         tm[i] = in ? __builtin_amdgcn_readlane(rec.m, src) : 0;
         tA[i] = __builtin_amdgcn_readlane(rec.colA, src);
         tB[i] = __builtin_amdgcn_readlane(rec.colB, src);
         tdB[i] = in ? __builtin_amdgcn_readlane(rec.dB, src) : 0;
         tdst[i] = __builtin_amdgcn_readlane(rec.dst, src);
         trd[i] = __builtin_amdgcn_rcpf((float)max(tdB[i], 1));
+        tpair[i] = tm[i] == 2 && (joff & 1) == 0;
         mmax = max(mmax, tm[i]);
         nemax = max(nemax, tdB[i] * dA);
       }
@@ -538,11 +541,20 @@ __global__ void assemble_h_kernel(DevProblem P, DevSymbolic S, const int* vars, 
         }
 #pragma unroll
         for (int i = 0; i < kTG; ++i) {
-          const bool r0 = on[i] && tm[i] > 0, r1 = on[i] && tm[i] > 1;
-          a0[i] = r0 ? tj[i][oa[i]] : 0.0;
-          b0[i] = r0 ? tj[i][ob[i]] : 0.0;
-          a1[i] = r1 ? tj[i][oa[i] + 1u] : 0.0;
-          b1[i] = r1 ? tj[i][ob[i] + 1u] : 0.0;
+          if (tpair[i]) {  // wave-uniform: two-row factor at an even offset — rows 0 and 1 of a column in one 16-byte load
+            double2 av = {0.0, 0.0}, bv = {0.0, 0.0};
+            if (on[i]) {
+              av = *reinterpret_cast<const double2*>(tj[i] + oa[i]);
+              bv = *reinterpret_cast<const double2*>(tj[i] + ob[i]);
+            }
+            a0[i] = av.x; a1[i] = av.y; b0[i] = bv.x; b1[i] = bv.y;
+          } else {
+            const bool r0 = on[i] && tm[i] > 0, r1 = on[i] && tm[i] > 1;
+            a0[i] = r0 ? tj[i][oa[i]] : 0.0;
+            b0[i] = r0 ? tj[i][ob[i]] : 0.0;
+            a1[i] = r1 ? tj[i][oa[i] + 1u] : 0.0;
+            b1[i] = r1 ? tj[i][ob[i] + 1u] : 0.0;
+          }
         }
 #pragma unroll
         for (int i = 0; i < kTG; ++i) acc[i] = a0[i] * b0[i] + a1[i] * b1[i];
