@@ -96,6 +96,15 @@ __device__ __forceinline__ void whiten_store(double (&J)[M * NC], int kind, cons
       for (int r = 0; r < M; ++r) J[c * M + r] = col[r];
     }
   }
+  // a lane owns its factor's block: 16-byte stores halve the memory instructions when the block allows it
+  if constexpr ((M * NC) % 2 == 0) {
+    if ((reinterpret_cast<size_t>(out) & 15) == 0) {
+      double2* out2 = reinterpret_cast<double2*>(out);
+#pragma unroll
+      for (int i = 0; i < M * NC / 2; ++i) out2[i] = double2{J[2 * i], J[2 * i + 1]};
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < M * NC; ++i) out[i] = J[i];
 }
