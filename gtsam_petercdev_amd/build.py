@@ -30,8 +30,6 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
                "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value", "-c", os.path.join(CSRC, s), "-o", o]
         if os.environ.get("GSX_STAMP") and s.endswith(".hip"):
             cmd.insert(1, "-DGSX_STAMP")
-        if os.environ.get("GSX_BIG_NT") and s.endswith(".hip"):
-            cmd.insert(1, "-DGSX_BIG_NT=" + os.environ["GSX_BIG_NT"])
         if s.endswith(".cpp"):
             cmd.insert(1, "-x")
             cmd.insert(2, "c++")

@@ -125,6 +125,7 @@ void launch_backsolve(const DevSymbolic& S, const int* ids, int count, int threa
 void launch_backsolve_leaf(const DevSymbolic& S, const int* ids, int count, const double* arena, double* delta,
                            DevStatus* status, hipStream_t st);
 void launch_set_scalar(double* scalars, int slot, double v, hipStream_t st);
+void launch_begin_factorization(double* scalars, double lambda, DevStatus* status, hipStream_t st);
 // dense unit kernel for gsx_cholesky_partial: in-place lower partial Cholesky of an n x n
 // column-major matrix (lower triangle significant)
 void launch_dense_partial(double* a, int n, int nf, DevStatus* status, hipStream_t st);

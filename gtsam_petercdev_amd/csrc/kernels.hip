@@ -567,7 +567,7 @@ __global__ void assemble_h_kernel(DevProblem P, DevSymbolic S, const int* vars, 
         }
 #pragma unroll
         for (int i = 0; i < kTG; ++i) acc[i] = a0[i] * b0[i] + a1[i] * b1[i];
-        for (int r = 2; r < mmax; ++r) {
+        for (int r = 2; r < mmax; ++r) {  // (16-byte pair loads here too were measured: the extra registers cost more)
           double ar[kTG], br[kTG];
 #pragma unroll
           for (int i = 0; i < kTG; ++i) {
@@ -665,6 +665,17 @@ void launch_make_damping(int n, const double* hdiag, int diagonal, double mind, 
 __global__ void set_scalar_kernel(double* scalars, int slot, double v) { scalars[slot] = v; }
 void launch_set_scalar(double* scalars, int slot, double v, hipStream_t st) {
   set_scalar_kernel<<<1, 1, 0, st>>>(scalars, slot, v);
+}
+// start of a factorization: lambda + the status words of the factorization / back-substitution in ONE tiny launch
+// (three memset / memcpy nodes cost ~5 us each on the stream; the cheirality count of the last linearize is kept)
+__global__ void begin_factorization_kernel(double* scalars, double lambda, DevStatus* status) {
+  scalars[SC_LAMBDA] = lambda;
+  status->n_fail = 0;
+  status->first_front = 0x7fffffff;
+  status->n_nonfinite = 0;
+}
+void launch_begin_factorization(double* scalars, double lambda, DevStatus* status, hipStream_t st) {
+  begin_factorization_kernel<<<1, 1, 0, st>>>(scalars, lambda, status);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -59,7 +59,7 @@ struct SmallLaunch {
 };
 struct BigLevel {
   int begin = 0, count = 0, steps = 0, max_s1 = 0;
-  std::vector<int> row_tiles, pairs;  // per kb
+  std::vector<int> pairs;  // per panel step kb: the most lower tile pairs of any front of the level
 };
 
 enum Phase { PH_LINEARIZE, PH_ASSEMBLE_H, PH_FACTORIZE, PH_BACKSOLVE, PH_LINERR, PH_RETRACT, PH_ERROR,
@@ -440,14 +440,12 @@ gsx_status upload_symbolic(gsx_context* c) {
       c->big_max_nfv = std::max(c->big_max_nfv, S.nfrontal_vars[f]);
     }
     B.count = (int)c->big_descs.size() - B.begin;
-    B.row_tiles.assign(B.steps, 0);
     B.pairs.assign(B.steps, 0);
     for (int k = B.begin; k < B.begin + B.count; ++k) {
       const BigDesc& d = c->big_descs[k];
       for (int kb = 0; kb * kTile < d.F; ++kb) {
         const int c0 = kb * kTile, w = std::min(kTile, d.F - c0), base = c0 + w;
         const int nt = (d.N - base + kTile - 1) / kTile;
-        B.row_tiles[kb] = std::max(B.row_tiles[kb], nt);
         B.pairs[kb] = std::max(B.pairs[kb], nt * (nt + 1) / 2);
       }
     }
@@ -538,12 +536,7 @@ void dev_damping(gsx_context* c, int diagonal, double mind, double maxd) {
 void dev_factorize(gsx_context* c, double lambda) {
   const Symbolic& S = c->S;
   timer_begin(c, PH_FACTORIZE);
-  launch_set_scalar(c->d_scalars.p, SC_LAMBDA, lambda, c->stream);
-  DevStatus init{0, INT_MAX, 0, 0};
-  // keep the cheirality count of the last linearize
-  hipMemsetAsync(&c->d_status.p->n_fail, 0, sizeof(int), c->stream);
-  hipMemcpyAsync(&c->d_status.p->first_front, &init.first_front, sizeof(int), hipMemcpyHostToDevice, c->stream);
-  hipMemsetAsync(&c->d_status.p->n_nonfinite, 0, sizeof(int), c->stream);
+  launch_begin_factorization(c->d_scalars.p, lambda, c->d_status.p, c->stream);
   if (!c->big_descs.empty())
     launch_big_init(c->DP, c->DS, c->d_big.p, (int)c->big_descs.size(), c->big_max_n, c->big_max_nfv, c->d_H.p,
                     c->d_damp.p, c->d_scalars.p, c->d_arena.p, c->stream);
