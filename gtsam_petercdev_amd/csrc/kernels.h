@@ -28,6 +28,15 @@ struct VarRec {
   i64 h_off, hmap_off;
   int dA, rows, loc, toff;
 };
+// Everything the leaf kernels need about one leaf clique, in schedule order (80 bytes through the scalar path: the
+// dependent-load chain of a 64-thread workgroup is record -> data instead of id -> front tables -> variable tables ->
+// data).  The H-panel fields describe the FIRST frontal variable (the only one of a BAL landmark clique).
+struct LeafRec {
+  i64 off, h_off, hmap_off, gidx_ptr;
+  int n, F, nfv, lean;
+  int dA, rows, loc, toff;
+  int fvar_ptr, front, pad0, pad1;
+};
 struct ChildRec {
   i64 src0, cmap_off;   // arena offset of the child's Schur complement (top-left), offset of its row map
   int nc, s1, pad0, pad1;
@@ -94,7 +103,7 @@ void launch_big_init(const DevProblem& P, const DevSymbolic& S, const BigDesc* d
 void launch_big_potrf0(const BigDesc* descs, int count, double* arena, DevStatus* status, hipStream_t st);
 void launch_big_step(const BigDesc* descs, int count, int kb, int max_pairs, double* arena, DevStatus* status,
                      hipStream_t st);
-void launch_front_leaf(const DevProblem& P, const DevSymbolic& S, const int* ids, int count, int max_panel, int threads,
+void launch_front_leaf(const DevProblem& P, const DevSymbolic& S, const LeafRec* recs, int count, int max_panel, int threads,
                        const double* H, const double* damp, const double* scalars, double* arena, DevStatus* status,
                        hipStream_t st);
 // Deterministic extend-add into big parents (big_gather).
@@ -122,7 +131,7 @@ void launch_big_gather(const GatherArgs& G, int seg0, int nseg, int m0, int nm, 
 void launch_backsolve(const DevSymbolic& S, const int* ids, int count, int threads, int max_n, const double* arena,
                       double* delta, DevStatus* status, hipStream_t st);
 // leaf cliques of a level, a wave per clique
-void launch_backsolve_leaf(const DevSymbolic& S, const int* ids, int count, const double* arena, double* delta,
+void launch_backsolve_leaf(const DevSymbolic& S, const LeafRec* recs, int count, const double* arena, double* delta,
                            DevStatus* status, hipStream_t st);
 void launch_set_scalar(double* scalars, int slot, double v, hipStream_t st);
 void launch_begin_factorization(double* scalars, double lambda, DevStatus* status, hipStream_t st);

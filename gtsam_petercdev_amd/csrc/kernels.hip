@@ -894,24 +894,29 @@ void launch_front_small(const DevProblem& P, const DevSymbolic& S, const int* id
 // matrix in LDS, no zeroing of it, no trailing-update sweeps (the reference allocates and sweeps the full
 // (F+S+1)^2 augmented Hessian per landmark: HessianFactor.cpp:240-253, cholesky.cpp:108-143).
 // ---------------------------------------------------------------------------------------------
-__global__ void front_leaf_kernel(DevProblem P, DevSymbolic S, const int* ids, const double* H, const double* damp,
+__global__ void front_leaf_kernel(DevProblem P, DevSymbolic S, const LeafRec* recs, const double* H, const double* damp,
                                   const double* scalars, double* arena, DevStatus* status) {
   extern __shared__ double Pn[];  // n x F, column-major, ld = n
-  const int f = ids[blockIdx.x];
-  const int n = S.fr_N[f], F = S.fr_F[f];
+  const LeafRec rec = recs[blockIdx.x];
+  const int f = rec.front;
+  const int n = rec.n, F = rec.F;
   const int tid = threadIdx.x, nt = blockDim.x;
   const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
   const double lambda = scalars[SC_LAMBDA];
   for (int e = tid; e < n * F; e += nt) Pn[e] = 0;
   __syncthreads();
-  const int nfv = S.fr_nfv[f];
-  const int* fv = S.fvars + S.fr_fvar_ptr[f];
-  for (int k = 0; k < nfv; ++k) {
-    const int v = fv[k];
-    const int dA = P.var_dim[v], rows = S.h_rows[v], c0 = S.h_loc[v];
-    const double* hp = H + S.h_off[v];
-    const int* hm = S.hmap + S.hmap_ptr[v];
-    const int toff = P.var_tan_off[v];
+  for (int k = 0; k < rec.nfv; ++k) {
+    // the first frontal variable's panel is described by the record itself; further ones (merged leaf cliques of
+    // pose graphs) by their VarRec
+    int dA = rec.dA, rows = rec.rows, c0 = rec.loc, toff = rec.toff;
+    const double* hp = H + rec.h_off;
+    const int* hm = S.hmap + rec.hmap_off;
+    if (k > 0) {
+      const VarRec vr = S.var_recs[S.fvars[rec.fvar_ptr + k]];
+      dA = vr.dA; rows = vr.rows; c0 = vr.loc; toff = vr.toff;
+      hp = H + vr.h_off;
+      hm = S.hmap + vr.hmap_off;
+    }
     const float rrows = 1.0f / (float)rows;
     for (int e = tid; e < rows * dA; e += nt) {
       int r, j;
@@ -948,11 +953,11 @@ __global__ void front_leaf_kernel(DevProblem P, DevSymbolic S, const int* ids, c
     if (!(e1 > -12)) fail = 1;
   }
   if (fail && tid == 0) report_failure(status, f);
-  double* A = arena + S.fr_off[f];
+  double* A = arena + rec.off;
   for (int c = wave; c < F; c += nw)
     for (int r = c + lane; r < n; r += 64) A[r + (i64)c * n] = Pn[r + c * n];
   // a lean leaf stops here: its big parent's gather forms the Schur complement blocks from this panel
-  if (S.fr_lean[f]) return;
+  if (rec.lean) return;
   // Schur complement -L21 L21' as an outer product, thread-per-row: row r's F values stay in registers
   // (F <= kLeafMaxF), the threads of a row split the columns, two columns in flight per iteration.
   const int s1 = n - F;
@@ -987,11 +992,11 @@ __global__ void front_leaf_kernel(DevProblem P, DevSymbolic S, const int* ids, c
   }
 }
 
-void launch_front_leaf(const DevProblem& P, const DevSymbolic& S, const int* ids, int count, int max_panel, int threads,
+void launch_front_leaf(const DevProblem& P, const DevSymbolic& S, const LeafRec* recs, int count, int max_panel, int threads,
                        const double* H, const double* damp, const double* scalars, double* arena, DevStatus* status,
                        hipStream_t st) {
   if (count)
-    front_leaf_kernel<<<count, threads, (size_t)max_panel * sizeof(double), st>>>(P, S, ids, H, damp, scalars, arena,
+    front_leaf_kernel<<<count, threads, (size_t)max_panel * sizeof(double), st>>>(P, S, recs, H, damp, scalars, arena,
                                                                                    status);
 }
 
@@ -1660,15 +1665,15 @@ __global__ void backsolve_kernel(DevSymbolic S, const int* ids, const double* ar
 // Leaf cliques (F <= kLeafMaxF: BAL landmarks, pose-graph leaves): one WAVE per clique, four per workgroup, no
 // barriers.  The separator part of the solution is gathered once per lane (rows lane, lane + 64, ...), each frontal
 // column is a wave-wide dot product, and the F x F triangle is solved by substitution on the reduced values.
-__global__ void __launch_bounds__(256) backsolve_leaf_kernel(DevSymbolic S, const int* ids, int count, const double* arena,
-                                                             double* delta, DevStatus* status) {
+__global__ void __launch_bounds__(256) backsolve_leaf_kernel(DevSymbolic S, const LeafRec* recs, int count,
+                                                             const double* arena, double* delta, DevStatus* status) {
   const int lane = threadIdx.x & 63;
   const int k = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
   if (k >= count) return;
-  const int f = ids[k];
-  const int n = S.fr_N[f], F = S.fr_F[f];
-  const double* A = arena + S.fr_off[f];
-  const int* gi = S.gidx + S.gidx_ptr[f];
+  const LeafRec rec = recs[k];
+  const int n = rec.n, F = rec.F;
+  const double* A = arena + rec.off;
+  const int* gi = S.gidx + rec.gidx_ptr;
   // y_c = d_c - sum_{r >= F} L[r][c] x_r, c < F
   double yc[kLeafMaxF];
 #pragma unroll
@@ -1712,9 +1717,9 @@ __global__ void __launch_bounds__(256) backsolve_leaf_kernel(DevSymbolic S, cons
   }
 }
 
-void launch_backsolve_leaf(const DevSymbolic& S, const int* ids, int count, const double* arena, double* delta,
+void launch_backsolve_leaf(const DevSymbolic& S, const LeafRec* recs, int count, const double* arena, double* delta,
                            DevStatus* status, hipStream_t st) {
-  if (count) backsolve_leaf_kernel<<<(count + 3) / 4, 256, 0, st>>>(S, ids, count, arena, delta, status);
+  if (count) backsolve_leaf_kernel<<<(count + 3) / 4, 256, 0, st>>>(S, recs, count, arena, delta, status);
 }
 
 void launch_backsolve(const DevSymbolic& S, const int* ids, int count, int threads, int max_n, const double* arena,

@@ -102,6 +102,8 @@ struct gsx_context {
   DevBuf<TermRec> d_terms;
   DevBuf<VarRec> d_var_recs;
   DevBuf<ChildRec> d_child_recs;
+  DevBuf<LeafRec> d_leaf_recs;   // leaf-kernel cliques of level 0, in schedule order
+  int leaf_base = 0;             // schedule position of d_leaf_recs[0]
   DevBuf<int> d_fr_N, d_fr_F, d_fr_nfv, d_fr_fvar_ptr, d_fvars, d_fr_parent, d_fr_lean, d_fr_child_ptr, d_children, d_cmap,
       d_gidx, d_h_rows, d_hmap, d_h_loc, d_sched, d_hvars;
   DevBuf<BigDesc> d_big;
@@ -318,6 +320,21 @@ gsx_status upload_symbolic(gsx_context* c) {
     HIPCHK(c, hipStreamSynchronize(st));
   }
   HIPCHK(c, c->d_sched.upload(S.sched, st));
+  {
+    // leaf-kernel cliques are childless, hence all at level 0, first in its schedule
+    const int b = S.n_levels ? S.lvl_ptr[0] : 0, e = S.n_levels ? S.lvl_leaf_end[0] : 0;
+    std::vector<LeafRec> lr((size_t)std::max(e - b, 0));
+    for (int k = b; k < e; ++k) {
+      const int f = S.sched[k];
+      const int v0 = S.fvars[S.fvar_ptr[f]];
+      lr[k - b] = LeafRec{(i64)S.off[f], (i64)S.h_off[v0], (i64)S.hmap_ptr[v0], (i64)S.gidx_ptr[f],
+                          S.N[f], S.F[f], S.nfrontal_vars[f], (int)S.lean[f],
+                          P.dims[v0], S.h_rows[v0], S.h_loc[v0], P.tan_off[v0],
+                          S.fvar_ptr[f], f, 0, 0};
+    }
+    c->leaf_base = b;
+    HIPCHK(c, c->d_leaf_recs.upload(lr, st));
+  }
   HIPCHK(c, c->d_H.alloc(std::max<int64_t>(S.h_size, 1)));
   HIPCHK(c, c->d_arena.alloc(std::max<int64_t>(S.arena_size, 1)));
   // ---- H assembly groups: variables bucketed by panel size (LDS) and term count -----------------
@@ -543,7 +560,7 @@ void dev_factorize(gsx_context* c, double lambda) {
   for (int l = 0; l < S.n_levels; ++l) {
     for (const SmallLaunch& sl : c->leaf_launch[l]) {
       if (c->profiling) timer_begin(c, PH_FACTOR_LEAF);
-      launch_front_leaf(c->DP, c->DS, c->d_sched.p + sl.begin, sl.count, sl.max_panel, sl.threads, c->d_H.p,
+      launch_front_leaf(c->DP, c->DS, c->d_leaf_recs.p + (sl.begin - c->leaf_base), sl.count, sl.max_panel, sl.threads, c->d_H.p,
                         c->d_damp.p, c->d_scalars.p, c->d_arena.p, c->d_status.p, c->stream);
       if (c->profiling) timer_end(c, PH_FACTOR_LEAF);
     }
@@ -615,8 +632,8 @@ void dev_backsolve(gsx_context* c) {
     }
     // all leaf-kernel cliques of the level in one launch (a wave each)
     if (S.lvl_leaf_end[l] > S.lvl_ptr[l])
-      launch_backsolve_leaf(c->DS, c->d_sched.p + S.lvl_ptr[l], S.lvl_leaf_end[l] - S.lvl_ptr[l], c->d_arena.p,
-                            c->d_delta.p, c->d_status.p, c->stream);
+      launch_backsolve_leaf(c->DS, c->d_leaf_recs.p + (S.lvl_ptr[l] - c->leaf_base), S.lvl_leaf_end[l] - S.lvl_ptr[l],
+                            c->d_arena.p, c->d_delta.p, c->d_status.p, c->stream);
   }
   timer_end(c, PH_BACKSOLVE);
 }
