@@ -1590,6 +1590,7 @@ __global__ void backsolve_kernel(DevSymbolic S, const int* ids, const double* ar
   extern __shared__ double xs[];  // n-1 solution entries of this front (frontal + separator)
   __shared__ double tile[TB][TB + 1];
   __shared__ double y[TB];
+  __shared__ double dv[TB];
   const int f = ids[blockIdx.x];
   const int n = S.fr_N[f], F = S.fr_F[f];
   const double* A = arena + S.fr_off[f];
@@ -1601,13 +1602,29 @@ __global__ void backsolve_kernel(DevSymbolic S, const int* ids, const double* ar
   const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
   for (int r = F + tid; r < n - 1; r += nt) xs[r] = delta[gi[r]];
   __syncthreads();
-  // big fronts carry (L^-1)' of every 32x32 diagonal tile in that tile's strictly upper triangle
-  // (diag_tile_factor; kTile == TB): the tile solve is then a 32-term dot product per lane instead of
-  // a 32-step serial substitution with divisions.
+  // big fronts carry (L^-1)' of every 32x32 diagonal tile in that tile's strictly upper triangle and 1 / L_cc in
+  // the L-panel area (diag_tile_factor; kTile == TB): the tile solve is then a 32-term dot product per lane instead
+  // of a 32-step serial substitution with divisions.
   const bool has_inv = big && (T == TB);
   const int nblk = (F + TB - 1) / TB;
+  constexpr int kTR = 16;  // tile entries per thread at the smallest block size (64 threads)
   for (int kb = nblk - 1; kb >= 0; --kb) {
     const int c0 = kb * TB, w = min(TB, F - c0);
+    // the diagonal tile (and the reciprocal diagonal) travels in registers while the dot products below stream the
+    // panel: nothing but LDS sits between the two barriers of a panel
+    double treg[kTR], dreg = 0.0;
+    const float rw = __builtin_amdgcn_rcpf((float)w);
+#pragma unroll
+    for (int q = 0; q < kTR; ++q) {
+      const int e = tid + q * nt;
+      treg[q] = 0.0;
+      if (e < w * w) {
+        int r, c;
+        divmod_small(e, w, rw, c, r);
+        if (has_inv || r >= c) treg[q] = A[(c0 + r) + (i64)(c0 + c) * n];
+      }
+    }
+    if (has_inv && tid < w) dreg = Lp[(c0 + tid) + (i64)(c0 + tid) * n];
     for (int c = 2 * wave; c < w; c += 2 * nw) {  // two columns per wave: independent loads and reductions
       const double* col0 = Lp + (i64)(c0 + c) * n;
       const bool two = c + 1 < w;
@@ -1628,10 +1645,16 @@ __global__ void backsolve_kernel(DevSymbolic S, const int* ids, const double* ar
         if (two) y[c + 1] = col1[n - 1] - acc1;
       }
     }
-    for (int e = tid; e < w * w; e += nt) {
-      const int r = e % w, c = e / w;
-      if (has_inv || r >= c) tile[r][c] = A[(c0 + r) + (i64)(c0 + c) * n];
+#pragma unroll
+    for (int q = 0; q < kTR; ++q) {
+      const int e = tid + q * nt;
+      if (e < w * w) {
+        int r, c;
+        divmod_small(e, w, rw, c, r);
+        tile[r][c] = treg[q];
+      }
     }
+    if (tid < w) dv[tid] = dreg;
     __syncthreads();
     if (wave == 0) {
       double yr;
@@ -1639,7 +1662,7 @@ __global__ void backsolve_kernel(DevSymbolic S, const int* ids, const double* ar
         // x = (L^-1)' y:  x[c] = y[c] / L[c][c] + sum_{r > c} (L^-1)[r][c] y[r],  (L^-1)[r][c] = tile[c][r]
         yr = 0;
         if (lane < w) {
-          yr = y[lane] * Lp[(c0 + lane) + (i64)(c0 + lane) * n];  // 1 / L_cc (diag_tile_factor)
+          yr = y[lane] * dv[lane];
           for (int r = lane + 1; r < w; ++r) yr += tile[lane][r] * y[r];
         }
       } else {
@@ -1651,14 +1674,18 @@ __global__ void backsolve_kernel(DevSymbolic S, const int* ids, const double* ar
           else if (lane < c) yr -= tile[c][lane] * xc;
         }
       }
-      if (lane < w) {
-        xs[c0 + lane] = yr;
-        delta[gi[c0 + lane]] = yr;
-        if (!isfinite(yr)) atomicAdd(&status->n_nonfinite, 1);
-      }
+      if (lane < w) xs[c0 + lane] = yr;
     }
-    __syncthreads();
+    lds_barrier();
   }
+  // the frontal part of the solution goes out once, coalesced, off the chain of panels
+  int bad = 0;
+  for (int r = tid; r < F; r += nt) {
+    const double x = xs[r];
+    delta[gi[r]] = x;
+    if (!isfinite(x)) bad = 1;
+  }
+  if (bad) atomicAdd(&status->n_nonfinite, 1);
 }
 // (A thread-per-column, right-looking variant for big fronts — separator part first, panel rows prefetched into
 //  registers two panels ahead — was built and measured: 36-65 us per level against 25-39 us for the kernel above.)
