@@ -197,14 +197,17 @@ def test_step_parity_with_relaxed_amalgamation(gpu, oracle, name, relax, maxf):
 
 @pytest.mark.parametrize("name", ["bal_small", "bal_bigfront", "pose2", "pose3"])
 @pytest.mark.parametrize("preset", ["legacy", "ceres"])
-def test_lm_trajectory_parity(gpu, oracle, name, preset):
-    """Same accept/reject decisions and the same (error, lambda) trace as the oracle; final chi^2 within 1e-6."""
+@pytest.mark.parametrize("relax", [0.0, 0.5])
+def test_lm_trajectory_parity(gpu, oracle, name, preset, relax):
+    """Same accept/reject decisions and the same (error, lambda) trace as the oracle; final chi^2 within 1e-6 — with
+    the reference's cliques and with relaxed amalgamation (the oracle always eliminates the reference tree)."""
     arr = PROBLEMS[name]
     p = A.lm_params_legacy() if preset == "legacy" else A.lm_params_ceres()
     p.max_iterations = 12
     gb = gpu.product_backend(arr)
     ob = oracle.oracle_backend(arr)
     ordering = gb.compute_ordering(A.ORDER_MINDEGREE)
+    gb.set_amalgamation(relax, 128)
     gb.set_ordering(ordering)
     ob.set_ordering(ordering)
     rg, ro = gb.lm_optimize(p), ob.lm_optimize(p)
