@@ -131,7 +131,7 @@ struct gsx_context {
   double* h_scalars = nullptr;  // pinned
   DevStatus* h_status = nullptr;
   static constexpr int kPartials = 4096;
-  bool values_set = false, linearized = false, h_ready = false, solved = false, damp_ready = false;
+  bool values_set = false, linearized = false, h_ready = false, hdiag_ready = false, solved = false, damp_ready = false;
   int damp_kind = -1;
   double damp_min = 0, damp_max = 0;
   // LM state
@@ -536,13 +536,20 @@ void dev_assemble_h(gsx_context* c) {
   for (const auto& g : c->hgroups)
     launch_assemble_h_group(c->DP, c->DS, c->d_hvars.p + g.begin, g.count, g.threads, g.lds, g.global, c->d_jac.p,
                             c->d_H.p, c->stream);
-  launch_hessian_diag(c->DP, c->DS, c->d_H.p, c->d_hdiag.p, c->stream);
   timer_end(c, PH_ASSEMBLE_H);
   c->h_ready = true;
+  c->hdiag_ready = false;  // diag(H) is extracted on demand: lambda * I damping never needs it
+}
+
+void dev_hessian_diag(gsx_context* c) {
+  if (c->hdiag_ready) return;
+  launch_hessian_diag(c->DP, c->DS, c->d_H.p, c->d_hdiag.p, c->stream);
+  c->hdiag_ready = true;
 }
 
 void dev_damping(gsx_context* c, int diagonal, double mind, double maxd) {
   if (c->damp_ready && c->damp_kind == diagonal && c->damp_min == mind && c->damp_max == maxd) return;
+  if (diagonal) dev_hessian_diag(c);
   launch_make_damping((int)c->P.tan_size, c->d_hdiag.p, diagonal, mind, maxd, c->d_damp.p, c->stream);
   c->damp_ready = true;
   c->damp_kind = diagonal;
@@ -1009,6 +1016,7 @@ gsx_status gsx_hessian_diagonal(gsx_handle h, double* out, int64_t n) {
   }
   hipSetDevice(h->device);
   if (!h->h_ready) dev_assemble_h(h);
+  dev_hessian_diag(h);
   if (n > 0) {
     HIPCHK(h, hipMemcpyAsync(out, h->d_hdiag.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
