@@ -221,10 +221,12 @@ def test_lm_trajectory_parity(gpu, oracle, name, preset, relax):
 
 
 # ---- the reference's own known-answer tests through the HIP path --------------------------------------------------
-def test_PinholeCamera_BAL(gpu, golden_dir):
-    """tests/testGeneralSFMFactorB.cpp:44-63: dubrovnik-3-7-pre, default LM -> graph.error = 0.0199833 +- 1e-5."""
-    sfm = datasets.read_bal(golden_dir + "/dubrovnik-3-7-pre.txt")
-    arrays = datasets.bal_arrays(sfm, priors=False)
+@pytest.mark.parametrize("reader", ["python", "native"])
+def test_PinholeCamera_BAL(gpu, golden_dir, reader):
+    """tests/testGeneralSFMFactorB.cpp:44-63: dubrovnik-3-7-pre, default LM -> graph.error = 0.0199833 +- 1e-5 (file
+    read by the Python reader and by the native gsx_read_bal)."""
+    path = golden_dir + "/dubrovnik-3-7-pre.txt"
+    arrays = datasets.bal_arrays(datasets.read_bal(path), priors=False) if reader == "python" else gpu.read_bal(path)
     be = gpu.product_backend(arrays)
     be.set_ordering(np.load(golden_dir + "/dubrovnik_colamd_ordering.npy"))  # the reference's CCOLAMD result
     res = be.lm_optimize(A.lm_params_legacy())

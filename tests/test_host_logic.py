@@ -196,10 +196,12 @@ def test_datasets_roundtrip_g2o(tmp_path, golden_dir):
         assert np.allclose(arr.meas, arr2.meas, atol=1e-9)
 
 
-def test_pose3example_oracle_gn_converges(oracle, golden_dir):
-    """examples/Pose3SLAMExample_g2o.cpp on examples/Data/pose3example.txt (oracle, CPU): the error must
-    drop monotonically under Gauss-Newton with the anchoring prior."""
-    arr = datasets.read_g2o(os.path.join(golden_dir, "pose3example.txt"), is3D=True)
+@pytest.mark.parametrize("reader", ["python", "native"])
+def test_pose3example_oracle_gn_converges(oracle, golden_dir, reader):
+    """examples/Pose3SLAMExample_g2o.cpp on examples/Data/pose3example.txt (oracle, CPU), read by the Python reader
+    and by the native one (gsx_read_g2o): the reference's printed errors."""
+    path = os.path.join(golden_dir, "pose3example.txt")
+    arr = datasets.read_g2o(path, is3D=True) if reader == "python" else _lib.read_g2o(path, True)
     ob = oracle.oracle_backend(arr)
     ob.set_ordering(arr.var_keys if not oracle.have_ref_colamd() else oracle.colamd_ordering(arr))
     r = ob.gn_optimize(100)
