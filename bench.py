@@ -44,6 +44,9 @@ def parse():
                          "reference's cliques")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the N>1 path on a box "
+                         "with fewer GPUs than ranks)")
     return ap.parse_args()
 
 
@@ -130,12 +133,15 @@ def main():
     import torch
     from gtsam_petercdev_amd import _abi as A, _lib, distributed as D
     dist = None
+    ndev = max(torch.cuda.device_count(), 1)
+    device = local_rank % ndev  # == local_rank on a node with one GPU per rank
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist = D.init("nccl", torch.device("cuda", local_rank))
+        torch.cuda.set_device(device)
+        dist = D.init(args.backend, torch.device("cuda", device) if args.backend == "nccl" else None)
+    red_dev = "cuda" if (dist is not None and args.backend == "nccl") else "cpu"
 
     arrays, default_order = make_problem(args.workload, seed=D.replica_seed(42))
-    be = _lib.product_backend(arrays, device=local_rank)
+    be = _lib.product_backend(arrays, device=device)
     okind = {"schur": A.ORDER_SCHUR, "schur_nd": A.ORDER_SCHUR_ND, "mindegree": A.ORDER_MINDEGREE,
              "nd": A.ORDER_ND}[args.ordering or default_order]
     t0 = time.time()
@@ -172,7 +178,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    value, ms_step = D.aggregate_throughput(dist, args.steps, elapsed, device="cuda" if dist is not None else "cpu")
+    value, ms_step = D.aggregate_throughput(dist, args.steps, elapsed, device=red_dev)
     st = be.stats()
     ms_solve = (st["ms_factorize"] + st["ms_backsolve"]) / max(st["n_factorize"], 1)
 
