@@ -136,3 +136,27 @@ def test_full_size_properties(gpu, name):
     r = gb.lm_optimize(p)
     acc = r["trace_error"][r["trace_accepted"] == 1]
     assert acc.size >= 1 and np.all(np.diff(np.concatenate([[r["initial_error"]], acc])) < 0)
+
+
+@pytest.mark.parametrize("name", ["bal1723", "pose3_100k"])
+def test_full_size_lm_run_matches_oracle(gpu, oracle, name):
+    """north star: the LM run itself — same accept/reject decisions, same lambda schedule, final chi^2 within 1e-6 of the
+    reference algorithm — at BASELINE's full sizes, in the configuration bench.py times (relaxed amalgamation on the
+    device, the reference's cliques in the oracle)."""
+    build, kind, relax, maxf = BENCH_CONFIGS[name]
+    arr = build()
+    gb = gpu.product_backend(arr)
+    ob = oracle.oracle_backend(arr)
+    ordering = gb.compute_ordering(kind)
+    gb.set_amalgamation(relax, maxf)
+    gb.set_ordering(ordering)
+    ob.set_ordering(ordering)
+    p = A.lm_params_legacy()
+    p.max_iterations = 6
+    rg, ro = gb.lm_optimize(p), ob.lm_optimize(p)
+    assert rg["iterations"] == ro["iterations"] and rg["inner_iterations"] == ro["inner_iterations"]
+    assert np.array_equal(rg["trace_accepted"], ro["trace_accepted"])
+    assert np.allclose(rg["trace_lambda"], ro["trace_lambda"], rtol=1e-9)
+    assert abs(rg["final_error"] - ro["final_error"]) <= 1e-6 * ro["final_error"]
+    assert rg["final_error"] < rg["initial_error"]
+    assert relerr(gb.get_values(), ob.get_values()) < 1e-6
