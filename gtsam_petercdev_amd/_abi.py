@@ -351,6 +351,18 @@ class Backend:
         self._check(self._fn("lm_iterate")(self._h, C.byref(params), C.byref(e), C.byref(l)), "lm_iterate")
         return e.value, l.value
 
+    def dogleg_optimize(self, delta_initial=1.0, max_iterations=100, relative_error_tol=1e-5, absolute_error_tol=1e-5,
+                        error_tol=0.0, trace_cap=4096):
+        """DoglegOptimizer (ONE_STEP_PER_ITERATION); trace_lambda / final_lambda carry the trust-region radius."""
+        r, tr = self._result(trace_cap)
+        st = self._fn("dogleg_optimize")(self._h, C.c_double(delta_initial), C.c_int32(max_iterations),
+                                         C.c_double(relative_error_tol), C.c_double(absolute_error_tol),
+                                         C.c_double(error_tol), C.byref(r))
+        if st == GSX_E_INDETERMINATE:
+            raise IndeterminantLinearSystemException(0, self._pfx + "dogleg_optimize")
+        self._check(st, "dogleg_optimize")
+        return self._result_dict(r, tr)
+
     def gn_optimize(self, max_iterations=100, relative_error_tol=1e-5, absolute_error_tol=1e-5, error_tol=0.0,
                     trace_cap=4096):
         r, tr = self._result(trace_cap)

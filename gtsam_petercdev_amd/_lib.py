@@ -120,5 +120,19 @@ def read_bal(path: str, priors: bool = False) -> A.ProblemArrays:
     return _dataset_to_arrays(ds, dict(kind="bal", source=str(path)))
 
 
+def dogleg_point(delta: float, dx_u, dx_n) -> np.ndarray:
+    """DoglegOptimizerImpl::ComputeDoglegPoint (gsx_dogleg_point, host)."""
+    u = np.ascontiguousarray(dx_u, dtype=np.float64)
+    n = np.ascontiguousarray(dx_n, dtype=np.float64)
+    out = np.zeros_like(u)
+    f = load().gsx_dogleg_point
+    f.restype = C.c_int32
+    st = f(C.c_double(delta), u.ctypes.data_as(C.POINTER(C.c_double)), n.ctypes.data_as(C.POINTER(C.c_double)),
+           C.c_int64(u.size), out.ctypes.data_as(C.POINTER(C.c_double)))
+    if st != A.GSX_OK:
+        raise A.GsxError(st, "gsx_dogleg_point", "")
+    return out
+
+
 def product_backend(arrays: A.ProblemArrays, device: int = 0) -> ProductBackend:
     return ProductBackend(arrays, device)

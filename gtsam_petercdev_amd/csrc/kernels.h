@@ -70,7 +70,8 @@ struct DevStatus {
 };
 
 // scalar slots in the device scalar buffer
-enum { SC_LAMBDA = 0, SC_ERR = 1, SC_LIN0 = 2, SC_LIND = 3, SC_TRIAL_ERR = 4, SC_COUNT = 8 };
+enum { SC_LAMBDA = 0, SC_ERR = 1, SC_LIN0 = 2, SC_LIND = 3, SC_TRIAL_ERR = 4, SC_DOT0 = 5, SC_DOT1 = 6, SC_DOT2 = 7,
+       SC_DOT3 = 8, SC_COUNT = 12 };
 
 struct BigDesc {   // one big front of a level
   i64 off, xoff;             // arena offsets of the n x n front and of its n x F L-panel area
@@ -133,6 +134,14 @@ void launch_backsolve(const DevSymbolic& S, const int* ids, int count, int threa
 // leaf cliques of a level, a wave per clique
 void launch_backsolve_leaf(const DevSymbolic& S, const LeafRec* recs, int count, const double* arena, double* delta,
                            DevStatus* status, hipStream_t st);
+// Dogleg (gtsam/nonlinear/DoglegOptimizerImpl.*): gradient g = A'b out of the H panels' rhs rows, |A x|^2 over the
+// linearized graph, dot products and out = alpha a + beta b on tangent vectors (deterministic two-stage reductions)
+void launch_gradient(const DevProblem& P, const DevSymbolic& S, const double* H, double* g, hipStream_t st);
+void launch_ax_sqnorm(const DevProblem& P, const double* jac, const double* x, double* partials, int cap, double* scalars,
+                      int slot, hipStream_t st);
+void launch_vec_dot(const double* a, const double* b, int64_t n, double* partials, int cap, double* scalars, int slot,
+                    hipStream_t st);
+void launch_vec_axpby(double* out, double alpha, const double* a, double beta, const double* b, int64_t n, hipStream_t st);
 void launch_set_scalar(double* scalars, int slot, double v, hipStream_t st);
 void launch_begin_factorization(double* scalars, double lambda, DevStatus* status, hipStream_t st);
 // dense unit kernel for gsx_cholesky_partial: in-place lower partial Cholesky of an n x n

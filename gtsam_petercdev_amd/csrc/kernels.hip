@@ -662,6 +662,65 @@ void launch_make_damping(int n, const double* hdiag, int diagonal, double mind, 
   if (n) make_damping_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, hdiag, diagonal, mind, maxd, damp);
 }
 
+// ---- Dogleg helpers -------------------------------------------------------------------------------------------
+__global__ void gradient_kernel(DevProblem P, DevSymbolic S, const double* H, double* g) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= P.n_vars) return;
+  const int d = P.var_dim[v], rows = S.h_rows[v];
+  const double* p = H + S.h_off[v];
+  for (int k = 0; k < d; ++k) g[P.var_tan_off[v] + k] = p[(rows - 1) + k * rows];  // rhs row of the panel = (A'b)_v
+}
+void launch_gradient(const DevProblem& P, const DevSymbolic& S, const double* H, double* g, hipStream_t st) {
+  gradient_kernel<<<(P.n_vars + 255) / 256, 256, 0, st>>>(P, S, H, g);
+}
+__global__ void __launch_bounds__(256) ax_sqnorm_kernel(DevProblem P, const double* jac, const double* xv, double* partials) {
+  double acc = 0;
+  for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < P.n_factors; f += gridDim.x * blockDim.x) {
+    const int m = P.f_rows[f];
+    const double* J = jac + P.f_jac_off[f];
+    for (int r = 0; r < m; ++r) {
+      double e = 0;
+      int col = 0;
+      for (int k = P.f_key_ptr[f]; k < P.f_key_ptr[f + 1]; ++k) {
+        const int v = P.f_vars[k];
+        const double* x = xv + P.var_tan_off[v];
+        const int d = P.var_dim[v];
+        for (int c = 0; c < d; ++c, ++col) e += J[col * m + r] * x[c];
+      }
+      acc += e * e;
+    }
+  }
+  const double s = block_sum(acc);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+void launch_ax_sqnorm(const DevProblem& P, const double* jac, const double* x, double* partials, int cap, double* scalars,
+                      int slot, hipStream_t st) {
+  int nb = (P.n_factors + 255) / 256;
+  nb = nb < 1 ? 1 : (nb > cap ? cap : nb);
+  ax_sqnorm_kernel<<<nb, 256, 0, st>>>(P, jac, x, partials);
+  reduce_final_kernel<<<1, 256, 0, st>>>(partials, nb, 1, scalars, slot);
+}
+__global__ void __launch_bounds__(256) vec_dot_kernel(const double* a, const double* b, i64 n, double* partials) {
+  double acc = 0;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) acc += a[i] * b[i];
+  const double s = block_sum(acc);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+void launch_vec_dot(const double* a, const double* b, int64_t n, double* partials, int cap, double* scalars, int slot,
+                    hipStream_t st) {
+  int nb = (int)((n + 1023) / 1024);
+  nb = nb < 1 ? 1 : (nb > cap ? cap : nb);
+  vec_dot_kernel<<<nb, 256, 0, st>>>(a, b, n, partials);
+  reduce_final_kernel<<<1, 256, 0, st>>>(partials, nb, 1, scalars, slot);
+}
+__global__ void vec_axpby_kernel(double* out, double alpha, const double* a, double beta, const double* b, i64 n) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = alpha * a[i] + beta * b[i];
+}
+void launch_vec_axpby(double* out, double alpha, const double* a, double beta, const double* b, int64_t n, hipStream_t st) {
+  if (n > 0) vec_axpby_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(out, alpha, a, beta, b, n);
+}
+
 __global__ void set_scalar_kernel(double* scalars, int slot, double v) { scalars[slot] = v; }
 void launch_set_scalar(double* scalars, int slot, double v, hipStream_t st) {
   set_scalar_kernel<<<1, 1, 0, st>>>(scalars, slot, v);

@@ -127,6 +127,7 @@ struct gsx_context {
   std::vector<HGroup> hgroups;
   // numeric buffers
   DevBuf<double> d_values, d_trial, d_delta, d_udelta, d_jac, d_H, d_arena, d_hdiag, d_damp, d_partials, d_scalars;
+  DevBuf<double> d_dlu, d_dld;  // Dogleg: steepest-descent point, dog-leg point (allocated on first use)
   DevBuf<DevStatus> d_status;
   double* h_scalars = nullptr;  // pinned
   DevStatus* h_status = nullptr;
@@ -1213,6 +1214,148 @@ gsx_status gsx_gn_optimize(gsx_handle h, int32_t max_iterations, double relTol, 
   if (r) {
     r->final_error = h->lm_error;
     r->final_lambda = 0;
+    r->iterations = h->lm_iterations;
+    r->inner_iterations = h->lm_iterations;
+  }
+  return GSX_OK;
+}
+
+// DoglegOptimizerImpl::ComputeDoglegPoint coefficients: dx_d = cu dx_u + cn dx_n  (DoglegOptimizerImpl.cpp:26-86)
+static void dogleg_coefficients(double delta, double uu, double nn, double un, double* cu, double* cn) {
+  const double deltaSq = delta * delta;
+  if (deltaSq < uu) {
+    *cu = std::sqrt(deltaSq / uu);
+    *cn = 0.0;
+  } else if (deltaSq < nn) {
+    const double a = uu - 2. * un + nn, b = 2. * (un - uu), c = uu - deltaSq;
+    const double sq = std::sqrt(b * b - 4 * a * c);
+    const double tau1 = (-b + sq) / (2. * a), tau2 = (-b - sq) / (2. * a);
+    const double eps = std::numeric_limits<double>::epsilon();
+    const double tau = (-eps <= tau1 && tau1 <= 1.0 + eps) ? tau1 : tau2;
+    *cu = 1. - tau;
+    *cn = tau;
+  } else {
+    *cu = 0.0;
+    *cn = 1.0;
+  }
+}
+
+gsx_status gsx_dogleg_point(double delta, const double* dx_u, const double* dx_n, int64_t n, double* out) {
+  if (!dx_u || !dx_n || !out || n < 0 || !(delta >= 0)) return GSX_E_INVALID;
+  double uu = 0, nn = 0, un = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    uu += dx_u[i] * dx_u[i];
+    nn += dx_n[i] * dx_n[i];
+    un += dx_u[i] * dx_n[i];
+  }
+  double cu, cn;
+  dogleg_coefficients(delta, uu, nn, un, &cu, &cn);
+  for (int64_t i = 0; i < n; ++i) out[i] = (cn == 0.0 ? cu * dx_u[i] : (cu == 0.0 ? dx_n[i] : cu * dx_u[i] + cn * dx_n[i]));
+  return GSX_OK;
+}
+
+// DoglegOptimizer::iterate (gtsam/nonlinear/DoglegOptimizer.cpp:84-121) with DoglegOptimizerImpl::Iterate in
+// ONE_STEP_PER_ITERATION mode (DoglegOptimizerImpl.h:137-252), inside NonlinearOptimizer::defaultOptimize.
+// The reference evaluates the model M on the Bayes tree [R S d]; M(0) - M(dx) is the same number on the linearized
+// graph it was eliminated from (the two differ by a constant), which is what the device has.
+gsx_status gsx_dogleg_optimize(gsx_handle h, double delta_initial, int32_t max_iterations, double relTol, double absTol,
+                               double errTol, gsx_lm_result* r) {
+  if (!h || !(delta_initial >= 0)) return GSX_E_INVALID;
+  gsx_status st = ensure_ready(h, true, true);
+  if (st != GSX_OK) return st;
+  hipSetDevice(h->device);
+  const int64_t nt = h->P.tan_size;
+  if (!h->d_dlu.p) {
+    HIPCHK(h, h->d_dlu.alloc(std::max<int64_t>(nt, 1)));
+    HIPCHK(h, h->d_dld.alloc(std::max<int64_t>(nt, 1)));
+  }
+  st = compute_error_sync(h, &h->lm_error);
+  if (st != GSX_OK) return st;
+  h->lm_iterations = 0;
+  double delta = delta_initial;
+  Trace tr{r};
+  if (r) {
+    r->initial_error = h->lm_error;
+    r->trace_len = 0;
+    r->n_solve_failures = 0;
+  }
+  double currentError = h->lm_error;
+  if (!(currentError <= errTol) && max_iterations > 0) {
+    double newError = currentError;
+    do {
+      currentError = newError;
+      dev_linearize(h);
+      dev_assemble_h(h);
+      dev_damping(h, 0, 0, 0);
+      dev_factorize(h, 0.0);
+      dev_backsolve(h);  // d_delta = Newton point dx_n
+      // steepest-descent point: grad = -A'b = -g, dx_u = -(grad'grad / |A grad|^2) grad = (g'g / |A g|^2) g
+      launch_gradient(h->DP, h->DS, h->d_H.p, h->d_dlu.p, h->stream);
+      launch_vec_dot(h->d_dlu.p, h->d_dlu.p, nt, h->d_partials.p, gsx_context::kPartials, h->d_scalars.p, SC_DOT0, h->stream);
+      launch_ax_sqnorm(h->DP, h->d_jac.p, h->d_dlu.p, h->d_partials.p, gsx_context::kPartials, h->d_scalars.p, SC_DOT1,
+                       h->stream);
+      launch_vec_dot(h->d_delta.p, h->d_delta.p, nt, h->d_partials.p, gsx_context::kPartials, h->d_scalars.p, SC_DOT2,
+                     h->stream);
+      launch_vec_dot(h->d_dlu.p, h->d_delta.p, nt, h->d_partials.p, gsx_context::kPartials, h->d_scalars.p, SC_DOT3,
+                     h->stream);
+      st = readback(h);
+      if (st != GSX_OK) return st;
+      if (h->h_status->n_fail > 0 || h->h_status->n_nonfinite > 0) {
+        h->err = "indeterminate linear system";
+        return GSX_E_INDETERMINATE;
+      }
+      const double gg = h->h_scalars[SC_DOT0], ag2 = h->h_scalars[SC_DOT1];
+      const double step = gg / ag2;
+      const double uu = step * step * gg, nn = h->h_scalars[SC_DOT2], un = step * h->h_scalars[SC_DOT3];
+      const double f_error = h->lm_error;
+      double result_f = f_error, cu = 0, cn = 0;
+      bool stay = true, zero_step = false;
+      while (stay) {
+        dogleg_coefficients(delta, uu, nn, un, &cu, &cn);
+        launch_vec_axpby(h->d_dld.p, cu * step, h->d_dlu.p, cn, h->d_delta.p, nt, h->stream);  // dx_d (d_dlu holds g)
+        dev_retract(h, h->d_dld.p);
+        dev_error(h, h->d_trial.p, SC_TRIAL_ERR);
+        launch_linear_error(h->DP, h->d_jac.p, h->d_dld.p, h->d_partials.p, gsx_context::kPartials, h->d_scalars.p,
+                            h->stream);
+        st = readback(h);
+        if (st != GSX_OK) return st;
+        result_f = h->h_scalars[SC_TRIAL_ERR];
+        const double M_error = h->h_scalars[SC_LIN0], new_M = h->h_scalars[SC_LIND];
+        const double rho = (std::abs(f_error - result_f) < 1e-15 || std::abs(M_error - new_M) < 1e-15)
+                               ? 0.5
+                               : (f_error - result_f) / (M_error - new_M);
+        if (rho >= 0.75) {
+          const double dnorm = std::sqrt(cu * cu * uu + 2 * cu * cn * un + cn * cn * nn);
+          delta = std::max(delta, 3.0 * dnorm);
+          stay = false;
+        } else if (rho >= 0.25) {
+          stay = false;
+        } else if (rho >= 0.0) {
+          if (delta > 1e-5) delta *= 0.5;
+          stay = false;
+        } else {  // f increased (NaN lands here too): shrink the region until it does not
+          if (delta > 1e-5) {
+            delta *= 0.5;
+            stay = true;
+          } else {
+            zero_step = true;  // do not allow the error to increase
+            result_f = f_error;
+            stay = false;
+          }
+        }
+      }
+      if (!zero_step) std::swap(h->d_values.p, h->d_trial.p);
+      h->linearized = h->h_ready = h->solved = false;
+      h->lm_error = result_f;
+      h->lm_iterations++;
+      newError = h->lm_error;
+      tr.push(newError, delta, 1);  // the trace's "lambda" column carries the trust-region radius
+    } while (h->lm_iterations < max_iterations && !check_convergence(relTol, absTol, errTol, currentError, newError) &&
+             std::isfinite(currentError));
+  }
+  if (r) {
+    r->final_error = h->lm_error;
+    r->final_lambda = delta;
     r->iterations = h->lm_iterations;
     r->inner_iterations = h->lm_iterations;
   }

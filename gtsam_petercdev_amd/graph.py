@@ -613,6 +613,22 @@ class LevenbergMarquardtOptimizer(_OptimizerBase):
         return self._lambda
 
 
+class DoglegOptimizer(_OptimizerBase):
+    """gtsam/nonlinear/DoglegOptimizer.h: DoglegParams::deltaInitial = 1.0, NonlinearOptimizerParams defaults."""
+
+    def __init__(self, graph, initialValues, ordering=None, deltaInitial=1.0, maxIterations=100, relativeErrorTol=1e-5,
+                 absoluteErrorTol=1e-5, errorTol=0.0, backend_factory=None, ordering_fn=None, orderingType="COLAMD"):
+        super().__init__(graph, initialValues, ordering, orderingType, backend_factory, ordering_fn)
+        self._p = (deltaInitial, maxIterations, relativeErrorTol, absoluteErrorTol, errorTol)
+
+    def optimize(self) -> Values:
+        self.result = self.backend.dogleg_optimize(*self._p)
+        return self.values()
+
+    def getDelta(self) -> float:
+        return float(self.result["final_lambda"])
+
+
 class GaussNewtonOptimizer(_OptimizerBase):
     def __init__(self, graph, initialValues, ordering=None, maxIterations=100, relativeErrorTol=1e-5,
                  absoluteErrorTol=1e-5, errorTol=0.0, backend_factory=None, ordering_fn=None, orderingType="COLAMD"):

@@ -287,6 +287,13 @@ gsx_status gsx_lm_iterate(gsx_handle h, const gsx_lm_params* p, double* error,
                           double* lambda);
 gsx_status gsx_gn_optimize(gsx_handle h, int32_t max_iterations, double relative_error_tol,
                            double absolute_error_tol, double error_tol, gsx_lm_result* r);
+/* DoglegOptimizer (gtsam/nonlinear/DoglegOptimizer.cpp:84-121; DoglegOptimizerImpl::Iterate in
+ * ONE_STEP_PER_ITERATION mode, DoglegOptimizerImpl.h:137-252) on the same kernels.  The result's
+ * final_lambda / trace_lambda carry the trust-region radius delta.  DoglegParams::deltaInitial = 1.0. */
+gsx_status gsx_dogleg_optimize(gsx_handle h, double delta_initial, int32_t max_iterations, double relative_error_tol,
+                               double absolute_error_tol, double error_tol, gsx_lm_result* result);
+/* DoglegOptimizerImpl::ComputeDoglegPoint (DoglegOptimizerImpl.cpp:26-86) on plain vectors (host). */
+gsx_status gsx_dogleg_point(double delta, const double* dx_u, const double* dx_n, int64_t n, double* out);
 
 /* ---- the linear seam (NonlinearOptimizer::solve override) ------------------- */
 /* desc must contain only GSX_F_LINEAR factors and GSX_VAR_VECTOR variables;

@@ -946,6 +946,161 @@ static void gn_optimize(Problem& P, int maxIter, double relTol, double absTol, d
   }
 }
 
+// ---------------------------------------------------------------------------
+// Dogleg — gtsam/nonlinear/DoglegOptimizer.cpp:84-121, DoglegOptimizerImpl.h:137-252, DoglegOptimizerImpl.cpp:26-86.
+// The Bayes tree of the undamped linearization is used the way the reference uses it: as a GaussianFactorGraph of
+// its conditionals (GaussianBayesTree.cpp:73-91), every conditional one unit-noise Jacobian row block [R S | d].
+// ---------------------------------------------------------------------------
+static void bt_row_block(const Problem& P, const Conditional& cd, const double* x, Vec& out) {  // [R S] x
+  out.assign(cd.nf, 0.0);
+  int col = 0;
+  auto add = [&](int v) {
+    const double* xv = x + P.tan_off[v];
+    for (int c = 0; c < P.dims[v]; ++c, ++col)
+      for (int r = 0; r < cd.nf; ++r) out[r] += cd.RSd[(size_t)col * cd.nf + r] * xv[c];
+  };
+  for (int v : cd.frontals) add(v);
+  for (int v : cd.parents) add(v);
+}
+static double bt_error(const Problem& P, const double* x) {  // GaussianFactorGraph::error of the conditionals
+  double total = 0;
+  Vec e;
+  for (const Conditional& cd : P.bayes_tree) {
+    bt_row_block(P, cd, x, e);
+    double s = 0;
+    for (int r = 0; r < cd.nf; ++r) {
+      const double d = e[r] - cd.RSd[(size_t)(cd.ncols - 1) * cd.nf + r];
+      s += d * d;
+    }
+    total += 0.5 * s;
+  }
+  return total;
+}
+static void bt_gradient_at_zero(const Problem& P, Vec& g) {  // -sum [R S]' d  (GaussianFactorGraph.cpp:360-378)
+  g.assign(P.tan_size, 0.0);
+  for (const Conditional& cd : P.bayes_tree) {
+    const double* d = &cd.RSd[(size_t)(cd.ncols - 1) * cd.nf];
+    int col = 0;
+    auto add = [&](int v) {
+      double* gv = g.data() + P.tan_off[v];
+      for (int c = 0; c < P.dims[v]; ++c, ++col)
+        for (int r = 0; r < cd.nf; ++r) gv[c] -= cd.RSd[(size_t)col * cd.nf + r] * d[r];
+    };
+    for (int v : cd.frontals) add(v);
+    for (int v : cd.parents) add(v);
+  }
+}
+static double vdot(const Vec& a, const Vec& b) {
+  double s = 0;
+  for (size_t i = 0; i < a.size(); ++i) s += a[i] * b[i];
+  return s;
+}
+// DoglegOptimizerImpl::ComputeBlend — DoglegOptimizerImpl.cpp:54-86
+static void compute_blend(double delta, const Vec& xu, const Vec& xn, Vec& out) {
+  const double un = vdot(xu, xn), uu = vdot(xu, xu), nn = vdot(xn, xn);
+  const double a = uu - 2. * un + nn, b = 2. * (un - uu), c = uu - delta * delta;
+  const double sq = std::sqrt(b * b - 4 * a * c);
+  const double tau1 = (-b + sq) / (2. * a), tau2 = (-b - sq) / (2. * a);
+  const double eps = std::numeric_limits<double>::epsilon();
+  const double tau = (-eps <= tau1 && tau1 <= 1.0 + eps) ? tau1 : tau2;
+  out.resize(xu.size());
+  for (size_t i = 0; i < xu.size(); ++i) out[i] = (1. - tau) * xu[i] + tau * xn[i];
+}
+// DoglegOptimizerImpl::ComputeDoglegPoint — DoglegOptimizerImpl.cpp:26-51
+static void compute_dogleg_point(double delta, const Vec& xu, const Vec& xn, Vec& out) {
+  const double deltaSq = delta * delta, uu = vdot(xu, xu), nn = vdot(xn, xn);
+  if (deltaSq < uu) {
+    const double f = std::sqrt(deltaSq / uu);
+    out.resize(xu.size());
+    for (size_t i = 0; i < xu.size(); ++i) out[i] = f * xu[i];
+  } else if (deltaSq < nn) {
+    compute_blend(delta, xu, xn, out);
+  } else {
+    out = xn;
+  }
+}
+// DoglegOptimizer::iterate with ONE_STEP_PER_ITERATION + NonlinearOptimizer::defaultOptimize
+static void dogleg_optimize(Problem& P, double deltaInitial, int maxIter, double relTol, double absTol, double errTol,
+                            gsx_lm_result* res) {
+  P.lm_error = graph_error(P, P.values.data());
+  P.lm_iterations = 0;
+  double delta = deltaInitial;
+  LMTrace tr{res};
+  if (res) {
+    res->initial_error = P.lm_error;
+    res->trace_len = 0;
+    res->n_solve_failures = 0;
+  }
+  double currentError = P.lm_error;
+  if (!(currentError <= errTol) && maxIter > 0) {
+    double newError = currentError;
+    do {
+      currentError = newError;
+      linearize(P);
+      Vec dx_n;
+      solve_gfg(P, P.linear, dx_n);  // Bayes tree + Newton point
+      Vec dx_u;
+      bt_gradient_at_zero(P, dx_u);  // optimizeGradientSearch — GaussianFactorGraph.cpp:381-407
+      {
+        const double gg = vdot(dx_u, dx_u);
+        double rg = 0;
+        Vec e;
+        for (const Conditional& cd : P.bayes_tree) {
+          bt_row_block(P, cd, dx_u.data(), e);
+          for (double q : e) rg += q * q;
+        }
+        const double step = -gg / rg;
+        for (double& q : dx_u) q *= step;
+      }
+      const double f_error = P.lm_error;
+      Vec zero(P.tan_size, 0.0), dx_d, nv(P.state_size);
+      const double M_error = bt_error(P, zero.data());
+      double result_f = f_error;
+      bool stay = true;
+      while (stay) {  // DoglegOptimizerImpl::Iterate, mode ONE_STEP_PER_ITERATION
+        compute_dogleg_point(delta, dx_u, dx_n, dx_d);
+        retract(P, P.values.data(), dx_d.data(), nv.data());
+        result_f = graph_error(P, nv.data());
+        const double new_M = bt_error(P, dx_d.data());
+        const double rho = (std::abs(f_error - result_f) < 1e-15 || std::abs(M_error - new_M) < 1e-15)
+                               ? 0.5
+                               : (f_error - result_f) / (M_error - new_M);
+        if (rho >= 0.75) {
+          delta = std::max(delta, 3.0 * std::sqrt(vdot(dx_d, dx_d)));
+          stay = false;
+        } else if (rho >= 0.25) {
+          stay = false;
+        } else if (rho >= 0.0) {
+          if (delta > 1e-5) delta *= 0.5;
+          stay = false;
+        } else {  // f increased (also NaN): shrink until it does not
+          if (delta > 1e-5) {
+            delta *= 0.5;
+            stay = true;
+          } else {
+            std::fill(dx_d.begin(), dx_d.end(), 0.0);
+            result_f = f_error;
+            stay = false;
+          }
+        }
+      }
+      retract(P, P.values.data(), dx_d.data(), nv.data());
+      P.values = nv;
+      P.lm_error = result_f;
+      P.lm_iterations++;
+      newError = P.lm_error;
+      tr.push(newError, delta, 1);  // the trace's "lambda" column carries the trust-region radius
+    } while (P.lm_iterations < maxIter && !check_convergence(relTol, absTol, errTol, currentError, newError) &&
+             std::isfinite(currentError));
+  }
+  if (res) {
+    res->final_error = P.lm_error;
+    res->final_lambda = delta;
+    res->iterations = P.lm_iterations;
+    res->inner_iterations = P.lm_iterations;
+  }
+}
+
 static Problem* build_problem(const gsx_problem_desc* d, std::string& err) {
   auto P = std::make_unique<Problem>();
   P->n_vars = d->n_vars;
@@ -1167,6 +1322,30 @@ int orc_gn_optimize(void* h, int32_t max_iterations, double rel, double abs_, do
   } catch (const orc::IndeterminantLinearSystem&) {
     return GSX_E_INDETERMINATE;
   }
+  return GSX_OK;
+}
+int orc_dogleg_optimize(void* h, double delta_initial, int32_t max_iterations, double rel, double abs_, double errtol,
+                        gsx_lm_result* r) {
+  Problem& P = *(Problem*)h;
+  if (!P.has_ordering) return GSX_E_STATE;
+  try {
+    orc::dogleg_optimize(P, delta_initial, max_iterations, rel, abs_, errtol, r);
+  } catch (const orc::IndeterminantLinearSystem&) {
+    return GSX_E_INDETERMINATE;
+  }
+  return GSX_OK;
+}
+// DoglegOptimizerImpl::ComputeDoglegPoint on plain vectors (known-answer tests)
+int orc_dogleg_point(double delta, const double* xu, const double* xn, int64_t n, double* out) {
+  orc::Vec u(xu, xu + n), nn(xn, xn + n), o;
+  orc::compute_dogleg_point(delta, u, nn, o);
+  std::copy(o.begin(), o.end(), out);
+  return GSX_OK;
+}
+int orc_dogleg_blend(double delta, const double* xu, const double* xn, int64_t n, double* out) {
+  orc::Vec u(xu, xu + n), nn(xn, xn + n), o;
+  orc::compute_blend(delta, u, nn, o);
+  std::copy(o.begin(), o.end(), out);
   return GSX_OK;
 }
 // Bayes tree of the last solve: cliques in elimination post-order.

@@ -62,6 +62,17 @@ def oracle_backend(arrays: A.ProblemArrays, device: int = 0) -> OracleBackend:
     return OracleBackend(arrays, device)
 
 
+def dogleg_point(delta: float, dx_u, dx_n, blend_only: bool = False) -> np.ndarray:
+    """DoglegOptimizerImpl::ComputeDoglegPoint / ComputeBlend restatement on plain vectors."""
+    u = np.ascontiguousarray(dx_u, dtype=np.float64)
+    n = np.ascontiguousarray(dx_n, dtype=np.float64)
+    out = np.zeros_like(u)
+    f = load().orc_dogleg_blend if blend_only else load().orc_dogleg_point
+    f(C.c_double(delta), u.ctypes.data_as(C.POINTER(C.c_double)), n.ctypes.data_as(C.POINTER(C.c_double)),
+      C.c_int64(u.size), out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out
+
+
 def cholesky_partial(abc: np.ndarray, nfrontal: int):
     """gtsam::choleskyPartial restatement on a (n,n) array (upper triangle significant)."""
     n = abc.shape[0]

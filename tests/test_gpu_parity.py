@@ -400,3 +400,34 @@ def test_bad_ordering_is_rejected(gpu):
     bad[0] = bad[1]
     with pytest.raises(gt.GsxError):
         be.set_ordering(bad)
+
+
+# ---- Dogleg (gsx_dogleg_optimize) -----------------------------------------------------------------------------
+def test_dogleg_point_matches_the_oracle(gpu, oracle):
+    """gsx_dogleg_point (host) against the oracle's restatement of ComputeDoglegPoint in its three regimes + edges."""
+    rng = np.random.default_rng(3)
+    for n in (3, 10, 1000):
+        xn = rng.normal(size=n)
+        xu = 0.3 * xn + 0.05 * rng.normal(size=n)
+        for delta in (0.1 * np.linalg.norm(xu), 0.5 * (np.linalg.norm(xu) + np.linalg.norm(xn)), 2 * np.linalg.norm(xn),
+                      np.linalg.norm(xu), np.linalg.norm(xn)):
+            assert np.allclose(gpu.dogleg_point(delta, xu, xn), oracle.dogleg_point(delta, xu, xn), rtol=1e-12, atol=1e-14)
+
+
+@pytest.mark.parametrize("name", ["bal_small", "bal_bigfront", "pose2", "pose3"])
+@pytest.mark.parametrize("delta0", [1.0, 0.05])
+def test_dogleg_trajectory_parity(gpu, oracle, name, delta0):
+    """DoglegOptimizer on the device against the oracle: same trust-region schedule, errors within 1e-6."""
+    arr = PROBLEMS[name]
+    gb = gpu.product_backend(arr)
+    ob = oracle.oracle_backend(arr)
+    ordering = gb.compute_ordering(A.ORDER_MINDEGREE)
+    gb.set_ordering(ordering)
+    ob.set_ordering(ordering)
+    rg, ro = gb.dogleg_optimize(delta0, 10), ob.dogleg_optimize(delta0, 10)
+    assert rg["iterations"] == ro["iterations"]
+    assert np.allclose(rg["trace_lambda"], ro["trace_lambda"], rtol=1e-6)   # the trust-region radius
+    assert np.allclose(rg["trace_error"], ro["trace_error"], rtol=1e-6)
+    assert abs(rg["final_error"] - ro["final_error"]) <= 1e-6 * max(ro["final_error"], 1e-12)
+    assert rg["final_error"] < rg["initial_error"]
+    assert relerr(gb.get_values(), ob.get_values()) < 1e-6

@@ -422,3 +422,63 @@ def test_colamd_chain(orc):
     cm[[2, 4]] = 1
     cm[5] = 2
     assert orc.colamd_ordering(arrays, cm).tolist() == [0, 1, 3, 2, 4, 5]
+
+
+# ---- tests/testDoglegOptimizer.cpp ---------------------------------------------------------------------
+def test_Dogleg_ComputeBlendEdgeCases(orc):
+    """:76-92 (issue #1861) — a trust region equal to |n| returns n, equal to |u| returns u."""
+    n = np.array([0.3233546123, -0.2133456123, 0.3664345632])
+    u = np.array([0.0023456342, -0.04535687, 0.087345661212])
+    assert np.allclose(orc.dogleg_point(np.linalg.norm(n), u, n, blend_only=True), n, atol=1e-9)
+    assert np.allclose(orc.dogleg_point(np.linalg.norm(u), u, n, blend_only=True), u, atol=1e-9)
+
+
+def _dogleg_bayes_net_points(orc):
+    """The Bayes net of :42-62 / :97-113 as a linear graph of unit-noise rows [R S | d]: its steepest-descent point
+    (GaussianFactorGraph::optimizeGradientSearch) and Newton point, in key order 0..4 (2 dims each)."""
+    rows = [  # (keys, blocks, d)
+        ((0, 3, 4), ([[3, 4], [0, 6]], [[7, 8], [9, 10]], [[11, 12], [13, 14]]), (1, 2)),
+        ((1, 2, 4), ([[17, 18], [0, 20]], [[21, 22], [23, 24]], [[25, 26], [27, 28]]), (15, 16)),
+        ((2, 3), ([[31, 32], [0, 34]], [[35, 36], [37, 38]]), (29, 30)),
+        ((3, 4), ([[41, 42], [0, 44]], [[45, 46], [47, 48]]), (39, 40)),
+        ((4,), ([[51, 52], [0, 54]],), (49, 50)),
+    ]
+    A_ = np.zeros((10, 10))
+    b = np.zeros(10)
+    for i, (keys, blocks, d) in enumerate(rows):
+        for k, blk in zip(keys, blocks):
+            A_[2 * i:2 * i + 2, 2 * k:2 * k + 2] = blk
+        b[2 * i:2 * i + 2] = d
+    xn = np.linalg.solve(A_, b)
+    grad = -A_.T @ b
+    xu = -(grad @ grad) / np.sum((A_ @ grad) ** 2) * grad
+    return xu, xn
+
+
+def test_Dogleg_ComputeBlend_and_DoglegPoint(orc):
+    """:40-73, :95-130 — the blend has norm Delta; the dog-leg point is the scaled steepest-descent point, the blend,
+    or the Newton point depending on Delta."""
+    xu, xn = _dogleg_bayes_net_points(orc)
+    assert np.linalg.norm(xu) < np.linalg.norm(xn)
+    assert abs(np.linalg.norm(orc.dogleg_point(1.5, xu, xn, blend_only=True)) - 1.5) < 1e-10
+    assert abs(np.linalg.norm(orc.dogleg_point(0.5, xu, xn)) - 0.5) < 1e-5
+    assert np.allclose(orc.dogleg_point(1.5, xu, xn), orc.dogleg_point(1.5, xu, xn, blend_only=True), atol=1e-12)
+    assert np.allclose(orc.dogleg_point(5.0, xu, xn), xn, atol=1e-12)
+
+
+def test_Dogleg_converges_on_the_pose2_examples(orc):
+    """Dogleg on the graphs of tests/testNonlinearOptimizer.cpp:248-321 and :485-503 reaches the same optimum as LM."""
+    from gtsam_petercdev_amd.graph import DoglegOptimizer
+    fg = more_optimization_graph()
+    init = Values()
+    init.insert(0, Pose2(3, 4, -math.pi))
+    init.insert(1, Pose2(10, 2, -math.pi))
+    init.insert(2, Pose2(11, 7, -math.pi))
+    opt = DoglegOptimizer(fg, init, Ordering([0, 1, 2]), backend_factory=orc.oracle_backend)
+    actual = opt.optimize()
+    for k, e in {0: Pose2(0, 0, 0), 1: Pose2(1, 0, math.pi / 2), 2: Pose2(1, 1, math.pi)}.items():
+        assert actual.at(k).equals(e, 1e-5)
+    graph, init, expected = disconnected_graph()
+    actual = DoglegOptimizer(graph, init, Ordering([X(1), X(2), X(3)]), backend_factory=orc.oracle_backend).optimize()
+    for k, e in expected.items():
+        assert actual.at(k).equals(e, 1e-6)
