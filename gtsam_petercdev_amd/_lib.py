@@ -120,6 +120,18 @@ def read_bal(path: str, priors: bool = False) -> A.ProblemArrays:
     return _dataset_to_arrays(ds, dict(kind="bal", source=str(path)))
 
 
+def write_g2o(path: str, arrays: A.ProblemArrays, packed_values) -> None:
+    """Native g2o writer (gsx_write_g2o, include/gsx.h)."""
+    lib = load()
+    lib.gsx_write_g2o.restype = C.c_int32
+    vals = np.ascontiguousarray(packed_values, dtype=np.float64)
+    desc = arrays.desc()
+    st = lib.gsx_write_g2o(C.byref(desc), vals.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(vals.size),
+                           str(path).encode())
+    if st != A.GSX_OK:
+        raise A.GsxError(st, "gsx_write_g2o", str(path))
+
+
 def dogleg_point(delta: float, dx_u, dx_n) -> np.ndarray:
     """DoglegOptimizerImpl::ComputeDoglegPoint (gsx_dogleg_point, host)."""
     u = np.ascontiguousarray(dx_u, dtype=np.float64)

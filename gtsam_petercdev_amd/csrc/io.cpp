@@ -326,4 +326,92 @@ gsx_status gsx_dataset_get(const gsx_dataset* D, gsx_problem_desc* desc, const d
 
 void gsx_dataset_free(gsx_dataset* D) { delete D; }
 
+// writeG2o — gtsam/slam/dataset.cpp:636-735: VERTEX_SE2 / VERTEX_SE3:QUAT for the Pose2 / Pose3 variables, EDGE_SE2 /
+// EDGE_SE3:QUAT for the between factors with the upper triangle of the information matrix (3-D: permuted back to the
+// file's (t, R) order).  Priors and other factor types are not part of the format.  17 significant digits: the file
+// reads back to the same doubles.
+gsx_status gsx_write_g2o(const gsx_problem_desc* d, const double* values, int64_t n_values, const char* path) {
+  if (!d || !values || !path) return GSX_E_INVALID;
+  std::vector<int64_t> soff(d->n_vars + 1, 0);
+  for (int v = 0; v < d->n_vars; ++v) {
+    const int t = d->var_types[v];
+    const int sd = t == GSX_VAR_POSE2 ? 3 : (t == GSX_VAR_POSE3 ? 12 : (t == GSX_VAR_CAMERA ? 17 : d->var_dims[v]));
+    soff[v + 1] = soff[v] + sd;
+  }
+  if (soff[d->n_vars] != n_values) return GSX_E_INVALID;
+  FILE* fh = std::fopen(path, "w");
+  if (!fh) return GSX_E_INVALID;
+  auto quat = [](const double* R, double* q) {  // q = (w, x, y, z); R row-major
+    const double tr = R[0] + R[4] + R[8];
+    if (tr > 0) {
+      const double s = std::sqrt(tr + 1.0) * 2;
+      q[0] = 0.25 * s; q[1] = (R[7] - R[5]) / s; q[2] = (R[2] - R[6]) / s; q[3] = (R[3] - R[1]) / s;
+      return;
+    }
+    int i = 0;
+    if (R[4] > R[0]) i = 1;
+    if (R[8] > R[i * 4]) i = 2;
+    const int j = (i + 1) % 3, k = (i + 2) % 3;
+    const double s = std::sqrt(1.0 + R[i * 4] - R[j * 4] - R[k * 4]) * 2;
+    q[0] = (R[k * 3 + j] - R[j * 3 + k]) / s;
+    q[1 + i] = 0.25 * s;
+    q[1 + j] = (R[j * 3 + i] + R[i * 3 + j]) / s;
+    q[1 + k] = (R[k * 3 + i] + R[i * 3 + k]) / s;
+  };
+  for (int v = 0; v < d->n_vars; ++v) {
+    const double* s = values + soff[v];
+    if (d->var_types[v] == GSX_VAR_POSE2) {
+      std::fprintf(fh, "VERTEX_SE2 %llu %.17g %.17g %.17g\n", (unsigned long long)d->var_keys[v], s[0], s[1], s[2]);
+    } else if (d->var_types[v] == GSX_VAR_POSE3) {
+      double q[4];
+      quat(s, q);
+      std::fprintf(fh, "VERTEX_SE3:QUAT %llu %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n",
+                   (unsigned long long)d->var_keys[v], s[9], s[10], s[11], q[1], q[2], q[3], q[0]);
+    }
+  }
+  for (int f = 0; f < d->n_factors; ++f) {
+    if (d->f_type[f] != GSX_F_BETWEEN) continue;
+    const int dd = d->f_rows[f];
+    if (dd != 3 && dd != 6) continue;
+    const int a = d->f_vars[d->f_key_ptr[f]], b = d->f_vars[d->f_key_ptr[f] + 1];
+    const double* z = d->meas + d->f_meas_ptr[f];
+    const double* nz = d->noise + d->f_noise_ptr[f];
+    double info[36] = {0};
+    for (int r = 0; r < dd; ++r)
+      for (int c = 0; c < dd; ++c) {
+        double x = 0;
+        if (d->f_noise_kind[f] == GSX_NOISE_GAUSSIAN) {
+          for (int k = 0; k < dd; ++k) x += nz[k * dd + r] * nz[k * dd + c];  // R'R
+        } else if (r == c) {
+          x = d->f_noise_kind[f] == GSX_NOISE_DIAGONAL ? 1.0 / (nz[r] * nz[r])
+              : (d->f_noise_kind[f] == GSX_NOISE_ISOTROPIC ? 1.0 / (nz[0] * nz[0]) : 1.0);
+        }
+        info[r * dd + c] = x;
+      }
+    if (dd == 3) {
+      std::fprintf(fh, "EDGE_SE2 %llu %llu %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n",
+                   (unsigned long long)d->var_keys[a], (unsigned long long)d->var_keys[b], z[0], z[1], z[2], info[0],
+                   info[1], info[2], info[4], info[5], info[8]);
+    } else {
+      double q[4], m[36];
+      quat(z, q);
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {  // GTSAM's (R, t) order back to the file's (t, R)
+          m[r * 6 + c] = info[(3 + r) * 6 + (3 + c)];
+          m[(3 + r) * 6 + (3 + c)] = info[r * 6 + c];
+          m[r * 6 + (3 + c)] = info[(3 + r) * 6 + c];
+          m[(3 + r) * 6 + c] = info[r * 6 + (3 + c)];
+        }
+      std::fprintf(fh, "EDGE_SE3:QUAT %llu %llu %.17g %.17g %.17g %.17g %.17g %.17g %.17g",
+                   (unsigned long long)d->var_keys[a], (unsigned long long)d->var_keys[b], z[9], z[10], z[11], q[1], q[2],
+                   q[3], q[0]);
+      for (int r = 0; r < 6; ++r)
+        for (int c = r; c < 6; ++c) std::fprintf(fh, " %.17g", m[r * 6 + c]);
+      std::fprintf(fh, "\n");
+    }
+  }
+  std::fclose(fh);
+  return GSX_OK;
+}
+
 }  // extern "C"

@@ -222,6 +222,9 @@ gsx_status gsx_read_g2o(const char* path, int32_t is3d, gsx_dataset** out);
 gsx_status gsx_read_bal(const char* path, int32_t add_priors, gsx_dataset** out);
 gsx_status gsx_dataset_get(const gsx_dataset* d, gsx_problem_desc* desc, const double** values, int64_t* n_values);
 void gsx_dataset_free(gsx_dataset* d);
+/* writeG2o (gtsam/slam/dataset.cpp:636-735): the Pose2 / Pose3 variables and the between factors of a problem with the
+ * given packed Values, in g2o format (17 significant digits). */
+gsx_status gsx_write_g2o(const gsx_problem_desc* desc, const double* values, int64_t n_values, const char* path);
 
 /* ---- lifecycle ------------------------------------------------------------ */
 gsx_status gsx_create(const gsx_problem_desc* desc, int32_t device, gsx_handle* out);
