@@ -64,8 +64,36 @@ __device__ __forceinline__ double block_sum(double v) {
   return s;
 }
 
+// mEstimator weight / loss of a whitened error norm — gtsam/linear/LossFunctions.cpp:179-191 (Huber), :250-267 (Tukey),
+// :217-224 (Cauchy); `loss` = GSX_NOISE_ROBUST_* >> 4, k = the model's parameter.
+__device__ __forceinline__ double robust_weight(int loss, double k, double dist) {
+  const double a = fabs(dist);
+  if (loss == 1) return (a <= k) ? 1.0 : k / a;
+  if (loss == 2) {
+    if (a > k) return 0.0;
+    const double t = 1.0 - dist * dist / (k * k);
+    return t * t;
+  }
+  return (k * k) / (k * k + dist * dist);
+}
+__device__ __forceinline__ double robust_loss(int loss, double k, double dist) {
+  const double a = fabs(dist);
+  if (loss == 1) return (a <= k) ? dist * dist / 2 : k * (a - k / 2);
+  if (loss == 2) {
+    if (a > k) return k * k / 6.0;
+    const double t = 1.0 - dist * dist / (k * k);
+    return k * k * (1 - t * t * t) / 6.0;
+  }
+  return k * k * log1p(dist * dist / (k * k)) * 0.5;
+}
+// number of parameters of the base noise model (the robust parameter follows them)
+__device__ __forceinline__ int noise_base_params(int base, int m) {
+  return base == GSX_NOISE_UNIT ? 0 : (base == GSX_NOISE_ISOTROPIC ? 1 : (base == GSX_NOISE_DIAGONAL ? m : m * m));
+}
+
 template <int M, int NC>
-__device__ __forceinline__ void whiten_store(double (&J)[M * NC], int kind, const double* np, double* out) {
+__device__ __forceinline__ void whiten_store(double (&J)[M * NC], int kind_full, const double* np, double* out) {
+  const int kind = kind_full & GSX_NOISE_BASE_MASK, loss = kind_full >> 4;
   if (kind == GSX_NOISE_ISOTROPIC) {
     const double inv = 1.0 / np[0];
 #pragma unroll
@@ -96,6 +124,14 @@ __device__ __forceinline__ void whiten_store(double (&J)[M * NC], int kind, cons
       for (int r = 0; r < M; ++r) J[c * M + r] = col[r];
     }
   }
+  if (loss) {  // Robust::WhitenSystem: Block reweighting by sqrt(weight(|b|)) — NoiseModel.cpp:714-722
+    double s = 0;
+#pragma unroll
+    for (int r = 0; r < M; ++r) s += J[(NC - 1) * M + r] * J[(NC - 1) * M + r];
+    const double w = sqrt(robust_weight(loss, np[noise_base_params(kind, M)], sqrt(s)));
+#pragma unroll
+    for (int i = 0; i < M * NC; ++i) J[i] *= w;
+  }
   // a lane owns its factor's block: 16-byte stores halve the memory instructions when the block allows it
   if constexpr ((M * NC) % 2 == 0) {
     if ((reinterpret_cast<size_t>(out) & 15) == 0) {
@@ -110,7 +146,8 @@ __device__ __forceinline__ void whiten_store(double (&J)[M * NC], int kind, cons
 }
 
 template <int M>
-__device__ __forceinline__ double whitened_half_sqnorm(double (&e)[M], int kind, const double* np) {
+__device__ __forceinline__ double whitened_half_sqnorm(double (&e)[M], int kind_full, const double* np) {
+  const int kind = kind_full & GSX_NOISE_BASE_MASK, loss = kind_full >> 4;
   double s = 0;
   if (kind == GSX_NOISE_UNIT) {
 #pragma unroll
@@ -134,13 +171,16 @@ __device__ __forceinline__ double whitened_half_sqnorm(double (&e)[M], int kind,
       s += x * x;
     }
   }
+  // NoiseModelFactor::error = loss(sqrt(squaredMahalanobisDistance)) — NonlinearFactor.cpp:138-149, NoiseModel.h Robust::loss
+  if (loss) return robust_loss(loss, np[noise_base_params(kind, M)], sqrt(s));
   return 0.5 * s;
 }
 
 // runtime-dimension whitening of an m x nc column-major block living in global memory
-__device__ inline void whiten_inplace(double* J, int m, int nc, int kind, const double* np) {
-  if (kind == GSX_NOISE_UNIT) return;
-  if (kind == GSX_NOISE_ISOTROPIC) {
+__device__ inline void whiten_inplace(double* J, int m, int nc, int kind_full, const double* np) {
+  const int kind = kind_full & GSX_NOISE_BASE_MASK, loss = kind_full >> 4;
+  if (kind == GSX_NOISE_UNIT) {
+  } else if (kind == GSX_NOISE_ISOTROPIC) {
     const double inv = 1.0 / np[0];
     for (int i = 0; i < m * nc; ++i) J[i] *= inv;
   } else if (kind == GSX_NOISE_DIAGONAL) {
@@ -153,6 +193,12 @@ __device__ inline void whiten_inplace(double* J, int m, int nc, int kind, const 
         for (int k = r; k < m; ++k) s += np[r * m + k] * J[c * m + k];
         J[c * m + r] = s;
       }
+  }
+  if (loss) {
+    double s = 0;
+    for (int r = 0; r < m; ++r) s += J[(nc - 1) * m + r] * J[(nc - 1) * m + r];
+    const double w = sqrt(robust_weight(loss, np[noise_base_params(kind, m)], sqrt(s)));
+    for (int i = 0; i < m * nc; ++i) J[i] *= w;
   }
 }
 
@@ -350,18 +396,20 @@ __device__ inline double factor_error(const DevProblem& P, int f, const double* 
     const double* x2 = values + P.var_state_off[P.f_vars[kp + 1]];
     for (int r = 0; r < m; ++r) e[r] = (x2[r] - x1[r]) - z[r];
   }
+  const int base = kind & GSX_NOISE_BASE_MASK, loss = kind >> 4;
   double s = 0;
   for (int r = 0; r < m; ++r) {
     double x;
-    if (kind == GSX_NOISE_UNIT) x = e[r];
-    else if (kind == GSX_NOISE_ISOTROPIC) x = e[r] * (1.0 / np[0]);
-    else if (kind == GSX_NOISE_DIAGONAL) x = e[r] * (1.0 / np[r]);
+    if (base == GSX_NOISE_UNIT) x = e[r];
+    else if (base == GSX_NOISE_ISOTROPIC) x = e[r] * (1.0 / np[0]);
+    else if (base == GSX_NOISE_DIAGONAL) x = e[r] * (1.0 / np[r]);
     else {
       x = 0;
       for (int k = r; k < m; ++k) x += np[r * m + k] * e[k];
     }
     s += x * x;
   }
+  if (loss) return robust_loss(loss, np[noise_base_params(base, m)], sqrt(s));
   return 0.5 * s;
 }
 

@@ -98,12 +98,19 @@ gsx_status lower_problem(const gsx_problem_desc* d, HostProblem& P, std::string&
       default:
         ok = false;
     }
-    switch (P.f_noise_kind[f]) {
-      case GSX_NOISE_UNIT: ok = ok && nnoise == 0; break;
-      case GSX_NOISE_ISOTROPIC: ok = ok && nnoise == 1; break;
-      case GSX_NOISE_DIAGONAL: ok = ok && nnoise == m; break;
-      case GSX_NOISE_GAUSSIAN: ok = ok && nnoise == (int64_t)m * m; break;
-      default: ok = false;
+    {
+      const int kind = P.f_noise_kind[f], loss = kind >> 4;
+      const int64_t extra = loss ? 1 : 0;  // a robust model appends its k / c
+      ok = ok && kind >= 0 && loss <= 3;
+      if (loss && P.f_type[f] == GSX_F_LINEAR) ok = false;  // a given linear factor is already whitened
+      switch (kind & GSX_NOISE_BASE_MASK) {
+        case GSX_NOISE_UNIT: ok = ok && nnoise == 0 + extra; break;
+        case GSX_NOISE_ISOTROPIC: ok = ok && nnoise == 1 + extra; break;
+        case GSX_NOISE_DIAGONAL: ok = ok && nnoise == m + extra; break;
+        case GSX_NOISE_GAUSSIAN: ok = ok && nnoise == (int64_t)m * m + extra; break;
+        default: ok = false;
+      }
+      if (loss && ok) ok = P.noise[P.f_noise_ptr[f + 1] - 1] > 0;
     }
     if (!ok) {
       err = "malformed factor " + std::to_string(f);

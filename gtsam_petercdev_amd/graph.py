@@ -309,6 +309,34 @@ class noiseModel:
         def Covariance(S, smart=True):
             return noiseModel.Gaussian.Information(np.linalg.inv(np.asarray(S, dtype=float)), smart)
 
+    class mEstimator:
+        """gtsam/linear/LossFunctions.h: robust M-estimators (Block reweighting)."""
+
+        class _M:
+            def __init__(self, code, k):
+                self.code, self.k = code, float(k)
+
+        class Huber:
+            @staticmethod
+            def Create(k=1.345):
+                return noiseModel.mEstimator._M(A.NOISE_ROBUST_HUBER, k)
+
+        class Tukey:
+            @staticmethod
+            def Create(c=4.6851):
+                return noiseModel.mEstimator._M(A.NOISE_ROBUST_TUKEY, c)
+
+        class Cauchy:
+            @staticmethod
+            def Create(k=0.1):
+                return noiseModel.mEstimator._M(A.NOISE_ROBUST_CAUCHY, k)
+
+    class Robust:
+        @staticmethod
+        def Create(robust, noise):
+            """noiseModel::Robust::Create(mEstimator, baseNoise) — gtsam/linear/NoiseModel.cpp:740-743."""
+            return _Noise(noise.kind | robust.code, noise.dim(), np.concatenate([noise.params, [robust.k]]))
+
 
 # ---- factors ---------------------------------------------------------------------------
 class _Factor:

@@ -108,8 +108,16 @@ enum {
   GSX_NOISE_UNIT = 0,       /* no parameters                                     */
   GSX_NOISE_ISOTROPIC = 1,  /* 1 parameter: sigma                                */
   GSX_NOISE_DIAGONAL = 2,   /* m parameters: sigmas                              */
-  GSX_NOISE_GAUSSIAN = 3    /* m*m parameters: upper-triangular sqrt information R,
+  GSX_NOISE_GAUSSIAN = 3,   /* m*m parameters: upper-triangular sqrt information R,
                                row-major (whitened = R * unwhitened)             */
+  /* noiseModel::Robust (gtsam/linear/NoiseModel.cpp:709-735, LossFunctions.cpp): OR one of these onto the base
+   * kind above and append ONE parameter (k / c) after the base model's parameters.  Linearization whitens with
+   * the base model and then scales [A b] by sqrt(weight(|b|)) (Block reweighting); the factor's error is
+   * loss(|whitened e|) instead of |e|^2 / 2. */
+  GSX_NOISE_ROBUST_HUBER = 1 << 4,   /* mEstimator::Huber  :179-191 */
+  GSX_NOISE_ROBUST_TUKEY = 2 << 4,   /* mEstimator::Tukey  :250-267 */
+  GSX_NOISE_ROBUST_CAUCHY = 3 << 4,  /* mEstimator::Cauchy :217-224 */
+  GSX_NOISE_BASE_MASK = 15
 };
 
 /* ---- ordering kinds for gsx_compute_ordering ----------------------------- */

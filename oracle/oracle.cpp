@@ -124,7 +124,43 @@ struct Problem {
 // :323-341 (Diagonal), :647-674 (Isotropic); Unit is a no-op.
 // M is m x ncols col-major (all Jacobian blocks + rhs), whitened in place.
 // ---------------------------------------------------------------------------
+// mEstimator weight / loss — gtsam/linear/LossFunctions.cpp:179-191 (Huber), :250-267 (Tukey), :217-224 (Cauchy)
+static double robust_weight(int loss, double k, double dist) {
+  const double a = std::abs(dist);
+  if (loss == 1) return (a <= k) ? 1.0 : k / a;
+  if (loss == 2) {
+    if (a > k) return 0.0;
+    const double t = 1.0 - dist * dist / (k * k);
+    return t * t;
+  }
+  return (k * k) / (k * k + dist * dist);
+}
+static double robust_loss(int loss, double k, double dist) {
+  const double a = std::abs(dist);
+  if (loss == 1) return (a <= k) ? dist * dist / 2 : k * (a - k / 2);
+  if (loss == 2) {
+    if (a > k) return k * k / 6.0;
+    const double t = 1.0 - dist * dist / (k * k);
+    return k * k * (1 - t * t * t) / 6.0;
+  }
+  return k * k * std::log1p(dist * dist / (k * k)) * 0.5;
+}
+// whitening with the BASE model only (Robust::unweightedWhiten / noise_->WhitenSystem)
+static void whiten_rows_base(const Factor& f, double* M, int m, int ncols);
+// Robust::WhitenSystem — NoiseModel.cpp:709-735 with Base::reweight (Block) — LossFunctions.cpp:51-125:
+// whiten with the base model, then scale [A b] by sqrt(weight(|b|)); the rhs is the LAST column of M.
 static void whiten_rows(const Factor& f, double* M, int m, int ncols) {
+  whiten_rows_base(f, M, m, ncols);
+  const int loss = f.noise_kind >> 4;
+  if (loss) {
+    double s = 0;
+    for (int r = 0; r < m; ++r) s += M[(size_t)(ncols - 1) * m + r] * M[(size_t)(ncols - 1) * m + r];
+    const double w = std::sqrt(robust_weight(loss, f.noise.back(), std::sqrt(s)));
+    for (int i = 0; i < m * ncols; ++i) M[i] *= w;
+  }
+}
+static void whiten_rows_base(const Factor& f0, double* M, int m, int ncols) {
+  struct { int noise_kind; const Vec& noise; } f{f0.noise_kind & GSX_NOISE_BASE_MASK, f0.noise};
   if (f.noise_kind == GSX_NOISE_UNIT) return;
   if (f.noise_kind == GSX_NOISE_ISOTROPIC) {
     const double inv = 1.0 / f.noise[0];
@@ -257,10 +293,11 @@ static double factor_error(const Problem& P, const Factor& f, const double* valu
   if (f.type == GSX_F_LINEAR) return 0.0;  // handled by the linear path
   double e[16];
   eval_factor(P, f, values, e, nullptr);
-  Factor tmp;  // whiten e as a 1-column system
-  whiten_rows(f, e, f.rows, 1);
+  whiten_rows_base(f, e, f.rows, 1);  // squaredMahalanobisDistance of the base model
   double s = 0;
   for (int i = 0; i < f.rows; ++i) s += e[i] * e[i];
+  const int loss = f.noise_kind >> 4;
+  if (loss) return robust_loss(loss, f.noise.back(), std::sqrt(s));  // Robust::loss — NoiseModel.h
   return 0.5 * s;
 }
 

@@ -431,3 +431,50 @@ def test_dogleg_trajectory_parity(gpu, oracle, name, delta0):
     assert abs(rg["final_error"] - ro["final_error"]) <= 1e-6 * max(ro["final_error"], 1e-12)
     assert rg["final_error"] < rg["initial_error"]
     assert relerr(gb.get_values(), ob.get_values()) < 1e-6
+
+
+# ---- robust noise models on the device ------------------------------------------------------------------------------
+def test_robust_functions_and_optimization(gpu):
+    """gtsam/linear/tests/testNoiseModel.cpp:476-569 (Huber / Cauchy / Tukey weight and loss) and
+    tests/testNonlinearOptimizer.cpp:351-482 (GN, LM, Dogleg with Huber factors) through the HIP path."""
+    from tests.test_oracle_golden import ROBUST_FUNCTIONS, robust_function_check, robust_optimization_check
+    for name, k, table in ROBUST_FUNCTIONS:
+        robust_function_check(gpu.product_backend, name, k, table)
+    robust_optimization_check(gpu.product_backend)
+
+
+def test_robust_step_parity(gpu, oracle):
+    """A pose graph with outlier loop closures under Huber / Tukey / Cauchy: errors, Jacobians, damped step and LM run
+    against the oracle."""
+    base = PROBLEMS["pose2"]
+    rng = np.random.default_rng(9)
+    kinds, ptr, vals = [], [0], []
+    for f in range(base.n_factors):
+        m = int(base.f_rows[f])
+        p = base.noise[base.f_noise_ptr[f]:base.f_noise_ptr[f + 1]]
+        k = int(base.f_noise_kind[f])
+        if base.f_type[f] == A.F_BETWEEN:
+            code = (A.NOISE_ROBUST_HUBER, A.NOISE_ROBUST_TUKEY, A.NOISE_ROBUST_CAUCHY)[f % 3]
+            k |= code
+            p = np.concatenate([p, [rng.uniform(0.5, 3.0) if code != A.NOISE_ROBUST_TUKEY else rng.uniform(20.0, 40.0)]])
+        kinds.append(k)
+        vals.append(p)
+        ptr.append(ptr[-1] + p.size)
+    arr = A.ProblemArrays(base.var_keys, base.var_types, base.var_dims, base.f_type, base.f_rows, base.f_key_ptr,
+                          base.f_vars, base.f_meas_ptr, base.meas, kinds, ptr, np.concatenate(vals), base.values,
+                          dict(base.meta))
+    gb, ob = gpu.product_backend(arr), oracle.oracle_backend(arr)
+    assert abs(gb.error() - ob.error()) <= 1e-11 * abs(ob.error())
+    ordering = gb.compute_ordering(A.ORDER_ND)
+    gb.set_ordering(ordering)
+    ob.set_ordering(ordering)
+    gb.linearize()
+    ob.linearize()
+    jg, jo = gb.jacobians(), ob.jacobians()
+    assert np.max(np.abs(jg - jo)) <= 1e-11 * max(1.0, np.max(np.abs(jo)))
+    assert relerr(gb.solve(1e-3, False), ob.solve(1e-3, False)) < 1e-8
+    p = A.lm_params_legacy()
+    p.max_iterations = 8
+    rg, ro = gb.lm_optimize(p), ob.lm_optimize(p)
+    assert np.array_equal(rg["trace_accepted"], ro["trace_accepted"])
+    assert abs(rg["final_error"] - ro["final_error"]) <= 1e-6 * ro["final_error"]

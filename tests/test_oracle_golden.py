@@ -482,3 +482,98 @@ def test_Dogleg_converges_on_the_pose2_examples(orc):
     actual = DoglegOptimizer(graph, init, Ordering([X(1), X(2), X(3)]), backend_factory=orc.oracle_backend).optimize()
     for k, e in expected.items():
         assert actual.at(k).equals(e, 1e-6)
+
+
+# ---- robust noise models: gtsam/linear/tests/testNoiseModel.cpp, tests/testNonlinearOptimizer.cpp ------------------
+ROBUST_FUNCTIONS = [  # (mEstimator, k, {error: (weight, loss)}) — testNoiseModel.cpp:476-569
+    ("Huber", 5.0, {1.0: (1.0, 0.5), 10.0: (0.5, 37.5), -10.0: (0.5, 37.5), -1.0: (1.0, 0.5)}),
+    ("Cauchy", 5.0, {1.0: (0.961538461538461, 0.490258914416017), 10.0: (0.2, 20.117973905426254),
+                     -10.0: (0.2, 20.117973905426254), -1.0: (0.961538461538461, 0.490258914416017)}),
+    ("Tukey", 5.0, {1.0: (0.9216, 0.480266666666667), 10.0: (0.0, 4.166666666666667),
+                    -10.0: (0.0, 4.166666666666667), -1.0: (0.9216, 0.480266666666667)}),
+]
+
+
+def robust_function_check(backend_factory, name, k, table):
+    """A 1-D prior with Robust(mEstimator(k), Unit): error() is loss(e), the linearized [A b] is sqrt(weight(e)) [1 -e]."""
+    for e, (weight, loss) in table.items():
+        g = NonlinearFactorGraph()
+        m = getattr(noiseModel.mEstimator, name).Create(k)
+        g.add(PriorFactor(0, np.array([0.0]), noiseModel.Robust.Create(m, noiseModel.Unit.Create(1))))
+        v = Values()
+        v.insert(0, np.array([e]))
+        be = backend_factory(g.to_arrays(v))
+        assert abs(be.error() - loss) < 1e-8, (name, e)
+        be.linearize()
+        J = be.jacobians()
+        assert abs(J[0] - math.sqrt(weight)) < 1e-8 and abs(J[1] + math.sqrt(weight) * e) < 1e-8, (name, e, J)
+
+
+@pytest.mark.parametrize("name,k,table", ROBUST_FUNCTIONS)
+def test_robustFunction(orc, name, k, table):
+    robust_function_check(orc.oracle_backend, name, k, table)
+
+
+def huber(k, base):
+    return noiseModel.Robust.Create(noiseModel.mEstimator.Huber.Create(k), base)
+
+
+def robust_optimization_cases():
+    """tests/testNonlinearOptimizer.cpp:351-482: (graph, initial, expected, tolerance, ordering)."""
+    iso = noiseModel.Isotropic.Sigma
+    fg = NonlinearFactorGraph()
+    fg.addPrior(0, Pose2(0, 0, 0), iso(3, 1))
+    fg.add(BetweenFactor(0, 1, Pose2(1, 1.1, math.pi / 4), huber(2.0, iso(3, 1))))
+    fg.add(BetweenFactor(0, 1, Pose2(1, 0.9, math.pi / 2), huber(3.0, iso(3, 1))))
+    init = Values()
+    init.insert(0, Pose2(0, 0, 0))
+    init.insert(1, Pose2(0.961187, 0.99965, 1.1781))
+    yield "Pose2OptimizationWithHuberNoOutlier", fg, init, {0: Pose2(0, 0, 0), 1: Pose2(0.961187, 0.99965, 1.1781)}, 3e-2
+
+    fg = NonlinearFactorGraph()
+    fg.addPrior(0, Point2(0, 0), iso(2, 0.01))
+    for z in ((1, 1.8), (1, 0.9), (1, 90)):
+        fg.add(BetweenFactor(0, 1, Point2(*z), huber(1.0, iso(2, 1))))
+    init = Values()
+    init.insert(0, Point2(1, 1))
+    init.insert(1, Point2(1, 0))
+    yield "Point2LinearOptimizationWithHuber", fg, init, {0: Point2(0, 0), 1: Point2(1, 1.85)}, 1e-4
+
+    fg = NonlinearFactorGraph()
+    fg.addPrior(0, Pose2(0, 0, 0), iso(3, 0.1))
+    for z in ((0, 9, math.pi / 2), (0, 11, math.pi / 2), (0, 10, math.pi / 2), (0, 9, 0)):
+        fg.add(BetweenFactor(0, 1, Pose2(*z), huber(0.2, iso(3, 1))))
+    init = Values()
+    init.insert(0, Pose2(0, 0, 0))
+    init.insert(1, Pose2(0, 10, math.pi / 4))
+    yield "Pose2OptimizationWithHuber", fg, init, {0: Pose2(0, 0, 0), 1: Pose2(0, 10, 1.45212)}, 1e-1
+
+    fg = NonlinearFactorGraph()
+    for pt in (-10, -3, -1, 1, 3, 10, 1000):
+        fg.add(PriorFactor(0, np.array([float(pt)]), huber(20, iso(1, 1))))
+    init = Values()
+    init.insert(0, np.array([100.0]))
+    yield "RobustMeanCalculation", fg, init, {0: np.array([3.33333333])}, 1e-5
+
+
+def robust_optimization_check(backend_factory):
+    from gtsam_petercdev_amd.graph import DoglegOptimizer
+    for name, fg, init, expected, tol in robust_optimization_cases():
+        order = Ordering(sorted(init.keys()))
+        results = [GaussNewtonOptimizer(fg, init, order, backend_factory=backend_factory).optimize(),
+                   LevenbergMarquardtOptimizer(fg, init, order, LevenbergMarquardtParams(),
+                                               backend_factory=backend_factory).optimize(),
+                   DoglegOptimizer(fg, init, order, relativeErrorTol=1e-10 if name == "RobustMeanCalculation" else 1e-5,
+                                   backend_factory=backend_factory).optimize()]
+        for res in results:
+            for k, e in expected.items():
+                a = res.at(k)
+                if isinstance(e, np.ndarray):
+                    assert np.allclose(a, e, atol=tol), (name, a, e)
+                else:
+                    assert a.equals(e, tol), (name, k)
+
+
+def test_optimization_with_Huber(orc):
+    """tests/testNonlinearOptimizer.cpp:351-482 — GN, LM and Dogleg with Huber-robust factors reach the expected values."""
+    robust_optimization_check(orc.oracle_backend)
