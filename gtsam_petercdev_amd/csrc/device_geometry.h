@@ -250,4 +250,43 @@ __device__ inline bool sfm_project(const double* cam, const double* pt, double* 
   return true;
 }
 
+// ---- pinhole projection with a fixed Cal3_S2 (GenericProjectionFactor; returns false on cheirality) -------------
+// pose: R9 t3; K = (fx, fy, s, u0, v0).  H1 2x6 / H2 2x3 row-major when non-null.
+// PinholeBase::project2 + Dpose / Dpoint (gtsam/geometry/CalibratedCamera.cpp:27-46,116-135), Cal3_S2::uncalibrate
+// (gtsam/geometry/Cal3_S2.cpp:54-62): (u, v) = (fx x + s y + u0, fy y + v0), Dp = [[fx, s], [0, fy]].
+__device__ inline bool pinhole_project_s2(const double* pose, const double* pt, const double* K, double* pi, double* H1,
+                                          double* H2) {
+  const double dx = pt[0] - pose[9], dy = pt[1] - pose[10], dz = pt[2] - pose[11];
+  const double qx = pose[0] * dx + pose[3] * dy + pose[6] * dz;
+  const double qy = pose[1] * dx + pose[4] * dy + pose[7] * dz;
+  const double qz = pose[2] * dx + pose[5] * dy + pose[8] * dz;
+  if (qz <= 0) return false;
+  const double d = 1.0 / qz;
+  const double u = qx * d, v = qy * d;
+  const double fx = K[0], fy = K[1], sk = K[2];
+  pi[0] = fx * u + sk * v + K[3];
+  pi[1] = fy * v + K[4];
+  if (H1) {
+    const double uv = u * v, uu = u * u, vv = v * v;
+    const double Dpose[12] = {uv, -1 - uu, v, -d, 0, d * u, 1 + vv, -uv, -u, 0, -d, d * v};
+    double Dpoint[6];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      Dpoint[j] = d * (pose[3 * j + 0] - u * pose[3 * j + 2]);
+      Dpoint[3 + j] = d * (pose[3 * j + 1] - v * pose[3 * j + 2]);
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      H1[j] = fx * Dpose[j] + sk * Dpose[6 + j];
+      H1[6 + j] = fy * Dpose[6 + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      H2[j] = fx * Dpoint[j] + sk * Dpoint[3 + j];
+      H2[3 + j] = fy * Dpoint[3 + j];
+    }
+  }
+  return true;
+}
+
 }  // namespace gsxd

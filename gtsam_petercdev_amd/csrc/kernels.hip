@@ -256,6 +256,43 @@ __global__ void __launch_bounds__(256) linearize_sfm_kernel(DevProblem P, const 
   whiten_store<2, 13>(J, P.f_noise_kind[f], P.noise + P.f_noise_off[f], jac + P.f_jac_off[f]);
 }
 
+// GenericProjectionFactor<Pose3,Point3,Cal3_S2>::evaluateError — gtsam/slam/ProjectionFactor.h:138-166
+__global__ void __launch_bounds__(256) linearize_projection_kernel(DevProblem P, const int* list, int n, const double* values,
+                                                                   double* jac) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int f = list[i];
+  const int kp = P.f_key_ptr[f];
+  const double* pose = values + P.var_state_off[P.f_vars[kp]];
+  const double* pt = values + P.var_state_off[P.f_vars[kp + 1]];
+  const double* z = P.meas + P.f_meas_off[f];  // u v fx fy s u0 v0
+  double pr[12], p3[3], K[5], pi[2], H1[12], H2[6], J[20];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) pr[k] = pose[k];
+  p3[0] = pt[0]; p3[1] = pt[1]; p3[2] = pt[2];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) K[k] = z[2 + k];
+  if (pinhole_project_s2(pr, p3, K, pi, H1, H2)) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      J[2 * c] = H1[c];
+      J[2 * c + 1] = H1[6 + c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      J[12 + 2 * c] = H2[c];
+      J[12 + 2 * c + 1] = H2[3 + c];
+    }
+    J[18] = z[0] - pi[0];  // b = -(h(x) - z)
+    J[19] = z[1] - pi[1];
+  } else {  // point behind the camera: zero Jacobians, error (2 fx, 2 fx)
+#pragma unroll
+    for (int k = 0; k < 18; ++k) J[k] = 0;
+    J[18] = J[19] = -2.0 * K[0];
+  }
+  whiten_store<2, 10>(J, P.f_noise_kind[f], P.noise + P.f_noise_off[f], jac + P.f_jac_off[f]);
+}
+
 // BetweenFactor<Pose2> via NoiseModelFactor::linearize — gtsam/nonlinear/NonlinearFactor.cpp:152-184
 __global__ void __launch_bounds__(256) linearize_between_pose2_kernel(DevProblem P, const int* list, int n,
                                                                       const double* values, double* jac) {
@@ -347,6 +384,8 @@ void launch_linearize(const DevProblem& P, const int* const type_lists[6], const
     linearize_between_pose3_kernel<<<grid(type_counts[2]), 256, 0, st>>>(P, type_lists[2], type_counts[2], values, jac);
   if (type_counts[3])
     linearize_generic_kernel<<<grid(type_counts[3]), 256, 0, st>>>(P, type_lists[3], type_counts[3], values, jac);
+  if (type_counts[4])
+    linearize_projection_kernel<<<grid(type_counts[4]), 256, 0, st>>>(P, type_lists[4], type_counts[4], values, jac);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -369,6 +408,23 @@ __device__ inline double factor_error(const DevProblem& P, int f, const double* 
     if (!sfm_project(camr, ptr3, pi, nullptr, nullptr)) return 0.0;
     e[0] = pi[0] - z[0];
     e[1] = pi[1] - z[1];
+    return whitened_half_sqnorm<2>(e, kind, np);
+  }
+  if (type == GSX_F_PROJECTION) {
+    const double* pose = values + P.var_state_off[P.f_vars[kp]];
+    const double* pt = values + P.var_state_off[P.f_vars[kp + 1]];
+    double pr[12], p3[3], K[5], pi[2], e[2];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) pr[k] = pose[k];
+    p3[0] = pt[0]; p3[1] = pt[1]; p3[2] = pt[2];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) K[k] = z[2 + k];
+    if (pinhole_project_s2(pr, p3, K, pi, nullptr, nullptr)) {
+      e[0] = pi[0] - z[0];
+      e[1] = pi[1] - z[1];
+    } else {
+      e[0] = e[1] = 2.0 * K[0];
+    }
     return whitened_half_sqnorm<2>(e, kind, np);
   }
   const int v0 = P.f_vars[kp];

@@ -381,6 +381,37 @@ def GeneralSFMFactor(measured, model, cameraKey, landmarkKey):
 GeneralSFMFactorCal3Bundler = GeneralSFMFactor
 
 
+class Cal3_S2:
+    """gtsam/geometry/Cal3_S2.h: (fx, fy, s, u0, v0), or (fov degrees, w, h) — Cal3_S2.cpp:28-41."""
+
+    def __init__(self, *args):
+        if len(args) == 3:
+            fov, w, h = args
+            a = fov * math.pi / 360.0  # fov/2 in radians
+            f = w / (2.0 * math.tan(a))
+            self.v = np.array([f, f, 0.0, w / 2.0, h / 2.0])
+        elif len(args) == 5:
+            self.v = np.asarray(args, dtype=float)
+        else:
+            self.v = np.array([1.0, 1.0, 0.0, 0.0, 0.0])
+
+    def fx(self):
+        return float(self.v[0])
+
+    def vector(self):
+        return self.v.copy()
+
+
+def GenericProjectionFactor(measured, model, poseKey, pointKey, K: "Cal3_S2"):
+    """GenericProjectionFactor<Pose3, Point3, Cal3_S2>(measured, model, poseKey, pointKey, K) —
+    gtsam/slam/ProjectionFactor.h (no body_P_sensor, default cheirality flags)."""
+    meas = np.concatenate([np.asarray(measured, dtype=float).reshape(2), K.vector()])
+    return _Factor(A.F_PROJECTION, [poseKey, pointKey], 2, meas, model)
+
+
+GenericProjectionFactorCal3_S2 = GenericProjectionFactor
+
+
 def JacobianFactor(*args):
     """JacobianFactor(key1, A1, [key2, A2, ...], b[, model]) — gtsam/linear/JacobianFactor.h.
     A diagonal/isotropic model is folded in by the backend (whitening)."""

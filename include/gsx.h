@@ -98,9 +98,15 @@ enum {
   GSX_F_BETWEEN = 2,        /* BetweenFactor<T> (gtsam/slam/BetweenFactor.h:111-124);
                                meas = measured T in state layout; T in
                                {VECTOR, POSE2, POSE3}                              */
-  GSX_F_SFM = 3             /* GeneralSFMFactor<PinholeCamera<Cal3Bundler>,Point3>
+  GSX_F_SFM = 3,            /* GeneralSFMFactor<PinholeCamera<Cal3Bundler>,Point3>
                                (gtsam/slam/GeneralSFMFactor.h:141-177); keys
                                (camera, point); meas = (u,v)                       */
+  GSX_F_PROJECTION = 4      /* GenericProjectionFactor<Pose3,Point3,Cal3_S2>
+                               (gtsam/slam/ProjectionFactor.h:138-166) with a fixed
+                               calibration and no body_P_sensor; keys (POSE3,
+                               VECTOR(3)); meas = (u, v, fx, fy, s, u0, v0).
+                               Cheirality (default flags): zero Jacobians and the
+                               constant error (2 fx, 2 fx)                         */
 };
 
 /* ---- noise model kinds (gtsam/linear/NoiseModel.cpp) --------------------- */

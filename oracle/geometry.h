@@ -298,4 +298,36 @@ inline bool sfm_project(const double* cam, const double* pt, double* pi, double*
   return true;
 }
 
+// GenericProjectionFactor's camera: PinholeCamera<Cal3_S2>(pose, K).project(point) — gtsam/geometry/PinholePose.h:90-109,
+// CalibratedCamera.cpp:27-46,116-135, Cal3_S2.cpp:54-62.  pose: R9 t3; K = (fx, fy, s, u0, v0); false = cheirality.
+inline bool pinhole_project_s2(const double* pose, const double* pt, const double* K, double* pi, double* H1, double* H2) {
+  const double dx = pt[0] - pose[9], dy = pt[1] - pose[10], dz = pt[2] - pose[11];
+  const double qx = pose[0] * dx + pose[3] * dy + pose[6] * dz;
+  const double qy = pose[1] * dx + pose[4] * dy + pose[7] * dz;
+  const double qz = pose[2] * dx + pose[5] * dy + pose[8] * dz;
+  if (qz <= 0) return false;
+  const double d = 1.0 / qz;
+  const double u = qx * d, v = qy * d;
+  pi[0] = K[0] * u + K[2] * v + K[3];
+  pi[1] = K[1] * v + K[4];
+  if (H1) {
+    const double uv = u * v, uu = u * u, vv = v * v;
+    const double Dpose[12] = {uv, -1 - uu, v, -d, 0, d * u, 1 + vv, -uv, -u, 0, -d, d * v};
+    double Dpoint[6];
+    for (int j = 0; j < 3; ++j) {
+      Dpoint[j] = d * (pose[3 * j + 0] - u * pose[3 * j + 2]);
+      Dpoint[3 + j] = d * (pose[3 * j + 1] - v * pose[3 * j + 2]);
+    }
+    for (int j = 0; j < 6; ++j) {
+      H1[j] = K[0] * Dpose[j] + K[2] * Dpose[6 + j];
+      H1[6 + j] = K[1] * Dpose[6 + j];
+    }
+    for (int j = 0; j < 3; ++j) {
+      H2[j] = K[0] * Dpoint[j] + K[2] * Dpoint[3 + j];
+      H2[3 + j] = K[1] * Dpoint[3 + j];
+    }
+  }
+  return true;
+}
+
 }  // namespace orc

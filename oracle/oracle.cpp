@@ -263,6 +263,30 @@ static bool eval_factor(const Problem& P, const Factor& f, const double* values,
     }
     return true;
   }
+  if (f.type == GSX_F_PROJECTION) {
+    // GenericProjectionFactor::evaluateError — gtsam/slam/ProjectionFactor.h:138-166 (no body_P_sensor; default
+    // throwCheirality = false: zero Jacobians and the constant error 2 fx)
+    const double* pose = values + P.state_off[f.vars[0]];
+    const double* pt = values + P.state_off[f.vars[1]];
+    const double* K = f.meas.data() + 2;
+    double pi[2], H1[12], H2[6];
+    const bool ok = pinhole_project_s2(pose, pt, K, pi, A ? H1 : nullptr, A ? H2 : nullptr);
+    if (!ok) {
+      e[0] = e[1] = 2.0 * K[0];
+      if (A)
+        for (int i = 0; i < 18; ++i) A[i] = 0;
+      return true;  // not a zeroed factor: the constant error stays in the system
+    }
+    e[0] = pi[0] - f.meas[0];
+    e[1] = pi[1] - f.meas[1];
+    if (A) {
+      for (int c = 0; c < 6; ++c)
+        for (int r = 0; r < 2; ++r) A[c * 2 + r] = H1[6 * r + c];
+      for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 2; ++r) A[12 + c * 2 + r] = H2[3 * r + c];
+    }
+    return true;
+  }
   if (f.type == GSX_F_SFM) {
     // GeneralSFMFactor::evaluateError — gtsam/slam/GeneralSFMFactor.h:127-139
     const double* cam = values + P.state_off[f.vars[0]];

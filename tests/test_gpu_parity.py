@@ -478,3 +478,73 @@ def test_robust_step_parity(gpu, oracle):
     rg, ro = gb.lm_optimize(p), ob.lm_optimize(p)
     assert np.array_equal(rg["trace_accepted"], ro["trace_accepted"])
     assert abs(rg["final_error"] - ro["final_error"]) <= 1e-6 * ro["final_error"]
+
+
+# ---- GenericProjectionFactor on the device ----------------------------------------------------------------------------
+def _visual_slam_arrays(n_poses=12, n_points=80, seed=5, with_outliers=False):
+    """Poses on a circle looking at a cloud of landmarks (examples/VisualISAM2Example.cpp style), Cal3_S2, pixel noise
+    sigma 1; priors on the first pose and the first landmark as SFMExample.cpp does."""
+    from gtsam_petercdev_amd.graph import Cal3_S2, GenericProjectionFactor
+    rng = np.random.default_rng(seed)
+    K = Cal3_S2(50.0, 50.0, 0.0, 50.0, 50.0)
+    pts = rng.uniform(-2, 2, (n_points, 3))
+    g, v = NonlinearFactorGraph(), Values()
+    noise = noiseModel.Isotropic.Sigma(2, 1.0)
+    if with_outliers:
+        noise = noiseModel.Robust.Create(noiseModel.mEstimator.Huber.Create(1.345), noise)
+    poses = []
+    for i in range(n_poses):
+        th = 2 * math.pi * i / n_poses
+        t = np.array([8 * math.cos(th), 8 * math.sin(th), 1.0])
+        zc = -t / np.linalg.norm(t)
+        xc = np.cross([0, 0, 1.0], zc)
+        xc /= np.linalg.norm(xc)
+        yc = np.cross(zc, xc)
+        R = np.stack([xc, yc, zc], axis=1)
+        poses.append((R, t))
+        for j in range(n_points):
+            q = R.T @ (pts[j] - t)
+            if q[2] <= 0.5:
+                continue
+            uv = np.array([K.v[0] * q[0] / q[2] + K.v[3], K.v[1] * q[1] / q[2] + K.v[4]]) + rng.normal(0, 1.0, 2)
+            if with_outliers and rng.random() < 0.02:
+                uv += rng.normal(0, 60.0, 2)
+            g.add(GenericProjectionFactor(uv, noise, X(i), L(j), K))
+        v.insert(X(i), Pose3(Rot3(R), Point3(*(t + rng.normal(0, 0.05, 3)))))
+    for j in range(n_points):
+        v.insert(L(j), Point3(*(pts[j] + rng.normal(0, 0.05, 3))))
+    g.add(PriorFactor(X(0), Pose3(Rot3(poses[0][0]), Point3(*poses[0][1])),
+                      noiseModel.Diagonal.Sigmas([0.1] * 3 + [0.3] * 3)))
+    g.add(PriorFactor(L(0), Point3(*pts[0]), noiseModel.Isotropic.Sigma(3, 0.1)))
+    return g.to_arrays(v)
+
+
+def test_ProjectionFactor(gpu):
+    """gtsam/slam/tests/testProjectionFactor.cpp:96-115,141-163 through the HIP path."""
+    from tests.test_oracle_golden import projection_factor_check
+    projection_factor_check(gpu.product_backend)
+
+
+@pytest.mark.parametrize("with_outliers", [False, True])
+def test_visual_slam_parity(gpu, oracle, with_outliers):
+    """A visual-SLAM problem of GenericProjectionFactors (plain and Huber-robust): errors, Jacobians, damped steps and
+    an LM run against the oracle."""
+    arr = _visual_slam_arrays(with_outliers=with_outliers)
+    gb, ob = gpu.product_backend(arr), oracle.oracle_backend(arr)
+    assert abs(gb.error() - ob.error()) <= 1e-11 * abs(ob.error())
+    for kind in (A.ORDER_MINDEGREE, A.ORDER_SCHUR_ND):
+        ordering = gb.compute_ordering(kind)
+        gb.set_ordering(ordering)
+        ob.set_ordering(ordering)
+        gb.linearize()
+        ob.linearize()
+        jg, jo = gb.jacobians(), ob.jacobians()
+        assert np.max(np.abs(jg - jo)) <= 1e-11 * max(1.0, np.max(np.abs(jo)))
+        for lam, diag in ((1e-3, False), (1.0, True)):
+            assert relerr(gb.solve(lam, diag), ob.solve(lam, diag)) < 1e-8
+    p = A.lm_params_legacy()
+    p.max_iterations = 10
+    rg, ro = gb.lm_optimize(p), ob.lm_optimize(p)
+    assert np.array_equal(rg["trace_accepted"], ro["trace_accepted"])
+    assert abs(rg["final_error"] - ro["final_error"]) <= 1e-6 * ro["final_error"]
+    assert rg["final_error"] < rg["initial_error"]  # (the residual floor is the pixel noise itself)

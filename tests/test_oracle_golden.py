@@ -577,3 +577,37 @@ def robust_optimization_check(backend_factory):
 def test_optimization_with_Huber(orc):
     """tests/testNonlinearOptimizer.cpp:351-482 — GN, LM and Dogleg with Huber-robust factors reach the expected values."""
     robust_optimization_check(orc.oracle_backend)
+
+
+# ---- gtsam/slam/tests/testProjectionFactor.cpp ------------------------------------------------------------------
+def projection_factor_check(backend_factory):
+    """:96-115 Error = (-3, 0); :141-163 Jacobians H1 / H2 (1e-3); cheirality: zero Jacobians, error (2 fx, 2 fx)."""
+    from gtsam_petercdev_amd.graph import Cal3_S2, GenericProjectionFactor, Pose3, Rot3, Point3
+    K = Cal3_S2(60, 640, 480)
+    assert abs(K.fx() - 554.256) < 1e-3
+    g = NonlinearFactorGraph()
+    g.add(GenericProjectionFactor([323.0, 240.0], noiseModel.Unit.Create(2), X(1), L(1), K))
+    v = Values()
+    v.insert(X(1), Pose3(Rot3(), Point3(0, 0, -6)))
+    v.insert(L(1), Point3(0.0, 0.0, 0.0))
+    be = backend_factory(g.to_arrays(v))
+    assert abs(be.error() - 0.5 * 9.0) < 1e-9                      # |(-3, 0)|^2 / 2
+    be.linearize()
+    J = be.jacobians().reshape(10, 2).T                              # 2 x (6 pose | 3 point | b): the factor's key order
+    H1, H2, b = J[:, :6], J[:, 6:9], J[:, 9]
+    assert np.allclose(b, [3.0, 0.0], atol=1e-9)                     # b = -(h(x) - z)
+    assert np.allclose(H1, [[0., -554.256, 0., -92.376, 0., 0.], [554.256, 0., 0., 0., -92.376, 0.]], atol=1e-3)
+    assert np.allclose(H2, [[92.376, 0., 0.], [0., 92.376, 0.]], atol=1e-3)
+    # point behind the camera (ProjectionFactor.h:154-165)
+    v2 = Values()
+    v2.insert(X(1), Pose3(Rot3(), Point3(0, 0, 6)))
+    v2.insert(L(1), Point3(0.0, 0.0, 0.0))
+    be2 = backend_factory(g.to_arrays(v2))
+    assert abs(be2.error() - 0.5 * 2 * (2 * K.fx()) ** 2) < 1e-6
+    be2.linearize()
+    J2 = be2.jacobians().reshape(10, 2).T
+    assert np.all(J2[:, :9] == 0.0) and np.allclose(J2[:, 9], -2 * K.fx())
+
+
+def test_ProjectionFactor(orc):
+    projection_factor_check(orc.oracle_backend)
