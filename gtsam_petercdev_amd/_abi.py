@@ -352,6 +352,15 @@ class Backend:
         self._check(self._fn("lm_iterate")(self._h, C.byref(params), C.byref(e), C.byref(l)), "lm_iterate")
         return e.value, l.value
 
+    def marginal_covariance(self, key) -> np.ndarray:
+        """Marginals::marginalCovariance(key): the dA x dA block of H^-1 of the current linearization."""
+        i = int(np.searchsorted(self.arrays.var_keys, np.uint64(key)))
+        d = int(self.arrays.var_dims[i])
+        out = np.zeros(d * d)
+        self._check(self._fn("marginal_covariance")(self._h, C.c_uint64(int(key)), out.ctypes.data_as(_p(C.c_double)),
+                                                    C.c_int64(d * d)), "marginal_covariance")
+        return out.reshape(d, d).T  # column-major
+
     def dogleg_optimize(self, delta_initial=1.0, max_iterations=100, relative_error_tol=1e-5, absolute_error_tol=1e-5,
                         error_tol=0.0, trace_cap=4096):
         """DoglegOptimizer (ONE_STEP_PER_ITERATION); trace_lambda / final_lambda carry the trust-region radius."""

@@ -142,6 +142,11 @@ void launch_ax_sqnorm(const DevProblem& P, const double* jac, const double* x, d
 void launch_vec_dot(const double* a, const double* b, int64_t n, double* partials, int cap, double* scalars, int slot,
                     hipStream_t st);
 void launch_vec_axpby(double* out, double alpha, const double* a, double beta, const double* b, int64_t n, hipStream_t st);
+// Marginal covariance block of one variable from the factorization: forward substitution of the
+// variable's unit columns up the path of cliques from its own clique to the root, Sigma_vv = sum over the path of y_F' y_F.
+// path[0..npath): front ids, child to root; (loc, dA): the variable's rows inside path[0]; lds_doubles = 2 max_n dA.
+void launch_marginal_path(const DevSymbolic& S, const int* path, int npath, int loc, int dA, int max_n, const double* arena,
+                          double* out, hipStream_t st);
 void launch_set_scalar(double* scalars, int slot, double v, hipStream_t st);
 void launch_begin_factorization(double* scalars, double lambda, DevStatus* status, hipStream_t st);
 // dense unit kernel for gsx_cholesky_partial: in-place lower partial Cholesky of an n x n

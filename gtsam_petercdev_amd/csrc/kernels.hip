@@ -766,6 +766,81 @@ void launch_make_damping(int n, const double* hdiag, int diagonal, double mind, 
   if (n) make_damping_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, hdiag, diagonal, mind, maxd, damp);
 }
 
+// ---- marginal covariance of one variable ---------------------------------------------------------------------
+// H = L L' (variable rows only).  (H^-1)_vv = sum_k (L^-1)_{k,v}' (L^-1)_{k,v}, and the columns (L^-1)_{:,v} are the
+// forward substitution L y = e_v, which only touches the cliques on the path from v's clique to the root: at a clique
+// y_F = L11^-1 w_F, w_S -= L21 y_F, Sigma += y_F' y_F, and w_S moves to the parent's rows through the child's row map.
+// One workgroup; w lives in LDS (two buffers of max_n x dA).  (The reference gets the same block by eliminating the
+// Bayes tree down to a marginal factor and inverting its information: gtsam/nonlinear/Marginals.cpp:107-136.)
+__global__ void __launch_bounds__(256) marginal_path_kernel(DevSymbolic S, const int* path, int npath, int loc, int dA,
+                                                            int max_n, const double* arena, double* out) {
+  extern __shared__ double mw[];
+  double* w = mw;                        // (n - 1) x dA, column-major, ld = max_n
+  double* wn = mw + (size_t)max_n * dA;  // the parent's
+  __shared__ double yj[16];
+  __shared__ double sig[16 * 16];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int e = tid; e < dA * dA; e += nt) sig[e] = 0.0;
+  for (int e = tid; e < max_n * dA; e += nt) w[e] = 0.0;
+  __syncthreads();
+  if (tid < dA) w[(loc + tid) + tid * max_n] = 1.0;
+  __syncthreads();
+  for (int pi = 0; pi < npath; ++pi) {
+    const int f = path[pi];
+    const int n = S.fr_N[f], F = S.fr_F[f];
+    const double* A = arena + S.fr_off[f];
+    const bool big = n > kSmallMaxN && !S.fr_lean[f];
+    const double* Lp = big ? A + big_panel_offset(n) : A;
+    for (int j = 0; j < F; ++j) {
+      // L(r, j): inside j's 32-row diagonal tile of a big front the value sits in the front itself, below it in the L panel
+      const int tile_end = big ? min((j / T + 1) * T, F) : 0;
+      if (tid < dA) yj[tid] = w[j + tid * max_n] / A[j + (i64)j * n];
+      __syncthreads();
+      if (tid < dA) w[j + tid * max_n] = yj[tid];
+      for (int e = tid; e < (n - 2 - j) * dA; e += nt) {
+        const int r = j + 1 + e % (n - 2 - j), c = e / (n - 2 - j);
+        const double l = (big && r >= tile_end) ? Lp[r + (i64)j * n] : A[r + (i64)j * n];
+        w[r + c * max_n] -= l * yj[c];
+      }
+      __syncthreads();
+    }
+    // Sigma += y_F' y_F
+    for (int e = tid; e < dA * dA; e += nt) {
+      const int a = e % dA, b = e / dA;
+      double acc = 0;
+      for (int r = 0; r < F; ++r) acc += w[r + a * max_n] * w[r + b * max_n];
+      sig[e] += acc;
+    }
+    if (pi + 1 < npath) {
+      const int np = S.fr_N[path[pi + 1]];
+      for (int e = tid; e < max_n * dA; e += nt) wn[e] = 0.0;
+      __syncthreads();
+      const int* cm = S.cmap + S.cmap_ptr[f];
+      const int s1 = n - F;  // separator rows + rhs row; the rhs row (last) is not part of the system
+      for (int e = tid; e < (s1 - 1) * dA; e += nt) {
+        const int i = e % (s1 - 1), c = e / (s1 - 1);
+        wn[cm[i] + c * max_n] = w[(F + i) + c * max_n];
+      }
+      (void)np;
+      __syncthreads();
+      double* t = w;
+      w = wn;
+      wn = t;
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < dA * dA; e += nt) out[e] = sig[e];
+}
+void launch_marginal_path(const DevSymbolic& S, const int* path, int npath, int loc, int dA, int max_n, const double* arena,
+                          double* out, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)marginal_path_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+    attr = true;
+  }
+  marginal_path_kernel<<<1, 256, (size_t)2 * max_n * dA * sizeof(double), st>>>(S, path, npath, loc, dA, max_n, arena, out);
+}
+
 // ---- Dogleg helpers -------------------------------------------------------------------------------------------
 __global__ void gradient_kernel(DevProblem P, DevSymbolic S, const double* H, double* g) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;

@@ -133,6 +133,8 @@ struct gsx_context {
   DevStatus* h_status = nullptr;
   static constexpr int kPartials = 4096;
   bool values_set = false, linearized = false, h_ready = false, hdiag_ready = false, solved = false, damp_ready = false;
+  bool fact_valid = false;   // the arena holds the factorization of the current linearization ...
+  double fact_lambda = 0.0;  // ... for this lambda
   int damp_kind = -1;
   double damp_min = 0, damp_max = 0;
   // LM state
@@ -529,6 +531,7 @@ void dev_linearize(gsx_context* c) {
   launch_linearize(c->DP, lists, c->type_count, c->d_values.p, c->d_jac.p, c->d_status.p, c->stream);
   timer_end(c, PH_LINEARIZE);
   c->linearized = true;
+  c->fact_valid = false;
   c->h_ready = false;
   c->damp_ready = false;
   c->solved = false;
@@ -562,6 +565,8 @@ void dev_damping(gsx_context* c, int diagonal, double mind, double maxd) {
 
 void dev_factorize(gsx_context* c, double lambda) {
   const Symbolic& S = c->S;
+  c->fact_valid = true;
+  c->fact_lambda = lambda;
   timer_begin(c, PH_FACTORIZE);
   launch_begin_factorization(c->d_scalars.p, lambda, c->d_status.p, c->stream);
   if (!c->big_descs.empty())
@@ -1361,6 +1366,60 @@ gsx_status gsx_dogleg_optimize(gsx_handle h, double delta_initial, int32_t max_i
     r->iterations = h->lm_iterations;
     r->inner_iterations = h->lm_iterations;
   }
+  return GSX_OK;
+}
+
+// Marginals::marginalCovariance(key) — gtsam/nonlinear/Marginals.cpp:107-136 — from the undamped factorization of the
+// current linearization (the block of H^-1 in the variable's tangent space), out: dA x dA column-major.
+gsx_status gsx_marginal_covariance(gsx_handle h, uint64_t key, double* out, int64_t n_out) {
+  if (!h || !out) return GSX_E_INVALID;
+  gsx_status st = ensure_ready(h, true, true);
+  if (st != GSX_OK) return st;
+  int v = -1;
+  {
+    auto it = std::lower_bound(h->P.keys.begin(), h->P.keys.end(), key);
+    if (it == h->P.keys.end() || *it != key) {
+      h->err = "marginal of a key that is not a variable of the graph";
+      return GSX_E_INVALID;
+    }
+    v = (int)(it - h->P.keys.begin());
+  }
+  const int dA = h->P.dims[v];
+  if (n_out != (int64_t)dA * dA || dA > 16) return GSX_E_INVALID;
+  hipSetDevice(h->device);
+  if (!h->linearized) dev_linearize(h);
+  if (!h->h_ready) dev_assemble_h(h);
+  if (!h->fact_valid || h->fact_lambda != 0.0) {
+    dev_damping(h, 0, 0, 0);
+    dev_factorize(h, 0.0);
+    st = readback(h);
+    if (st != GSX_OK) return st;
+    if (h->h_status->n_fail > 0) {
+      h->fact_valid = false;
+      h->err = "indeterminate linear system";
+      return GSX_E_INDETERMINATE;
+    }
+    h->solved = false;  // the back-substitution of a previous solve no longer matches the arena
+  }
+  const Symbolic& S = h->S;
+  std::vector<int> path;
+  int max_n = 0;
+  for (int f = S.front_of_var[v]; f >= 0; f = S.parent[f]) {
+    path.push_back(f);
+    max_n = std::max(max_n, S.N[f]);
+  }
+  if ((size_t)2 * max_n * dA * sizeof(double) > 160 * 1024 - 4096 - 4096) {
+    h->err = "marginal: the cliques on the path to the root are too large for the one-workgroup kernel";
+    return GSX_E_NOMEM;
+  }
+  DevBuf<int> d_path;
+  DevBuf<double> d_out;
+  HIPCHK(h, d_path.upload(path, h->stream));
+  HIPCHK(h, d_out.alloc((size_t)dA * dA));
+  launch_marginal_path(h->DS, d_path.p, (int)path.size(), S.h_loc[v], dA, max_n, h->d_arena.p, d_out.p, h->stream);
+  HIPCHK(h, hipMemcpyAsync(out, d_out.p, (size_t)dA * dA * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipGetLastError());
   return GSX_OK;
 }
 

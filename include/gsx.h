@@ -309,6 +309,9 @@ gsx_status gsx_gn_optimize(gsx_handle h, int32_t max_iterations, double relative
  * final_lambda / trace_lambda carry the trust-region radius delta.  DoglegParams::deltaInitial = 1.0. */
 gsx_status gsx_dogleg_optimize(gsx_handle h, double delta_initial, int32_t max_iterations, double relative_error_tol,
                                double absolute_error_tol, double error_tol, gsx_lm_result* result);
+/* Marginals::marginalCovariance(key) (gtsam/nonlinear/Marginals.cpp:107-136): the dA x dA block of H^-1 of the current
+ * linearization in the variable's tangent space (column-major), from the undamped factorization on the device. */
+gsx_status gsx_marginal_covariance(gsx_handle h, uint64_t key, double* out, int64_t n_out);
 /* DoglegOptimizerImpl::ComputeDoglegPoint (DoglegOptimizerImpl.cpp:26-86) on plain vectors (host). */
 gsx_status gsx_dogleg_point(double delta, const double* dx_u, const double* dx_n, int64_t n, double* out);
 

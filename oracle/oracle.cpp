@@ -1385,6 +1385,64 @@ int orc_gn_optimize(void* h, int32_t max_iterations, double rel, double abs_, do
   }
   return GSX_OK;
 }
+// Marginals::marginalCovariance — gtsam/nonlinear/Marginals.cpp:107-136: the inverse of the variable's marginal
+// information; restated densely (the block of H^-1, H = sum A'A of the current linearization) — for test-sized problems.
+int orc_marginal_covariance(void* h, uint64_t key, double* out, int64_t n_out) {
+  Problem& P = *(Problem*)h;
+  if (!P.linearized) return GSX_E_STATE;
+  int v = -1;
+  for (int i = 0; i < P.n_vars; ++i)
+    if (P.keys[i] == key) v = i;
+  if (v < 0) return GSX_E_INVALID;
+  const int d = P.dims[v];
+  const int64_t N = P.tan_size;
+  if (n_out != (int64_t)d * d || N > 6000) return GSX_E_INVALID;
+  orc::Vec H((size_t)N * N, 0.0);
+  for (const orc::LinFactor& L : P.linear) {
+    const int m = L.rows;
+    std::vector<int> cols;  // global tangent index of every Jacobian column
+    for (size_t k = 0; k < L.vars.size(); ++k)
+      for (int c = 0; c < L.dims[k]; ++c) cols.push_back(P.tan_off[L.vars[k]] + c);
+    for (size_t a = 0; a < cols.size(); ++a)
+      for (size_t b = 0; b < cols.size(); ++b) {
+        double s = 0;
+        for (int r = 0; r < m; ++r) s += L.M[a * m + r] * L.M[b * m + r];
+        H[(size_t)cols[a] * N + cols[b]] += s;
+      }
+  }
+  // in-place Cholesky H = G G' (lower), then solve for the unit columns of the variable
+  for (int64_t j = 0; j < N; ++j) {
+    double s = H[j * N + j];
+    for (int64_t k = 0; k < j; ++k) s -= H[j * N + k] * H[j * N + k];
+    if (!(s > 0)) return GSX_E_INDETERMINATE;
+    const double g = std::sqrt(s);
+    H[j * N + j] = g;
+    for (int64_t i = j + 1; i < N; ++i) {
+      double t = H[i * N + j];
+      for (int64_t k = 0; k < j; ++k) t -= H[i * N + k] * H[j * N + k];
+      H[i * N + j] = t / g;
+    }
+  }
+  const int64_t o = P.tan_off[v];
+  std::vector<orc::Vec> y(d, orc::Vec(N, 0.0));
+  for (int c = 0; c < d; ++c) {
+    orc::Vec& x = y[c];
+    x[o + c] = 1.0;
+    for (int64_t i = 0; i < N; ++i) {  // G z = e
+      double t = x[i];
+      for (int64_t k = 0; k < i; ++k) t -= H[i * N + k] * x[k];
+      x[i] = t / H[i * N + i];
+    }
+    for (int64_t i = N - 1; i >= 0; --i) {  // G' x = z
+      double t = x[i];
+      for (int64_t k = i + 1; k < N; ++k) t -= H[k * N + i] * x[k];
+      x[i] = t / H[i * N + i];
+    }
+  }
+  for (int a = 0; a < d; ++a)
+    for (int b = 0; b < d; ++b) out[a + b * d] = y[b][o + a];
+  return GSX_OK;
+}
 int orc_dogleg_optimize(void* h, double delta_initial, int32_t max_iterations, double rel, double abs_, double errtol,
                         gsx_lm_result* r) {
   Problem& P = *(Problem*)h;

@@ -548,3 +548,33 @@ def test_visual_slam_parity(gpu, oracle, with_outliers):
     assert np.array_equal(rg["trace_accepted"], ro["trace_accepted"])
     assert abs(rg["final_error"] - ro["final_error"]) <= 1e-6 * ro["final_error"]
     assert rg["final_error"] < rg["initial_error"]  # (the residual floor is the pixel noise itself)
+
+
+# ---- marginal covariances (gsx_marginal_covariance) ---------------------------------------------------------------
+def test_planarSLAMmarginals(gpu):
+    """tests/testMarginals.cpp:40-107: the reference's expected marginal covariances, for several elimination orders."""
+    from tests.test_oracle_golden import planar_slam_marginals_check
+    planar_slam_marginals_check(gpu.product_backend, [[1, 2, 3, 11, 12], [11, 12, 1, 2, 3], [3, 12, 2, 11, 1]])
+
+
+@pytest.mark.parametrize("name", ["bal_small", "bal_bigfront", "bal_wide_landmarks", "pose2", "pose3"])
+@pytest.mark.parametrize("relax", [0.0, 0.5])
+def test_marginal_covariance_matches_oracle(gpu, oracle, name, relax):
+    """Marginal covariance blocks from the device factorization (forward substitution up the clique path) against the
+    oracle's dense inverse: first / last eliminated variables, landmarks (lean leaves), cameras (big fronts)."""
+    arr = PROBLEMS[name]
+    gb, ob = gpu.product_backend(arr), oracle.oracle_backend(arr)
+    kind = A.ORDER_SCHUR_ND if name.startswith("bal") else A.ORDER_ND
+    ordering = gb.compute_ordering(kind)
+    gb.set_amalgamation(relax, 128)
+    gb.set_ordering(ordering)
+    ob.set_ordering(ordering)
+    gb.linearize()
+    ob.linearize()
+    keys = [ordering[0], ordering[1], ordering[len(ordering) // 2], ordering[-2], ordering[-1]]
+    for key in keys:
+        cg, co = gb.marginal_covariance(key), ob.marginal_covariance(key)
+        assert np.allclose(cg, cg.T, rtol=1e-9, atol=1e-14 * np.max(np.abs(co)))
+        assert np.max(np.abs(cg - co)) <= 1e-7 * np.max(np.abs(co)), (name, key)
+    # the factorization left behind is the undamped one: a following solve is unaffected
+    assert relerr(gb.solve(1e-3, False), ob.solve(1e-3, False)) < 1e-8

@@ -611,3 +611,63 @@ def projection_factor_check(backend_factory):
 
 def test_ProjectionFactor(orc):
     projection_factor_check(orc.oracle_backend)
+
+
+# ---- tests/testMarginals.cpp ----------------------------------------------------------------------------------------
+def planar_slam_linear_graph():
+    """tests/testMarginals.cpp:40-107 (PlanarSLAMSelfContained_advanced) linearized at its solution: prior + two odometry
+    BetweenFactor<Pose2> + three BearingRangeFactor<Pose2, Point2>.  BearingRange is not a factor type of this path, so the
+    whole graph is given as JacobianFactors (its Jacobians at the linearization point, in the Pose2 tangent (v_x, v_y,
+    omega) of the body frame / Point2), which is all Marginals sees.  Keys: x1..x3 = 1..3, l1, l2 = 11, 12."""
+    poses = {1: (0.0, 0.0, 0.0), 2: (2.0, 0.0, 0.0), 3: (4.0, 0.0, 0.0)}
+    lms = {11: (2.0, 2.0), 12: (4.0, 2.0)}
+    fg = GaussianFactorGraph()
+    fg.add(JacobianFactor(1, np.eye(3), np.zeros(3), noiseModel.Diagonal.Sigmas([0.3, 0.3, 0.1])))
+    odo = noiseModel.Diagonal.Sigmas([0.2, 0.2, 0.1])
+    for a, b in ((1, 2), (2, 3)):
+        # BetweenFactor<Pose2> at zero error: H1 = -Ad(h^-1) with h = (2, 0, 0), H2 = I  (BetweenFactor.h:111-124)
+        Ad_inv = np.array([[1.0, 0.0, 0.0], [0.0, 1.0, 2.0], [0.0, 0.0, 1.0]])  # Ad of (-2, 0, 0): [[c,-s,y],[s,c,-x],[0,0,1]]
+        fg.add(JacobianFactor(a, -Ad_inv, b, np.eye(3), np.zeros(3), odo))
+    meas = noiseModel.Diagonal.Sigmas([0.1, 0.2])
+    for xk, lk in ((1, 11), (2, 11), (3, 12)):
+        x, y, th = poses[xk]
+        c, s = math.cos(th), math.sin(th)
+        d = np.array(lms[lk]) - np.array([x, y])
+        q = np.array([c * d[0] + s * d[1], -s * d[0] + c * d[1]])     # point in the body frame
+        r2 = q @ q
+        r = math.sqrt(r2)
+        dq_dpose = np.array([[-1.0, 0.0, q[1]], [0.0, -1.0, -q[0]]])  # Pose2::transformTo, Pose2.cpp
+        dq_dpoint = np.array([[c, s], [-s, c]])
+        db_dq = np.array([-q[1], q[0]]) / r2                           # bearing = atan2(q_y, q_x)
+        dr_dq = q / r
+        Hpose = np.stack([db_dq @ dq_dpose, dr_dq @ dq_dpose])
+        Hpoint = np.stack([db_dq @ dq_dpoint, dr_dq @ dq_dpoint])
+        fg.add(JacobianFactor(xk, Hpose, lk, Hpoint, np.zeros(2), meas))
+    return fg
+
+
+PLANAR_SLAM_MARGINALS = {  # tests/testMarginals.cpp:76-100, tolerance 1e-8
+    1: [[0.09, 0, 0], [0, 0.09, 0], [0, 0, 0.01]],
+    2: [[0.120967742, -0.00129032258, 0.00451612903], [-0.00129032258, 0.158387097, 0.0206451613],
+        [0.00451612903, 0.0206451613, 0.0177419355]],
+    3: [[0.160967742, 0.00774193548, 0.00451612903], [0.00774193548, 0.351935484, 0.0561290323],
+        [0.00451612903, 0.0561290323, 0.0277419355]],
+    11: [[0.168709677, -0.0477419355], [-0.0477419355, 0.163548387]],
+    12: [[0.293870968, -0.104516129], [-0.104516129, 0.391935484]],
+}
+
+
+def planar_slam_marginals_check(backend_factory, orderings):
+    arrays = planar_slam_linear_graph().to_arrays(None)
+    arrays.values = np.zeros(int(arrays.var_dims.sum()))
+    for ordering in orderings:
+        be = backend_factory(arrays)
+        be.set_ordering(ordering)
+        be.linearize()
+        for key, expected in PLANAR_SLAM_MARGINALS.items():
+            assert np.allclose(be.marginal_covariance(key), expected, atol=1e-8), (ordering, key)
+
+
+def test_planarSLAMmarginals(orc):
+    """The reference's expected marginal covariances (tests/testMarginals.cpp:76-107)."""
+    planar_slam_marginals_check(orc.oracle_backend, [[1, 2, 3, 11, 12]])
