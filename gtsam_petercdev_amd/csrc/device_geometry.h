@@ -289,4 +289,27 @@ __device__ inline bool pinhole_project_s2(const double* pose, const double* pt, 
   return true;
 }
 
+// ---- BearingRange<Pose2, Point2>::Measure with Jacobians (Pose2::bearing / range, gtsam/geometry/Pose2.cpp:246-285;
+// Rot2::relativeBearing, Rot2.cpp:119-130).  pose = (x, y, theta); out: bearing angle, range; H1 2x3 / H2 2x2 row-major.
+__device__ inline void bearing_range_2d(const double* pose, const double* pt, double* br, double* H1, double* H2) {
+  const double c = cos(pose[2]), s = sin(pose[2]);
+  const double dx = pt[0] - pose[0], dy = pt[1] - pose[1];
+  const double qx = c * dx + s * dy, qy = -s * dx + c * dy;  // transformTo
+  const double d2 = qx * qx + qy * qy, n = sqrt(d2);
+  const bool far = fabs(n) > 1e-5;
+  br[0] = far ? atan2(qy, qx) : 0.0;
+  br[1] = n;
+  if (H1) {
+    const double bx = far ? -qy / d2 : 0.0, by = far ? qx / d2 : 0.0;  // D bearing / D q
+    // D q / D pose = [-1 0 qy; 0 -1 -qx], D q / D point = R'
+    H1[0] = -bx; H1[1] = -by; H1[2] = bx * qy - by * qx;
+    H2[0] = bx * c - by * s; H2[1] = bx * s + by * c;
+    // range: d = point - t (world), D r / D d = d' / r, D d / D pose = [-c s 0; -s -c 0]
+    const double rx = dx / n, ry = dy / n;
+    H1[3] = -rx * c - ry * s; H1[4] = rx * s - ry * c; H1[5] = 0.0;
+    H2[2] = rx; H2[3] = ry;
+  }
+}
+__device__ inline double wrap_angle(double a) { return atan2(sin(a), cos(a)); }
+
 }  // namespace gsxd

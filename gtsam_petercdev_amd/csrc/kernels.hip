@@ -256,6 +256,33 @@ __global__ void __launch_bounds__(256) linearize_sfm_kernel(DevProblem P, const 
   whiten_store<2, 13>(J, P.f_noise_kind[f], P.noise + P.f_noise_off[f], jac + P.f_jac_off[f]);
 }
 
+// BearingRangeFactor<Pose2,Point2> — gtsam/sam/BearingRangeFactor.h (ExpressionFactor: e = -Local(h(x), z))
+__global__ void __launch_bounds__(256) linearize_bearingrange_kernel(DevProblem P, const int* list, int n,
+                                                                     const double* values, double* jac) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int f = list[i];
+  const int kp = P.f_key_ptr[f];
+  const double* pose = values + P.var_state_off[P.f_vars[kp]];
+  const double* pt = values + P.var_state_off[P.f_vars[kp + 1]];
+  const double* z = P.meas + P.f_meas_off[f];
+  double ps[3] = {pose[0], pose[1], pose[2]}, p2[2] = {pt[0], pt[1]}, br[2], H1[6], H2[4], J[12];
+  bearing_range_2d(ps, p2, br, H1, H2);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    J[2 * c] = H1[c];
+    J[2 * c + 1] = H1[3 + c];
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    J[6 + 2 * c] = H2[c];
+    J[6 + 2 * c + 1] = H2[2 + c];
+  }
+  J[10] = -wrap_angle(br[0] - z[0]);
+  J[11] = -(br[1] - z[1]);
+  whiten_store<2, 6>(J, P.f_noise_kind[f], P.noise + P.f_noise_off[f], jac + P.f_jac_off[f]);
+}
+
 // GenericProjectionFactor<Pose3,Point3,Cal3_S2>::evaluateError — gtsam/slam/ProjectionFactor.h:138-166
 __global__ void __launch_bounds__(256) linearize_projection_kernel(DevProblem P, const int* list, int n, const double* values,
                                                                    double* jac) {
@@ -386,6 +413,8 @@ void launch_linearize(const DevProblem& P, const int* const type_lists[6], const
     linearize_generic_kernel<<<grid(type_counts[3]), 256, 0, st>>>(P, type_lists[3], type_counts[3], values, jac);
   if (type_counts[4])
     linearize_projection_kernel<<<grid(type_counts[4]), 256, 0, st>>>(P, type_lists[4], type_counts[4], values, jac);
+  if (type_counts[5])
+    linearize_bearingrange_kernel<<<grid(type_counts[5]), 256, 0, st>>>(P, type_lists[5], type_counts[5], values, jac);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -408,6 +437,15 @@ __device__ inline double factor_error(const DevProblem& P, int f, const double* 
     if (!sfm_project(camr, ptr3, pi, nullptr, nullptr)) return 0.0;
     e[0] = pi[0] - z[0];
     e[1] = pi[1] - z[1];
+    return whitened_half_sqnorm<2>(e, kind, np);
+  }
+  if (type == GSX_F_BEARINGRANGE) {
+    const double* pose = values + P.var_state_off[P.f_vars[kp]];
+    const double* pt = values + P.var_state_off[P.f_vars[kp + 1]];
+    double ps[3] = {pose[0], pose[1], pose[2]}, p2[2] = {pt[0], pt[1]}, br[2], e[2];
+    bearing_range_2d(ps, p2, br, nullptr, nullptr);
+    e[0] = wrap_angle(br[0] - z[0]);
+    e[1] = br[1] - z[1];
     return whitened_half_sqnorm<2>(e, kind, np);
   }
   if (type == GSX_F_PROJECTION) {

@@ -95,6 +95,9 @@ gsx_status lower_problem(const gsx_problem_desc* d, HostProblem& P, std::string&
       case GSX_F_SFM:
         ok = ok && nk == 2 && tv(0) == GSX_VAR_CAMERA && tv(1) == GSX_VAR_VECTOR && dv(1) == 3 && m == 2 && nmeas == 2;
         break;
+      case GSX_F_BEARINGRANGE:
+        ok = ok && nk == 2 && tv(0) == GSX_VAR_POSE2 && tv(1) == GSX_VAR_VECTOR && dv(1) == 2 && m == 2 && nmeas == 2;
+        break;
       case GSX_F_PROJECTION:
         ok = ok && nk == 2 && tv(0) == GSX_VAR_POSE3 && tv(1) == GSX_VAR_VECTOR && dv(1) == 3 && m == 2 && nmeas == 7;
         break;

@@ -94,7 +94,7 @@ struct gsx_context {
       d_f_noise_kind, d_f_cols;
   DevBuf<i64> d_f_meas_off, d_f_noise_off, d_f_jac_off;
   DevBuf<double> d_meas, d_noise;
-  DevBuf<int> d_type_list[5];
+  DevBuf<int> d_type_list[6];
   int type_count[6] = {0, 0, 0, 0, 0, 0};
   DevProblem DP{};
   // device symbolic
@@ -199,17 +199,18 @@ gsx_status upload_problem(gsx_context* c) {
   HIPCHK(c, c->d_meas.upload(P.meas, st));
   HIPCHK(c, c->d_noise.upload(P.noise, st));
   // factor type lists for the linearize kernels
-  std::vector<int> lists[5];
+  std::vector<int> lists[6];
   for (int f = 0; f < P.n_factors; ++f) {
     const int t = P.f_type[f];
     const int vt = P.types[P.f_vars[P.f_key_ptr[f]]];
     if (t == GSX_F_SFM) lists[0].push_back(f);
     else if (t == GSX_F_PROJECTION) lists[4].push_back(f);
+    else if (t == GSX_F_BEARINGRANGE) lists[5].push_back(f);
     else if (t == GSX_F_BETWEEN && vt == GSX_VAR_POSE2) lists[1].push_back(f);
     else if (t == GSX_F_BETWEEN && vt == GSX_VAR_POSE3) lists[2].push_back(f);
     else if (t != GSX_F_LINEAR) lists[3].push_back(f);
   }
-  for (int k = 0; k < 5; ++k) {
+  for (int k = 0; k < 6; ++k) {
     c->type_count[k] = (int)lists[k].size();
     HIPCHK(c, c->d_type_list[k].upload(lists[k], st));
   }
@@ -526,8 +527,7 @@ void dev_linearize(gsx_context* c) {
   timer_begin(c, PH_LINEARIZE);
   hipMemsetAsync(&c->d_status.p->n_cheirality, 0, sizeof(int), c->stream);
   const int* lists[6] = {c->d_type_list[0].p, c->d_type_list[1].p, c->d_type_list[2].p, c->d_type_list[3].p,
-                         c->d_type_list[4].p,
-                         nullptr};
+                         c->d_type_list[4].p, c->d_type_list[5].p};
   launch_linearize(c->DP, lists, c->type_count, c->d_values.p, c->d_jac.p, c->d_status.p, c->stream);
   timer_end(c, PH_LINEARIZE);
   c->linearized = true;

@@ -412,6 +412,15 @@ def GenericProjectionFactor(measured, model, poseKey, pointKey, K: "Cal3_S2"):
 GenericProjectionFactorCal3_S2 = GenericProjectionFactor
 
 
+def BearingRangeFactor(poseKey, pointKey, bearing, range_, model):
+    """BearingRangeFactor<Pose2, Point2>(poseKey, pointKey, Rot2 bearing, double range, model) — gtsam/sam/
+    BearingRangeFactor.h; `bearing` is the angle in radians (Rot2::fromAngle)."""
+    return _Factor(A.F_BEARINGRANGE, [poseKey, pointKey], 2, [float(bearing), float(range_)], model)
+
+
+BearingRangeFactor2D = BearingRangeFactor
+
+
 def JacobianFactor(*args):
     """JacobianFactor(key1, A1, [key2, A2, ...], b[, model]) — gtsam/linear/JacobianFactor.h.
     A diagonal/isotropic model is folded in by the backend (whitening)."""

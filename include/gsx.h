@@ -101,12 +101,18 @@ enum {
   GSX_F_SFM = 3,            /* GeneralSFMFactor<PinholeCamera<Cal3Bundler>,Point3>
                                (gtsam/slam/GeneralSFMFactor.h:141-177); keys
                                (camera, point); meas = (u,v)                       */
-  GSX_F_PROJECTION = 4      /* GenericProjectionFactor<Pose3,Point3,Cal3_S2>
+  GSX_F_PROJECTION = 4,     /* GenericProjectionFactor<Pose3,Point3,Cal3_S2>
                                (gtsam/slam/ProjectionFactor.h:138-166) with a fixed
                                calibration and no body_P_sensor; keys (POSE3,
                                VECTOR(3)); meas = (u, v, fx, fy, s, u0, v0).
                                Cheirality (default flags): zero Jacobians and the
                                constant error (2 fx, 2 fx)                         */
+  GSX_F_BEARINGRANGE = 5    /* BearingRangeFactor<Pose2,Point2> (gtsam/sam/
+                               BearingRangeFactor.h; Pose2::bearing / range,
+                               gtsam/geometry/Pose2.cpp:246-285, Rot2.cpp:119-130);
+                               keys (POSE2, VECTOR(2)); meas = (bearing angle,
+                               range); error = (wrapped bearing difference,
+                               range difference)                                   */
 };
 
 /* ---- noise model kinds (gtsam/linear/NoiseModel.cpp) --------------------- */

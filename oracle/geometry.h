@@ -330,4 +330,24 @@ inline bool pinhole_project_s2(const double* pose, const double* pt, const doubl
   return true;
 }
 
+// BearingRange<Pose2, Point2>::Measure — Pose2::bearing / range (gtsam/geometry/Pose2.cpp:246-285), Rot2::relativeBearing
+// (Rot2.cpp:119-130).  pose = (x, y, theta); br = (bearing angle, range); H1 2x3 / H2 2x2 row-major.
+inline void bearing_range_2d(const double* pose, const double* pt, double* br, double* H1, double* H2) {
+  const double c = std::cos(pose[2]), s = std::sin(pose[2]);
+  const double dx = pt[0] - pose[0], dy = pt[1] - pose[1];
+  const double qx = c * dx + s * dy, qy = -s * dx + c * dy;
+  const double d2 = qx * qx + qy * qy, n = std::sqrt(d2);
+  const bool far = std::abs(n) > 1e-5;
+  br[0] = far ? std::atan2(qy, qx) : 0.0;
+  br[1] = n;
+  if (H1) {
+    const double bx = far ? -qy / d2 : 0.0, by = far ? qx / d2 : 0.0;
+    H1[0] = -bx; H1[1] = -by; H1[2] = bx * qy - by * qx;
+    H2[0] = bx * c - by * s; H2[1] = bx * s + by * c;
+    const double rx = dx / n, ry = dy / n;
+    H1[3] = -rx * c - ry * s; H1[4] = rx * s - ry * c; H1[5] = 0.0;
+    H2[2] = rx; H2[3] = ry;
+  }
+}
+
 }  // namespace orc

@@ -263,6 +263,23 @@ static bool eval_factor(const Problem& P, const Factor& f, const double* values,
     }
     return true;
   }
+  if (f.type == GSX_F_BEARINGRANGE) {
+    // BearingRangeFactor (an ExpressionFactor): e = -Local(h(x), z) with the derivatives of h — ExpressionFactor.h:103-115
+    const double* pose = values + P.state_off[f.vars[0]];
+    const double* pt = values + P.state_off[f.vars[1]];
+    double br[2], H1[6], H2[4];
+    bearing_range_2d(pose, pt, br, A ? H1 : nullptr, A ? H2 : nullptr);
+    const double db = br[0] - f.meas[0];
+    e[0] = std::atan2(std::sin(db), std::cos(db));  // Rot2 local coordinates: the wrapped angle difference
+    e[1] = br[1] - f.meas[1];
+    if (A) {
+      for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 2; ++r) A[c * 2 + r] = H1[3 * r + c];
+      for (int c = 0; c < 2; ++c)
+        for (int r = 0; r < 2; ++r) A[6 + c * 2 + r] = H2[2 * r + c];
+    }
+    return true;
+  }
   if (f.type == GSX_F_PROJECTION) {
     // GenericProjectionFactor::evaluateError — gtsam/slam/ProjectionFactor.h:138-166 (no body_P_sensor; default
     // throwCheirality = false: zero Jacobians and the constant error 2 fx)

@@ -578,3 +578,79 @@ def test_marginal_covariance_matches_oracle(gpu, oracle, name, relax):
         assert np.max(np.abs(cg - co)) <= 1e-7 * np.max(np.abs(co)), (name, key)
     # the factorization left behind is the undamped one: a following solve is unaffected
     assert relerr(gb.solve(1e-3, False), ob.solve(1e-3, False)) < 1e-8
+
+
+# ---- BearingRangeFactor<Pose2, Point2> on the device -------------------------------------------------------------------
+def test_BearingRangeFactor2D(gpu):
+    """tests/testMarginals.cpp:40-107 with the nonlinear factors, testBearingRangeFactor.cpp's derivative check, angle
+    wrapping and an LM run, all through the HIP path."""
+    from tests.test_oracle_golden import bearing_range_check
+    bearing_range_check(gpu.product_backend, [[1, 2, 3, 11, 12], [11, 12, 1, 2, 3]])
+
+
+def _planar_slam_arrays(n_poses=400, n_landmarks=120, seed=11, robust=False):
+    """A robot driving a noisy spiral among landmarks (examples/PlanarSLAMExample.cpp at scale): odometry
+    BetweenFactor<Pose2> + BearingRangeFactor<Pose2, Point2> to the landmarks within 6 m, prior on the first pose."""
+    from gtsam_petercdev_amd.graph import BearingRangeFactor
+    rng = np.random.default_rng(seed)
+    lms = rng.uniform(-15, 15, (n_landmarks, 2))
+    g, v = NonlinearFactorGraph(), Values()
+    odo = noiseModel.Diagonal.Sigmas([0.05, 0.05, 0.02])
+    br = noiseModel.Diagonal.Sigmas([0.03, 0.1])
+    if robust:
+        br = noiseModel.Robust.Create(noiseModel.mEstimator.Cauchy.Create(1.0), br)
+    x, y, th = 0.0, 0.0, 0.0
+    ex, ey, eth = 0.0, 0.0, 0.0  # dead-reckoned estimate
+    g.add(PriorFactor(X(0), Pose2(0, 0, 0), noiseModel.Diagonal.Sigmas([0.1, 0.1, 0.05])))
+    seen = set()
+    for i in range(n_poses):
+        if i:
+            u = np.array([0.5, 0.0, 0.04 + 0.02 * math.sin(i / 17.0)])
+            x, y, th = x + math.cos(th) * u[0], y + math.sin(th) * u[0], th + u[2]
+            z = u + rng.normal(0, [0.05, 0.05, 0.02])
+            g.add(BetweenFactor(X(i - 1), X(i), Pose2(*z), odo))
+            ex, ey = ex + math.cos(eth) * z[0] - math.sin(eth) * z[1], ey + math.sin(eth) * z[0] + math.cos(eth) * z[1]
+            eth += z[2]
+        v.insert(X(i), Pose2(ex, ey, eth))
+        for j in range(n_landmarks):
+            d = lms[j] - (x, y)
+            r = math.hypot(*d)
+            if r < 6.0:
+                b = math.atan2(d[1], d[0]) - th + rng.normal(0, 0.03)
+                g.add(BearingRangeFactor(X(i), L(j), b, r + rng.normal(0, 0.1), br))
+                if j not in seen:  # initialise where the first sighting puts it
+                    seen.add(j)
+                    v.insert(L(j), Point2(ex + r * math.cos(eth + b), ey + r * math.sin(eth + b)))
+    return g.to_arrays(v)
+
+
+@pytest.mark.parametrize("robust", [False, True])
+def test_planar_slam_parity(gpu, oracle, robust):
+    """Planar SLAM with bearing-range measurements: errors, Jacobians, damped steps, an LM trajectory and landmark
+    marginals against the oracle."""
+    arr = _planar_slam_arrays(robust=robust)
+    gb, ob = gpu.product_backend(arr), oracle.oracle_backend(arr)
+    assert abs(gb.error() - ob.error()) <= 1e-11 * abs(ob.error())
+    for kind in (A.ORDER_MINDEGREE, A.ORDER_ND):
+        ordering = gb.compute_ordering(kind)
+        gb.set_ordering(ordering)
+        ob.set_ordering(ordering)
+        gb.linearize()
+        ob.linearize()
+        jg, jo = gb.jacobians(), ob.jacobians()
+        assert np.max(np.abs(jg - jo)) <= 1e-11 * max(1.0, np.max(np.abs(jo)))
+        for lam, diag in ((1e-3, False), (1.0, True)):
+            assert relerr(gb.solve(lam, diag), ob.solve(lam, diag)) < 1e-8
+    p = A.lm_params_legacy()
+    p.max_iterations = 15
+    rg, ro = gb.lm_optimize(p), ob.lm_optimize(p)
+    assert np.array_equal(rg["trace_accepted"], ro["trace_accepted"])
+    assert abs(rg["final_error"] - ro["final_error"]) <= 1e-6 * ro["final_error"]
+    assert rg["final_error"] < (0.5 if robust else 0.05) * rg["initial_error"]
+    gb.linearize()
+    ob.linearize()
+    gb.solve(0.0, False)
+    ob.solve(0.0, False)
+    for key in (int(arr.var_keys[0]), int(arr.var_keys[-1]), L(0) if L(0) in set(arr.var_keys.tolist()) else int(arr.var_keys[1])):
+        cg, co = gb.marginal_covariance(key), ob.marginal_covariance(key)
+        assert np.max(np.abs(cg - co)) <= 1e-7 * np.max(np.abs(co))

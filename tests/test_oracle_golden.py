@@ -668,6 +668,99 @@ def planar_slam_marginals_check(backend_factory, orderings):
             assert np.allclose(be.marginal_covariance(key), expected, atol=1e-8), (ordering, key)
 
 
+def planar_slam_nonlinear_graph():
+    """tests/testMarginals.cpp:40-75 with its own factor types: prior + BetweenFactor<Pose2> + BearingRangeFactor<Pose2,
+    Point2>, and the linearization point `soln` (lines 78-83)."""
+    from gtsam_petercdev_amd.graph import BearingRangeFactor
+    g = NonlinearFactorGraph()
+    g.add(PriorFactor(1, Pose2(0.0, 0.0, 0.0), noiseModel.Diagonal.Sigmas([0.3, 0.3, 0.1])))
+    odo = noiseModel.Diagonal.Sigmas([0.2, 0.2, 0.1])
+    g.add(BetweenFactor(1, 2, Pose2(2.0, 0.0, 0.0), odo))
+    g.add(BetweenFactor(2, 3, Pose2(2.0, 0.0, 0.0), odo))
+    meas = noiseModel.Diagonal.Sigmas([0.1, 0.2])
+    g.add(BearingRangeFactor(1, 11, math.radians(45), math.sqrt(8.0), meas))
+    g.add(BearingRangeFactor(2, 11, math.radians(90), 2.0, meas))
+    g.add(BearingRangeFactor(3, 12, math.radians(90), 2.0, meas))
+    v = Values()
+    v.insert(1, Pose2(0.0, 0.0, 0.0))
+    v.insert(2, Pose2(2.0, 0.0, 0.0))
+    v.insert(3, Pose2(4.0, 0.0, 0.0))
+    v.insert(11, Point2(2.0, 2.0))
+    v.insert(12, Point2(4.0, 2.0))
+    return g, v
+
+
+def bearing_range_check(backend_factory, orderings):
+    """BearingRangeFactor<Pose2, Point2>: (1) the reference's planar-SLAM marginals with the nonlinear factors
+    (tests/testMarginals.cpp:40-107, tolerance 1e-8), (2) zero error at that solution, (3) the factor's Jacobians against
+    central differences of its error, as gtsam/sam/tests/testBearingRangeFactor.cpp:45-57 does (1e-5 there),
+    (4) the bearing wraps (Rot2 local coordinates), (5) LM from a disturbed estimate returns to the solution."""
+    from gtsam_petercdev_amd.graph import BearingRangeFactor
+    g, v = planar_slam_nonlinear_graph()
+    arrays = g.to_arrays(v)
+    for ordering in orderings:
+        be = backend_factory(arrays)
+        be.set_ordering(ordering)
+        assert abs(be.error()) < 1e-18
+        be.linearize()
+        for key, expected in PLANAR_SLAM_MARGINALS.items():
+            assert np.allclose(be.marginal_covariance(key), expected, atol=1e-8), (ordering, key)
+    # (3) testBearingRangeFactor.cpp: factor2D(poseKey, pointKey, 1, 2, Isotropic(2, 0.5)), pose (1, 2, 0.3)?  The test
+    # uses its own values; any generic point will do for a derivative check.
+    g1 = NonlinearFactorGraph()
+    g1.add(BearingRangeFactor(1, 2, 1.0, 2.0, noiseModel.Isotropic.Sigma(2, 0.5)))
+    x0 = np.array([1.0, 2.0, 0.3, -4.0, 11.0])
+
+    def whitened_error(x):
+        vv = Values()
+        vv.insert(1, Pose2(*x[:3]))
+        vv.insert(2, Point2(*x[3:]))
+        b = backend_factory(g1.to_arrays(vv))
+        b.linearize()
+        return -b.jacobians().reshape(6, 2).T[:, 5].copy(), b
+
+    e0, b0 = whitened_error(x0)
+    J = b0.jacobians().reshape(6, 2).T[:, :5]
+    c, s = math.cos(x0[2]), math.sin(x0[2])
+    h = 1e-6
+    for k in range(5):
+        step = np.zeros(5)
+        if k < 2:  # Pose2 retract: translation moves in the body frame (Pose2::ChartAtOrigin::Retract, Pose2.cpp)
+            step[:2] = np.array([[c, -s], [s, c]])[:, k] * h
+        else:
+            step[k] = h
+        ep, _ = whitened_error(x0 + step)
+        em, _ = whitened_error(x0 - step)
+        assert np.allclose((ep - em) / (2 * h), J[:, k], atol=1e-5), k
+    # (4) measured bearing near +pi, predicted near -pi: the error is the short way round
+    g2 = NonlinearFactorGraph()
+    g2.add(BearingRangeFactor(1, 2, math.pi - 0.01, 1.0, noiseModel.Unit.Create(2)))
+    v2 = Values()
+    v2.insert(1, Pose2(0.0, 0.0, 0.0))
+    v2.insert(2, Point2(-1.0, -0.02))
+    be = backend_factory(g2.to_arrays(v2))
+    eb = math.atan2(-0.02, -1.0) - (math.pi - 0.01) + 2 * math.pi
+    er = math.hypot(1.0, 0.02) - 1.0
+    assert abs(be.error() - 0.5 * (eb * eb + er * er)) < 1e-12 and abs(eb) < 0.05
+    # (5)
+    vi = Values()
+    vi.insert(1, Pose2(0.3, -0.2, 0.15))
+    vi.insert(2, Pose2(2.4, 0.3, -0.2))
+    vi.insert(3, Pose2(3.7, -0.3, 0.1))
+    vi.insert(11, Point2(1.6, 2.5))
+    vi.insert(12, Point2(4.4, 1.7))
+    params = LevenbergMarquardtParams()
+    params.ordering = Ordering([11, 12, 1, 2, 3])
+    opt = LevenbergMarquardtOptimizer(g, vi, params, backend_factory=backend_factory)
+    opt.optimize()
+    assert opt.error() < 1e-10
+    assert np.allclose(opt.backend.get_values(), arrays.values, atol=1e-5)
+
+
+def test_BearingRangeFactor2D(orc):
+    bearing_range_check(orc.oracle_backend, [[1, 2, 3, 11, 12]])
+
+
 def test_planarSLAMmarginals(orc):
     """The reference's expected marginal covariances (tests/testMarginals.cpp:76-107)."""
     planar_slam_marginals_check(orc.oracle_backend, [[1, 2, 3, 11, 12]])
