@@ -37,6 +37,15 @@ def version() -> str:
     return f().decode()
 
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64)
+
+
+class ShardInfo(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("n_cap_fronts", C.c_int32), ("n_own_fronts", C.c_int32),
+                ("cap_level0", C.c_int32), ("n_own_factors", C.c_int32), ("cap_doubles", C.c_int64),
+                ("cap_flops", C.c_double), ("own_flops", C.c_double), ("total_flops", C.c_double)]
+
+
 class ProductBackend(A.Backend):
     def __init__(self, arrays: A.ProblemArrays, device: int = 0, host_only: bool = False):
         """host_only=True skips the upload of the initial values: only the host-side entry points
@@ -47,6 +56,35 @@ class ProductBackend(A.Backend):
         """Relaxed clique amalgamation for the next set_ordering (include/gsx.h); 0 = the reference's Bayes tree."""
         self._check(self._fn("set_amalgamation")(self._h, C.c_double(relax), C.c_int32(max_frontal_dim)),
                     "set_amalgamation")
+
+    # -- one problem over several GPUs (include/gsx.h: gsx_set_shard) ------------------------------------------
+    def set_shard(self, rank: int, world: int, allreduce):
+        """Make this handle rank `rank` of `world` handles solving ONE problem; call before set_ordering.
+        `allreduce(ptr, count) -> None` sums `count` doubles of device memory at address `ptr` over the ranks in place
+        (see distributed.torch_allreduce).  Every later call on the handle is collective."""
+        def cb(_user, ptr, count):
+            try:
+                allreduce(int(ptr), int(count))
+                return 0
+            except Exception as e:  # a raise cannot cross the C frame
+                import sys
+                print(f"gsx allreduce callback failed: {e!r}", file=sys.stderr)
+                return 1
+        self._shard_cb = ALLREDUCE_FN(cb)   # keep the trampoline alive as long as the handle
+        self._check(self._fn("set_shard")(self._h, C.c_int32(rank), C.c_int32(world), self._shard_cb, None),
+                    "set_shard")
+
+    def shard_info(self):
+        """(info dict, front_owner[n_fronts] with -1 = cap, factor_owned[n_factors]) of the current ordering."""
+        info = ShardInfo()
+        n = C.c_int32()
+        self._check(self._fn("get_tree")(self._h, C.byref(n), None, None, None, None, None, None), "get_tree")
+        owner = np.zeros(max(n.value, 1), np.int32)
+        owned = np.zeros(max(self.arrays.n_factors, 1), np.int32)
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+        self._check(self._fn("get_shard")(self._h, C.byref(info), ip(owner), ip(owned)), "get_shard")
+        d = {k: getattr(info, k) for k, _ in ShardInfo._fields_}
+        return d, owner[:n.value], owned[:self.arrays.n_factors]
 
     def stats(self) -> dict:
         s = A.Stats()

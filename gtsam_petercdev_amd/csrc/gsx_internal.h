@@ -81,6 +81,17 @@ struct Symbolic {
   std::vector<int> gm_task, gm_slot, gm_nslots;   // multi-segment task -> first slot, number of slots
   std::vector<int> gm_lvl_ptr;                    // level -> multi-task range
   int g_max_slots = 0;                            // scratch slots needed (x 128 doubles), reused per level
+  // sharding of ONE problem over the GPUs of a node (gsx_set_shard): the fronts whose subtree is cheaper than a share of
+  // the whole tree form independent subtrees dealt to the ranks; the rest — the top of the tree, the "cap" — is
+  // assembled from every rank's contributions with one all-reduce and factored by all ranks alike.
+  int shard_rank = 0, shard_world = 1;
+  std::vector<int> owner;            // front -> owning rank, -1 = cap (all ranks); all 0 when not sharded
+  std::vector<char> scheduled;       // front -> this rank processes it (owner == rank or cap)
+  std::vector<char> f_owned;         // factor -> this rank linearizes it and adds its J'J terms
+  int cap_level0 = -1;               // first level of the cap (every cap front is at or above it), -1: no cap
+  int64_t cap_begin = 0, cap_end = 0;  // the cap fronts' contiguous share of the arena (doubles)
+  int n_cap = 0;
+  double cap_cost = 0, own_cost = 0, total_cost = 0;  // flop estimates: cap, this rank's subtrees, whole tree
   // stats
   double flops = 0, front_bytes = 0, lpanel_bytes = 0;
   int64_t max_F = 0, max_rows = 0, n_small = 0, n_big = 0;
@@ -90,6 +101,6 @@ struct Symbolic {
 gsx_status lower_problem(const gsx_problem_desc* d, HostProblem& P, std::string& err);
 void compute_ordering(const HostProblem& P, int kind, std::vector<int>& order);
 gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order, double relax, int relax_max_f,
-                             Symbolic& S, std::string& err);
+                             int shard_rank, int shard_world, Symbolic& S, std::string& err);
 
 }  // namespace gsx

@@ -15,6 +15,8 @@ struct DevProblem {
   const int *f_type, *f_rows, *f_key_ptr, *f_vars, *f_noise_kind, *f_cols;
   const i64 *f_meas_off, *f_noise_off, *f_jac_off;
   const double *meas, *noise;
+  const int* f_active;  // factors this rank evaluates in the error kernels (nullptr: all n_active = n_factors)
+  int n_active;
 };
 
 // One H-assembly term: panel[dst + i, j] += sum_r J[r, colB + i] * J[r, colA + j] (32-byte record).
@@ -70,6 +72,14 @@ struct DevStatus {
 };
 
 // scalar slots in the device scalar buffer
+// sharded problems: the slots summed over the ranks before the host reads them (bit k = slot k; two more bits for the
+// status counters of the factorization / of linearize), kXScalars doubles in the exchange vector
+constexpr int kXScalars = 16;
+constexpr unsigned kXFact = 1u << 12, kXLin = 1u << 13;
+void launch_shard_pack(const double* scalars, const DevStatus* status, unsigned dirty, double* x, hipStream_t st);
+void launch_shard_unpack(const double* x, unsigned dirty, double* scalars, DevStatus* status, hipStream_t st);
+void launch_mask_copy(const double* in, const unsigned char* mask, int64_t n, double* out, hipStream_t st);
+
 enum { SC_LAMBDA = 0, SC_ERR = 1, SC_LIN0 = 2, SC_LIND = 3, SC_TRIAL_ERR = 4, SC_DOT0 = 5, SC_DOT1 = 6, SC_DOT2 = 7,
        SC_DOT3 = 8, SC_COUNT = 12 };
 

@@ -509,8 +509,8 @@ __device__ inline double factor_error(const DevProblem& P, int f, const double* 
 
 __global__ void __launch_bounds__(256) error_kernel(DevProblem P, const double* values, double* partials) {
   double acc = 0;
-  for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < P.n_factors; f += gridDim.x * blockDim.x)
-    acc += factor_error(P, f, values);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n_active; i += gridDim.x * blockDim.x)
+    acc += factor_error(P, P.f_active ? P.f_active[i] : i, values);
   const double s = block_sum(acc);
   if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
@@ -525,7 +525,7 @@ __global__ void __launch_bounds__(256) reduce_final_kernel(const double* partial
 
 void launch_error(const DevProblem& P, const double* values, double* partials, int cap, double* scalars, int slot,
                   hipStream_t st) {
-  int nb = (P.n_factors + 255) / 256;
+  int nb = (P.n_active + 255) / 256;
   nb = nb < 1 ? 1 : (nb > cap ? cap : nb);
   error_kernel<<<nb, 256, 0, st>>>(P, values, partials);
   reduce_final_kernel<<<1, 256, 0, st>>>(partials, nb, 1, scalars, slot);
@@ -538,7 +538,8 @@ void launch_error(const DevProblem& P, const double* values, double* partials, i
 __global__ void __launch_bounds__(256) linear_error_kernel(DevProblem P, const double* jac, const double* delta,
                                                            double* partials) {
   double acc0 = 0, accd = 0;
-  for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < P.n_factors; f += gridDim.x * blockDim.x) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n_active; i += gridDim.x * blockDim.x) {
+    const int f = P.f_active ? P.f_active[i] : i;
     const int m = P.f_rows[f], nc = P.f_cols[f];
     const double* J = jac + P.f_jac_off[f];
     if (m == 2 && (P.f_jac_off[f] & 1) == 0) {
@@ -588,7 +589,7 @@ __global__ void __launch_bounds__(256) linear_error_kernel(DevProblem P, const d
 
 void launch_linear_error(const DevProblem& P, const double* jac, const double* delta, double* partials, int cap,
                          double* scalars, hipStream_t st) {
-  int nb = (P.n_factors + 255) / 256;
+  int nb = (P.n_active + 255) / 256;
   nb = nb < 1 ? 1 : (nb > cap / 2 ? cap / 2 : nb);
   linear_error_kernel<<<nb, 256, 0, st>>>(P, jac, delta, partials);
   reduce_final_kernel<<<1, 256, 0, st>>>(partials, nb, 2, scalars, SC_LIN0);
@@ -827,7 +828,7 @@ __global__ void __launch_bounds__(256) marginal_path_kernel(DevSymbolic S, const
     const int f = path[pi];
     const int n = S.fr_N[f], F = S.fr_F[f];
     const double* A = arena + S.fr_off[f];
-    const bool big = n > kSmallMaxN && !S.fr_lean[f];
+    const bool big = (S.fr_lean[f] & 2) != 0;
     const double* Lp = big ? A + big_panel_offset(n) : A;
     for (int j = 0; j < F; ++j) {
       // L(r, j): inside j's 32-row diagonal tile of a big front the value sits in the front itself, below it in the L panel
@@ -936,6 +937,46 @@ __global__ void vec_axpby_kernel(double* out, double alpha, const double* a, dou
 }
 void launch_vec_axpby(double* out, double alpha, const double* a, double beta, const double* b, int64_t n, hipStream_t st) {
   if (n > 0) vec_axpby_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(out, alpha, a, beta, b, n);
+}
+
+// ---- sharded problems: what crosses the exchange callback besides the cap fronts ----------------------------------
+__global__ void shard_pack_kernel(const double* scalars, const DevStatus* status, unsigned dirty, double* x) {
+  const int k = threadIdx.x;
+  if (k >= kXScalars) return;
+  double v = 0.0;
+  if (k < SC_COUNT) v = ((dirty >> k) & 1u) ? scalars[k] : 0.0;
+  else if (k == 12) v = (dirty & kXFact) ? (double)status->n_fail : 0.0;
+  else if (k == 13) v = (dirty & kXFact) ? (double)status->n_nonfinite : 0.0;
+  else if (k == 14) v = (dirty & kXLin) ? (double)status->n_cheirality : 0.0;
+  x[k] = v;
+}
+__global__ void shard_unpack_kernel(const double* x, unsigned dirty, double* scalars, DevStatus* status) {
+  const int k = threadIdx.x;
+  if (k >= kXScalars) return;
+  const double cap = 2147483647.0;
+  if (k < SC_COUNT) {
+    if ((dirty >> k) & 1u) scalars[k] = x[k];
+  } else if (k == 12) {
+    if (dirty & kXFact) status->n_fail = (int)fmin(x[k], cap);
+  } else if (k == 13) {
+    if (dirty & kXFact) status->n_nonfinite = (int)fmin(x[k], cap);
+  } else if (k == 14) {
+    if (dirty & kXLin) status->n_cheirality = (int)fmin(x[k], cap);
+  }
+}
+void launch_shard_pack(const double* scalars, const DevStatus* status, unsigned dirty, double* x, hipStream_t st) {
+  static_assert(SC_COUNT == 12 && kXScalars >= 15, "exchange vector layout");
+  shard_pack_kernel<<<1, 64, 0, st>>>(scalars, status, dirty, x);
+}
+void launch_shard_unpack(const double* x, unsigned dirty, double* scalars, DevStatus* status, hipStream_t st) {
+  shard_unpack_kernel<<<1, 64, 0, st>>>(x, dirty, scalars, status);
+}
+__global__ void mask_copy_kernel(const double* in, const unsigned char* mask, i64 n, double* out) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = mask[i] ? in[i] : 0.0;
+}
+void launch_mask_copy(const double* in, const unsigned char* mask, int64_t n, double* out, hipStream_t st) {
+  if (n > 0) mask_copy_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(in, mask, n, out);
 }
 
 __global__ void set_scalar_kernel(double* scalars, int slot, double v) { scalars[slot] = v; }
@@ -1870,7 +1911,7 @@ __global__ void backsolve_kernel(DevSymbolic S, const int* ids, const double* ar
   const int f = ids[blockIdx.x];
   const int n = S.fr_N[f], F = S.fr_F[f];
   const double* A = arena + S.fr_off[f];
-  const bool big = n > kSmallMaxN;  // (leaf-kernel cliques, which may be larger, never come here)
+  const bool big = (S.fr_lean[f] & 2) != 0;  // blocked layout (n > kSmallMaxN, and every cap front of a sharded problem)
   // big fronts keep the rows of L below each diagonal tile in their L-panel area right after the n x n front
   const double* Lp = big ? A + big_panel_offset(n) : A;
   const int* gi = S.gidx + S.gidx_ptr[f];

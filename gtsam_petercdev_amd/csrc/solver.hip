@@ -144,6 +144,17 @@ struct gsx_context {
   Timer timers[PH_COUNT];
   int profiling = 0;
   int64_t n_cheirality = 0;
+  // sharding (gsx_set_shard)
+  int shard_rank = 0, shard_world = 1;
+  gsx_allreduce_fn shard_cb = nullptr;
+  void* shard_user = nullptr;
+  bool shard_failed = false;    // an exchange callback failed since the last readback
+  bool values_synced = true;    // every rank holds every variable's current value
+  unsigned sc_dirty = 0;        // scalar slots / status counters written since the last exchange (kernels.h)
+  DevBuf<int> d_f_active;
+  DevBuf<unsigned char> d_own_tan, d_sched_tan, d_own_state;
+  DevBuf<double> d_xscal;
+  bool sharded() const { return shard_world > 1; }
 };
 
 namespace {
@@ -178,6 +189,39 @@ void timers_resolve(gsx_context* c) {
   }
 }
 
+// factor lists of the linearize kernels (one per factor family) and of the error kernels; `owned` (may be null: all)
+// restricts them to the factors this rank evaluates
+gsx_status upload_factor_lists(gsx_context* c, const std::vector<char>* owned) {
+  const HostProblem& P = c->P;
+  hipStream_t st = c->stream;
+  std::vector<int> lists[6], active;
+  for (int f = 0; f < P.n_factors; ++f) {
+    if (owned && !(*owned)[f]) continue;
+    active.push_back(f);
+    const int t = P.f_type[f];
+    const int vt = P.types[P.f_vars[P.f_key_ptr[f]]];
+    if (t == GSX_F_SFM) lists[0].push_back(f);
+    else if (t == GSX_F_PROJECTION) lists[4].push_back(f);
+    else if (t == GSX_F_BEARINGRANGE) lists[5].push_back(f);
+    else if (t == GSX_F_BETWEEN && vt == GSX_VAR_POSE2) lists[1].push_back(f);
+    else if (t == GSX_F_BETWEEN && vt == GSX_VAR_POSE3) lists[2].push_back(f);
+    else if (t != GSX_F_LINEAR) lists[3].push_back(f);
+  }
+  for (int k = 0; k < 6; ++k) {
+    c->type_count[k] = (int)lists[k].size();
+    HIPCHK(c, c->d_type_list[k].upload(lists[k], st));
+  }
+  if (owned) {
+    HIPCHK(c, c->d_f_active.upload(active, st));
+    c->DP.f_active = c->d_f_active.p;
+  } else {
+    c->DP.f_active = nullptr;
+  }
+  c->DP.n_active = (int)active.size();
+  HIPCHK(c, hipStreamSynchronize(st));
+  return GSX_OK;
+}
+
 gsx_status upload_problem(gsx_context* c) {
   const HostProblem& P = c->P;
   hipStream_t st = c->stream;
@@ -198,22 +242,8 @@ gsx_status upload_problem(gsx_context* c) {
   HIPCHK(c, c->d_f_jac_off.upload(jo, st));
   HIPCHK(c, c->d_meas.upload(P.meas, st));
   HIPCHK(c, c->d_noise.upload(P.noise, st));
-  // factor type lists for the linearize kernels
-  std::vector<int> lists[6];
-  for (int f = 0; f < P.n_factors; ++f) {
-    const int t = P.f_type[f];
-    const int vt = P.types[P.f_vars[P.f_key_ptr[f]]];
-    if (t == GSX_F_SFM) lists[0].push_back(f);
-    else if (t == GSX_F_PROJECTION) lists[4].push_back(f);
-    else if (t == GSX_F_BEARINGRANGE) lists[5].push_back(f);
-    else if (t == GSX_F_BETWEEN && vt == GSX_VAR_POSE2) lists[1].push_back(f);
-    else if (t == GSX_F_BETWEEN && vt == GSX_VAR_POSE3) lists[2].push_back(f);
-    else if (t != GSX_F_LINEAR) lists[3].push_back(f);
-  }
-  for (int k = 0; k < 6; ++k) {
-    c->type_count[k] = (int)lists[k].size();
-    HIPCHK(c, c->d_type_list[k].upload(lists[k], st));
-  }
+  gsx_status fl = upload_factor_lists(c, nullptr);
+  if (fl != GSX_OK) return fl;
   HIPCHK(c, c->d_values.alloc(std::max<int64_t>(P.state_size, 1)));
   HIPCHK(c, c->d_trial.alloc(std::max<int64_t>(P.state_size, 1)));
   HIPCHK(c, c->d_delta.alloc(std::max<int64_t>(P.tan_size, 1)));
@@ -293,7 +323,35 @@ gsx_status upload_symbolic(gsx_context* c) {
   HIPCHK(c, c->d_fr_fvar_ptr.upload(S.fvar_ptr, st));
   HIPCHK(c, c->d_fvars.upload(S.fvars, st));
   HIPCHK(c, c->d_fr_parent.upload(S.parent, st));
-  HIPCHK(c, c->d_fr_lean.upload(std::vector<int>(S.lean.begin(), S.lean.end()), st));
+  {
+    std::vector<int> flags(S.n_fronts);  // bit 0: lean leaf, bit 1: blocked (big) layout
+    for (int f = 0; f < S.n_fronts; ++f) flags[f] = (S.lean[f] ? 1 : 0) | (S.cls[f] == 2 ? 2 : 0);
+    HIPCHK(c, c->d_fr_lean.upload(flags, st));
+  }
+  if (c->sharded()) {
+    // what this rank evaluates, and the masks that complete a vector across the ranks: `own` = this rank's subtree
+    // variables (+ the cap's on rank 0): each scalar owned exactly once; `sched` = every variable this rank assembles
+    gsx_status fl = upload_factor_lists(c, &S.f_owned);
+    if (fl != GSX_OK) return fl;
+    std::vector<unsigned char> own_tan(std::max<int64_t>(P.tan_size, 1), 0), sched_tan(own_tan.size(), 0),
+        own_state(std::max<int64_t>(P.state_size, 1), 0);
+    for (int v = 0; v < P.n_vars; ++v) {
+      const int o = S.owner[S.front_of_var[v]];
+      const bool own = o < 0 ? c->shard_rank == 0 : o == c->shard_rank;
+      const bool sched = o < 0 || o == c->shard_rank;
+      for (int d = 0; d < P.dims[v]; ++d) {
+        own_tan[P.tan_off[v] + d] = own;
+        sched_tan[P.tan_off[v] + d] = sched;
+      }
+      const int sd = (v + 1 < P.n_vars ? P.state_off[v + 1] : (int)P.state_size) - P.state_off[v];
+      for (int d = 0; d < sd; ++d) own_state[P.state_off[v] + d] = own;
+    }
+    HIPCHK(c, c->d_own_tan.upload(own_tan, st));
+    HIPCHK(c, c->d_sched_tan.upload(sched_tan, st));
+    HIPCHK(c, c->d_own_state.upload(own_state, st));
+    HIPCHK(c, c->d_xscal.alloc(kXScalars));
+    HIPCHK(c, hipMemsetAsync(c->d_delta.p, 0, std::max<int64_t>(P.tan_size, 1) * sizeof(double), st));
+  }
   HIPCHK(c, c->d_fr_child_ptr.upload(S.child_ptr, st));
   HIPCHK(c, c->d_children.upload(S.children, st));
   HIPCHK(c, c->d_cmap_ptr.upload(std::vector<i64>(S.cmap_ptr.begin(), S.cmap_ptr.end()), st));
@@ -350,6 +408,7 @@ gsx_status upload_symbolic(gsx_context* c) {
     };
     std::vector<VI> light, heavy, huge;
     for (int v = 0; v < P.n_vars; ++v) {
+      if (!S.scheduled[S.front_of_var[v]]) continue;  // another rank's subtree
       const int psize = S.h_rows[v] * P.dims[v];
       const int64_t terms = S.term_ptr[v + 1] - S.term_ptr[v];
       if (terms >= 96 && (int64_t)psize * 4 * 8 <= 48 * 1024) heavy.push_back({v, psize, terms});
@@ -522,6 +581,13 @@ gsx_status upload_symbolic(gsx_context* c) {
   return GSX_OK;
 }
 
+// in-place sum of device memory over the ranks of a sharded problem (gsx_set_shard); a failure is latched and reported
+// by the next readback
+void shard_allreduce(gsx_context* c, double* dptr, int64_t n) {
+  if (!c->sharded() || n <= 0) return;
+  if (hipStreamSynchronize(c->stream) != hipSuccess || c->shard_cb(c->shard_user, dptr, n) != 0) c->shard_failed = true;
+}
+
 // ---- device pipeline pieces (all asynchronous) -------------------------------------------------------
 void dev_linearize(gsx_context* c) {
   timer_begin(c, PH_LINEARIZE);
@@ -530,6 +596,7 @@ void dev_linearize(gsx_context* c) {
                          c->d_type_list[4].p, c->d_type_list[5].p};
   launch_linearize(c->DP, lists, c->type_count, c->d_values.p, c->d_jac.p, c->d_status.p, c->stream);
   timer_end(c, PH_LINEARIZE);
+  c->sc_dirty |= kXLin;
   c->linearized = true;
   c->fact_valid = false;
   c->h_ready = false;
@@ -550,6 +617,11 @@ void dev_assemble_h(gsx_context* c) {
 void dev_hessian_diag(gsx_context* c) {
   if (c->hdiag_ready) return;
   launch_hessian_diag(c->DP, c->DS, c->d_H.p, c->d_hdiag.p, c->stream);
+  if (c->sharded()) {
+    // a subtree variable's diagonal lives on its owner, a cap variable's is the sum of every rank's terms
+    launch_mask_copy(c->d_hdiag.p, c->d_sched_tan.p, c->P.tan_size, c->d_hdiag.p, c->stream);
+    shard_allreduce(c, c->d_hdiag.p, c->P.tan_size);
+  }
   c->hdiag_ready = true;
 }
 
@@ -557,6 +629,8 @@ void dev_damping(gsx_context* c, int diagonal, double mind, double maxd) {
   if (c->damp_ready && c->damp_kind == diagonal && c->damp_min == mind && c->damp_max == maxd) return;
   if (diagonal) dev_hessian_diag(c);
   launch_make_damping((int)c->P.tan_size, c->d_hdiag.p, diagonal, mind, maxd, c->d_damp.p, c->stream);
+  // (a cap variable is damped once: by rank 0's share of the exchange)
+  if (c->sharded()) launch_mask_copy(c->d_damp.p, c->d_own_tan.p, c->P.tan_size, c->d_damp.p, c->stream);
   c->damp_ready = true;
   c->damp_kind = diagonal;
   c->damp_min = mind;
@@ -567,6 +641,7 @@ void dev_factorize(gsx_context* c, double lambda) {
   const Symbolic& S = c->S;
   c->fact_valid = true;
   c->fact_lambda = lambda;
+  c->sc_dirty |= kXFact;
   timer_begin(c, PH_FACTORIZE);
   launch_begin_factorization(c->d_scalars.p, lambda, c->d_status.p, c->stream);
   if (!c->big_descs.empty())
@@ -603,6 +678,9 @@ void dev_factorize(gsx_context* c, double lambda) {
                           S.gm_lvl_ptr[l + 1] - S.gm_lvl_ptr[l], c->d_arena.p, c->stream);
         if (prof) timer_end(c, PH_K_GATHER);
       }
+      // sharded: every rank's share of the cap (H terms, damping, its subtrees' Schur complements) is in; their sum
+      // is the assembled cap, which all ranks now factor alike
+      if (l == S.cap_level0) shard_allreduce(c, c->d_arena.p + S.cap_begin, S.cap_end - S.cap_begin);
       if (prof) timer_begin(c, PH_K_POTRF0);
       launch_big_potrf0(c->d_big.p + B.begin, B.count, c->d_arena.p, c->d_status.p, c->stream);
       if (prof) timer_end(c, PH_K_POTRF0);
@@ -657,6 +735,7 @@ void dev_linear_error(gsx_context* c) {
   timer_begin(c, PH_LINERR);
   launch_linear_error(c->DP, c->d_jac.p, c->d_delta.p, c->d_partials.p, gsx_context::kPartials, c->d_scalars.p,
                       c->stream);
+  c->sc_dirty |= (1u << SC_LIN0) | (1u << SC_LIND);
   timer_end(c, PH_LINERR);
 }
 void dev_retract(gsx_context* c, const double* d_delta) {
@@ -667,9 +746,22 @@ void dev_retract(gsx_context* c, const double* d_delta) {
 void dev_error(gsx_context* c, const double* d_vals, int slot) {
   timer_begin(c, PH_ERROR);
   launch_error(c->DP, d_vals, c->d_partials.p, gsx_context::kPartials, c->d_scalars.p, slot, c->stream);
+  c->sc_dirty |= 1u << slot;
   timer_end(c, PH_ERROR);
 }
 gsx_status readback(gsx_context* c) {
+  if (c->sharded() && c->sc_dirty) {
+    // partial sums and status counters of this rank's share -> the whole problem's, identical on every rank
+    launch_shard_pack(c->d_scalars.p, c->d_status.p, c->sc_dirty, c->d_xscal.p, c->stream);
+    shard_allreduce(c, c->d_xscal.p, kXScalars);
+    launch_shard_unpack(c->d_xscal.p, c->sc_dirty, c->d_scalars.p, c->d_status.p, c->stream);
+  }
+  c->sc_dirty = 0;
+  if (c->shard_failed) {
+    c->shard_failed = false;
+    c->err = "the all-reduce callback of a sharded handle failed";
+    return GSX_E_NO_DEVICE;
+  }
   HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_status.p, sizeof(DevStatus), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -751,6 +843,7 @@ gsx_status lm_try_lambda(gsx_context* c, const gsx_lm_params& p, Trace& tr, gsx_
     }
     newLambda = std::max(p.lambda_lower_bound, newLambda);
     std::swap(c->d_values.p, c->d_trial.p);  // accept the trial values
+    c->values_synced = false;
     c->linearized = false;
     c->h_ready = false;
     c->solved = false;
@@ -896,7 +989,7 @@ gsx_status gsx_set_ordering(gsx_handle h, const uint64_t* keys, int32_t n) {
     }
     ord[i] = it->second;
   }
-  gsx_status st = symbolic_analysis(h->P, ord, h->relax, h->relax_max_f, h->S, h->err);
+  gsx_status st = symbolic_analysis(h->P, ord, h->relax, h->relax_max_f, h->shard_rank, h->shard_world, h->S, h->err);
   if (st != GSX_OK) return st;
   h->order = ord;
   h->has_symbolic = true;
@@ -920,6 +1013,43 @@ gsx_status gsx_set_amalgamation(gsx_handle h, double relax, int32_t max_frontal_
   if (!h || !(relax >= 0.0) || max_frontal_dim < 1) return GSX_E_INVALID;
   h->relax = relax;
   h->relax_max_f = max_frontal_dim;
+  return GSX_OK;
+}
+
+gsx_status gsx_set_shard(gsx_handle h, int32_t rank, int32_t world, gsx_allreduce_fn allreduce, void* user) {
+  if (!h || world < 1 || rank < 0 || rank >= world || (world > 1 && !allreduce)) return GSX_E_INVALID;
+  if (h->has_symbolic) {
+    h->err = "gsx_set_shard must precede gsx_set_ordering";
+    return GSX_E_STATE;
+  }
+  h->shard_rank = rank;
+  h->shard_world = world;
+  h->shard_cb = allreduce;
+  h->shard_user = user;
+  return GSX_OK;
+}
+
+gsx_status gsx_get_shard(gsx_handle h, gsx_shard_info* info, int32_t* front_owner, int32_t* factor_owned) {
+  if (!h || !h->has_symbolic) return GSX_E_STATE;
+  const Symbolic& S = h->S;
+  if (info) {
+    info->rank = S.shard_rank;
+    info->world = S.shard_world;
+    info->n_cap_fronts = S.n_cap;
+    info->n_own_fronts = 0;
+    for (int f = 0; f < S.n_fronts; ++f) info->n_own_fronts += S.owner[f] == S.shard_rank;
+    info->cap_level0 = S.cap_level0;
+    info->n_own_factors = 0;
+    for (char o : S.f_owned) info->n_own_factors += o != 0;
+    info->cap_doubles = S.cap_end - S.cap_begin;
+    info->cap_flops = S.cap_cost;
+    info->own_flops = S.own_cost;
+    info->total_flops = S.total_cost;
+  }
+  if (front_owner)
+    for (int f = 0; f < S.n_fronts; ++f) front_owner[f] = S.owner[f];
+  if (factor_owned)
+    for (int f = 0; f < h->P.n_factors; ++f) factor_owned[f] = S.f_owned[f];
   return GSX_OK;
 }
 
@@ -965,6 +1095,7 @@ gsx_status gsx_set_values(gsx_handle h, const double* packed, int64_t n) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
   }
   h->values_set = true;
+  h->values_synced = true;
   h->linearized = h->h_ready = h->solved = false;
   return GSX_OK;
 }
@@ -974,6 +1105,18 @@ gsx_status gsx_get_values(gsx_handle h, double* packed, int64_t n) {
   gsx_status st = ensure_ready(h, true, false);
   if (st != GSX_OK) return st;
   hipSetDevice(h->device);
+  if (h->sharded() && !h->values_synced && h->has_symbolic) {
+    // every variable from its owner: the ranks only kept their own subtrees (and the cap) current
+    launch_mask_copy(h->d_values.p, h->d_own_state.p, n, h->d_trial.p, h->stream);
+    shard_allreduce(h, h->d_trial.p, n);
+    std::swap(h->d_values.p, h->d_trial.p);
+    h->values_synced = true;
+    if (h->shard_failed) {
+      h->shard_failed = false;
+      h->err = "the all-reduce callback of a sharded handle failed";
+      return GSX_E_NO_DEVICE;
+    }
+  }
   if (n > 0) {
     HIPCHK(h, hipMemcpyAsync(packed, h->d_values.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1056,7 +1199,13 @@ gsx_status gsx_solve(gsx_handle h, double lambda, int32_t diagonal_damping, doub
   }
   h->solved = true;
   if (delta_out && n > 0) {
-    HIPCHK(h, hipMemcpyAsync(delta_out, h->d_delta.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    const double* src = h->d_delta.p;
+    if (h->sharded()) {
+      launch_mask_copy(h->d_delta.p, h->d_own_tan.p, n, h->d_udelta.p, h->stream);
+      shard_allreduce(h, h->d_udelta.p, n);
+      src = h->d_udelta.p;
+    }
+    HIPCHK(h, hipMemcpyAsync(delta_out, src, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
   }
   return GSX_OK;
@@ -1100,6 +1249,7 @@ gsx_status gsx_retract(gsx_handle h, const double* delta, int64_t n, int32_t com
   if (trial_error) *trial_error = h->h_scalars[SC_TRIAL_ERR];
   if (commit) {
     std::swap(h->d_values.p, h->d_trial.p);
+    h->values_synced = false;
     h->linearized = h->h_ready = h->solved = false;
   }
   return GSX_OK;
@@ -1210,6 +1360,7 @@ gsx_status gsx_gn_optimize(gsx_handle h, int32_t max_iterations, double relTol, 
         return GSX_E_INDETERMINATE;
       }
       std::swap(h->d_values.p, h->d_trial.p);
+      h->values_synced = false;
       h->linearized = h->h_ready = h->solved = false;
       h->lm_error = h->h_scalars[SC_TRIAL_ERR];
       h->lm_iterations++;
@@ -1270,6 +1421,10 @@ gsx_status gsx_dogleg_optimize(gsx_handle h, double delta_initial, int32_t max_i
   if (!h || !(delta_initial >= 0)) return GSX_E_INVALID;
   gsx_status st = ensure_ready(h, true, true);
   if (st != GSX_OK) return st;
+  if (h->sharded()) {
+    h->err = "Dogleg is not available on a sharded handle";
+    return GSX_E_STATE;
+  }
   hipSetDevice(h->device);
   const int64_t nt = h->P.tan_size;
   if (!h->d_dlu.p) {
@@ -1375,6 +1530,10 @@ gsx_status gsx_marginal_covariance(gsx_handle h, uint64_t key, double* out, int6
   if (!h || !out) return GSX_E_INVALID;
   gsx_status st = ensure_ready(h, true, true);
   if (st != GSX_OK) return st;
+  if (h->sharded()) {
+    h->err = "marginals are not available on a sharded handle";
+    return GSX_E_STATE;
+  }
   int v = -1;
   {
     auto it = std::lower_bound(h->P.keys.begin(), h->P.keys.end(), key);

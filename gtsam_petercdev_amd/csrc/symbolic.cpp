@@ -17,7 +17,7 @@
 namespace gsx {
 
 gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order, double relax, int relax_max_f,
-                             Symbolic& S, std::string& err) {
+                             int shard_rank, int shard_world, Symbolic& S, std::string& err) {
   const int n = P.n_vars, m = P.n_factors;
   if ((int)order.size() != n) {
     err = "ordering size differs from the number of variables";
@@ -26,6 +26,8 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
   S = Symbolic();
   S.relax = relax;
   S.relax_max_f = relax_max_f;
+  S.shard_rank = shard_rank;
+  S.shard_world = std::max(shard_world, 1);
   S.order = order;
   S.pos.assign(n, -1);
   for (int j = 0; j < n; ++j) {
@@ -234,31 +236,137 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     S.max_F = std::max<int64_t>(S.max_F, F);
     S.max_rows = std::max<int64_t>(S.max_rows, F + Sd);
   }
+  for (int f = 0; f < nfr; ++f)  // children have smaller ids
+    if (S.parent[f] >= 0) S.level[S.parent[f]] = std::max(S.level[S.parent[f]], S.level[f] + 1);
+  // ---- sharding: cap + subtrees dealt to the ranks (proportional mapping of the assembly tree) -------------------
+  // sub[f] = flop estimate of f's whole subtree.  Fronts with sub[f] above a share of the total form the cap (an
+  // upward-closed set: a parent's subtree contains its children's); what hangs below the cap is a forest of independent
+  // subtrees, dealt to the ranks largest first onto the least loaded rank.  The share is chosen among a few candidates
+  // to minimise cap + heaviest rank.  All ranks compute the same partition from the same inputs.
+  S.owner.assign(nfr, 0);
+  std::vector<char> cap(nfr, 0);
+  if (S.shard_world > 1) {
+    std::vector<double> cost(nfr), sub(nfr);
+    double total = 0;
+    for (int f = 0; f < nfr; ++f) {
+      const double F = S.F[f], s1 = S.S[f] + 1.0;
+      cost[f] = F * F * F / 3.0 + F * F * s1 + F * s1 * s1 + 2000.0;  // (+ a constant: no front is free)
+      sub[f] = cost[f];
+    }
+    for (int f = 0; f < nfr; ++f) {
+      sub[f] += 0.0;
+      if (S.parent[f] >= 0) sub[S.parent[f]] += sub[f];
+      else total += sub[f];
+    }
+    // (children have smaller ids, so sub[f] is complete when f is reached as a child above)
+    std::vector<int> roots, assign(nfr, -1), best_assign;
+    std::vector<char> best_cap;
+    double best = -1, best_capc = 0;
+    std::vector<double> load(S.shard_world);
+    for (double alpha : {1.0, 2.0, 4.0, 8.0, 16.0, 32.0}) {
+      const double tau = total / (S.shard_world * alpha);
+      double capc = 0;
+      roots.clear();
+      for (int f = 0; f < nfr; ++f) {
+        cap[f] = sub[f] > tau;
+        if (cap[f]) capc += cost[f];
+      }
+      for (int f = 0; f < nfr; ++f)
+        if (!cap[f] && (S.parent[f] < 0 || cap[S.parent[f]])) roots.push_back(f);
+      std::stable_sort(roots.begin(), roots.end(), [&](int a, int b) { return sub[a] > sub[b]; });
+      std::fill(load.begin(), load.end(), 0.0);
+      for (int r : roots) {
+        int k = 0;
+        for (int q = 1; q < S.shard_world; ++q)
+          if (load[q] < load[k]) k = q;
+        assign[r] = k;
+        load[k] += sub[r];
+      }
+      const double worst = *std::max_element(load.begin(), load.end());
+      if (best < 0 || capc + worst < best) {
+        best = capc + worst;
+        best_capc = capc;
+        best_cap = cap;
+        best_assign = assign;
+      }
+    }
+    cap = best_cap;
+    for (int f = nfr - 1; f >= 0; --f) {  // parents first
+      if (cap[f]) S.owner[f] = -1;
+      else if (S.parent[f] < 0 || cap[S.parent[f]]) S.owner[f] = best_assign[f];
+      else S.owner[f] = S.owner[S.parent[f]];
+    }
+    S.cap_cost = best_capc;
+    S.total_cost = total;
+    for (int f = 0; f < nfr; ++f) {
+      if (S.owner[f] == S.shard_rank) S.own_cost += cost[f];
+      S.n_cap += cap[f];
+    }
+    // every cap level above every subtree level: the cap's assembly (H terms + subtree contributions) is then complete,
+    // on each rank for its share, before the first cap front is factored — ONE exchange per factorization
+    int lbase = 0;
+    for (int f = 0; f < nfr; ++f)
+      if (!cap[f]) lbase = std::max(lbase, S.level[f] + 1);
+    for (int f = 0; f < nfr; ++f)
+      if (cap[f]) S.level[f] = lbase;
+    for (int f = 0; f < nfr; ++f)
+      if (cap[f] && S.parent[f] >= 0) S.level[S.parent[f]] = std::max(S.level[S.parent[f]], S.level[f] + 1);
+    if (S.n_cap) S.cap_level0 = lbase;
+  }
+  S.scheduled.assign(nfr, 1);
+  for (int f = 0; f < nfr; ++f) S.scheduled[f] = S.owner[f] < 0 || S.owner[f] == S.shard_rank;
+  S.f_owned.assign(m, 1);
+  if (S.shard_world > 1)
+    for (int f = 0; f < m; ++f) {
+      int first = -1;
+      for (int q = P.f_key_ptr[f]; q < P.f_key_ptr[f + 1]; ++q)
+        if (first < 0 || S.pos[P.f_vars[q]] < S.pos[first]) first = P.f_vars[q];
+      const int o = first < 0 ? -1 : S.owner[S.front_of_var[first]];
+      S.f_owned[f] = o < 0 ? S.shard_rank == 0 : o == S.shard_rank;  // (factors of cap variables only: rank 0)
+    }
   // Size class of a front: 0 = leaf kernel (no children, few frontal scalars: only the n x F panel lives in LDS),
-  // 1 = small (whole front in LDS), 2 = big (blocked path in HBM).  A leaf is LEAN when its parent is big and every
+  // 1 = small (whole front in LDS), 2 = big (blocked path in HBM; every cap front, whatever its size, because its
+  // assembled state must exist in HBM for the exchange).  A leaf is LEAN when its parent is big and every
   // separator block fits a 16 x 16 matrix-core tile: its Schur complement is never materialised — the parent's
   // gather forms -L21 L21' block by block from the L panel — so it owns only n x F doubles of the arena and may
   // have any number of rows.
   S.lean.assign(nfr, 0);
   S.cls.assign(nfr, 1);
+  std::vector<int64_t> fsize(nfr);
   for (int f = 0; f < nfr; ++f) {
     const bool childless = S.child_ptr[f + 1] == S.child_ptr[f];
-    bool lean = childless && S.F[f] <= kLeafMaxF && S.F[f] > 0 && S.parent[f] >= 0 && S.N[S.parent[f]] > kSmallMaxN &&
-                (int64_t)S.N[f] * S.F[f] <= kLeafMaxPanel;
+    const int par = S.parent[f];
+    bool lean = !cap[f] && childless && S.F[f] <= kLeafMaxF && S.F[f] > 0 && par >= 0 &&
+                (S.N[par] > kSmallMaxN || cap[par]) && (int64_t)S.N[f] * S.F[f] <= kLeafMaxPanel;
     if (lean)
       for (int k = S.fvar_ptr[f] + nfv[f]; k < S.fvar_ptr[f + 1]; ++k) lean = lean && P.dims[S.fvars[k]] <= 16;
     S.lean[f] = lean;
     if (lean) S.cls[f] = 0;
-    else if (S.N[f] > kSmallMaxN) S.cls[f] = 2;
+    else if (S.N[f] > kSmallMaxN || cap[f]) S.cls[f] = 2;
     else if (childless && S.F[f] <= kLeafMaxF) S.cls[f] = 0;
     if (S.cls[f] == 2) S.n_big++; else S.n_small++;
     int64_t sz = lean ? (int64_t)S.N[f] * S.F[f] : (int64_t)S.N[f] * S.N[f];
     if (S.cls[f] == 2) sz = ((sz + 1) & ~int64_t(1)) + (int64_t)S.N[f] * S.F[f];  // + L-panel area (kernels.h)
-    S.off[f + 1] = S.off[f] + ((sz + 1) & ~int64_t(1));  // 16-byte aligned fronts
+    fsize[f] = (sz + 1) & ~int64_t(1);  // 16-byte aligned fronts
   }
-  S.arena_size = S.off[nfr];
-  for (int f = 0; f < nfr; ++f)  // children have smaller ids
-    if (S.parent[f] >= 0) S.level[S.parent[f]] = std::max(S.level[S.parent[f]], S.level[f] + 1);
+  {
+    // arena layout: the subtree fronts, then the cap fronts in one contiguous block (the exchange buffer)
+    int64_t cursor = 0;
+    for (int f = 0; f < nfr; ++f)
+      if (!cap[f]) {
+        S.off[f] = cursor;
+        cursor += fsize[f];
+      }
+    S.cap_begin = cursor;
+    for (int f = 0; f < nfr; ++f)
+      if (cap[f]) {
+        S.off[f] = cursor;
+        cursor += fsize[f];
+      }
+    S.cap_end = cursor;
+    S.off[nfr] = cursor;
+    S.arena_size = cursor;
+  }
   S.n_levels = 0;
   for (int f = 0; f < nfr; ++f) S.n_levels = std::max(S.n_levels, S.level[f] + 1);
   // ---- H panels and assembly terms (per variable) -----------------------------------------------------
@@ -302,6 +410,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
       int64_t c = 0;
       for (int k = vf_ptr[v]; k < vf_ptr[v + 1]; ++k) {
         const int f = vf[k];
+        if (!S.f_owned[f]) continue;
         c += 2;  // diagonal + rhs
         for (int q = P.f_key_ptr[f]; q < P.f_key_ptr[f + 1]; ++q)
           if (S.pos[P.f_vars[q]] > S.pos[v]) ++c;
@@ -324,6 +433,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
       int64_t t = S.term_ptr[v];
       for (int k = vf_ptr[v]; k < vf_ptr[v + 1]; ++k) {
         const int f = vf[k];
+        if (!S.f_owned[f]) continue;
         int colA = 0, col = 0;
         for (int q = P.f_key_ptr[f]; q < P.f_key_ptr[f + 1]; ++q) {
           if (P.f_vars[q] == v) colA = col;
@@ -405,8 +515,9 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
   }
   // ---- schedule: by level; inside a level: leaf-kernel fronts, other small (LDS) fronts by N, big fronts ----
   auto cls = [&](int f) { return (int)S.cls[f]; };
-  S.sched.resize(nfr);
-  std::iota(S.sched.begin(), S.sched.end(), 0);
+  S.sched.clear();
+  for (int f = 0; f < nfr; ++f)
+    if (S.scheduled[f]) S.sched.push_back(f);
   std::stable_sort(S.sched.begin(), S.sched.end(), [&](int a, int b) {
     if (S.level[a] != S.level[b]) return S.level[a] < S.level[b];
     const int ca = cls(a), cb = cls(b);
@@ -417,7 +528,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
   S.lvl_ptr.assign(S.n_levels + 1, 0);
   S.lvl_small_end.assign(S.n_levels, 0);
   S.lvl_leaf_end.assign(S.n_levels, 0);
-  for (int f = 0; f < nfr; ++f) S.lvl_ptr[S.level[f] + 1]++;
+  for (int f : S.sched) S.lvl_ptr[S.level[f] + 1]++;
   for (int l = 0; l < S.n_levels; ++l) S.lvl_ptr[l + 1] += S.lvl_ptr[l];
   for (int l = 0; l < S.n_levels; ++l) {
     int e = S.lvl_ptr[l];
@@ -436,7 +547,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     std::vector<Contribution> cs;
     std::vector<int> lo;  // local scalar offsets of the parent's variables
     for (int p = 0; p < nfr; ++p) {
-      if (S.cls[p] != 2) continue;
+      if (S.cls[p] != 2 || !S.scheduled[p]) continue;
       // parent local offset of each variable
       std::vector<std::pair<int, int>> ploc;  // (var, offset)
       int o = 0;
@@ -446,6 +557,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
       }
       for (int ci = S.child_ptr[p]; ci < S.child_ptr[p + 1]; ++ci) {
         const int ch = S.children[ci];
+        if (!S.scheduled[ch]) continue;  // another rank's subtree: its contribution arrives with the exchange
         const int Fc = S.F[ch], Nc = S.N[ch];
         // child's separator blocks: (parent offset, child offset, dim); the rhs is the last block
         std::vector<int> poff, coff, dim;
@@ -470,7 +582,9 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
         for (int a = 0; a < nb; ++a)
           for (int b = a; b < nb; ++b) {  // block (row b, col a), b >= a
             Contribution c;
-            c.level = S.level[p];
+            // a subtree's contribution to a cap front goes in with the first cap level, before the exchange; the cap
+            // fronts' own contributions follow level by level after it, the same on every rank
+            c.level = (S.owner[p] < 0 && S.owner[ch] >= 0) ? S.cap_level0 : S.level[p];
             c.dst = S.off[p] + poff[b] + (int64_t)poff[a] * S.N[p];
             c.ld = S.N[p];
             c.dims = dim[b] | (dim[a] << 8) | ((a == b) ? (1 << 16) : 0);

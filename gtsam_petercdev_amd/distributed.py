@@ -1,7 +1,7 @@
-"""One-process-per-GPU helpers used by bench.py (torch.distributed: backend "nccl" = RCCL on ROCm,
-"gloo" in the CPU tests).  The hot path itself has no data-path collective in the replica mode of
-round 1; these helpers only do what the bench contract needs: rendezvous from the
-torchrun environment, a barrier, and MAX-over-ranks of the timed region."""
+"""One-process-per-GPU helpers (torch.distributed: backend "nccl" = RCCL on ROCm, "gloo" in the CPU tests and the
+one-GPU rehearsals): rendezvous from the torchrun environment, a barrier, MAX-over-ranks of the timed region for the
+bench contract, and the all-reduce a SHARDED handle calls (include/gsx.h: gsx_set_shard) — the one data-path
+collective of the hot path: the sum of every rank's share of the cap fronts, once per factorization."""
 from __future__ import annotations
 
 import os
@@ -45,3 +45,29 @@ def aggregate_throughput(dist, steps: int, elapsed_local: float, device="cpu"):
     world = env_rank()[2]
     elapsed = max_over_ranks(dist, elapsed_local, device)
     return world * steps / elapsed, 1e3 * elapsed / steps
+
+
+class _DeviceDoubles:
+    """`count` doubles of device memory at `ptr`, as something torch.as_tensor aliases without a copy."""
+
+    def __init__(self, ptr: int, count: int):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def torch_allreduce(dist, device, group=None):
+    """allreduce(ptr, count) for ProductBackend.set_shard on top of torch.distributed.  backend "nccl": RCCL sums the
+    library's own buffer in place (over xGMI between the GPUs of a node); backend "gloo" (rehearsals with several ranks
+    on one GPU, where RCCL refuses duplicate devices): staged through host memory."""
+    import torch
+    staged = dist.get_backend(group) != "nccl"
+
+    def allreduce(ptr: int, count: int):
+        t = torch.as_tensor(_DeviceDoubles(ptr, count), device=device)
+        if staged:
+            h = t.cpu()
+            dist.all_reduce(h, group=group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, group=group)
+        torch.cuda.synchronize(device)
+    return allreduce

@@ -263,6 +263,43 @@ gsx_status gsx_compute_ordering(gsx_handle h, int32_t kind, uint64_t* keys_out);
  * <= max_frontal_dim: fewer, larger cliques, i.e. fewer levels and kernel launches on the latency-bound chains of
  * the elimination tree.  The solution is unchanged (zeros are factored as zeros); only gsx_get_tree differs. */
 gsx_status gsx_set_amalgamation(gsx_handle h, double relax, int32_t max_frontal_dim);
+/* ---- one problem over the GPUs of a node -------------------------------------------------------
+ * The reference has no distributed solver; the seam is the same as everywhere else in this header — the handle
+ * stands in for NonlinearOptimizer::solve()/iterate() — and the partition is the multifrontal one: subtrees of the
+ * Bayes tree are independent until their Schur complements meet in a common ancestor
+ * (gtsam/inference/ClusterTree-inst.h:256-265), and the solve hands only x_S down
+ * (gtsam/linear/linearAlgorithms-inst.h:60-62).
+ *
+ * One process per GPU; every rank creates its handle from the SAME problem, values and ordering and calls
+ * gsx_set_shard before gsx_set_ordering.  The next gsx_set_ordering then splits the tree into a CAP (the top fronts,
+ * whose subtrees are too heavy to give to one rank) and the forest below it, dealt to the ranks by cost.  A rank
+ * linearizes the factors of its subtrees, assembles and eliminates their fronts, and adds its share into the cap
+ * fronts; ONE sum all-reduce of the cap's contiguous arena block per factorization completes them, after which every
+ * rank factors and back-substitutes the cap alike (identical bits in, identical bits out) and solves its own
+ * subtrees.  Errors and status counters are summed the same way before the host reads them, so the LM policy takes
+ * the same decisions on every rank.  A rank keeps only its own variables (and the cap's) up to date between
+ * iterations; gsx_get_values and gsx_solve(delta_out) complete the vector with one more all-reduce.
+ *
+ * allreduce(user, device_buffer, count): in-place SUM of `count` doubles of device memory over all ranks, complete
+ * (device-visible) when it returns; non-zero return = failure.  The library synchronizes its own stream before the
+ * call.  With torch.distributed this is dist.all_reduce on a tensor aliasing the pointer (backend "nccl" = RCCL over
+ * xGMI); a C++ host would call ncclAllReduce.  In a sharded handle EVERY entry point is collective: all ranks call it
+ * in the same order.  gsx_dogleg_optimize and gsx_marginal_covariance are not available on a sharded handle
+ * (GSX_E_STATE).  world = 1 (the default) is the single-GPU path, bit for bit. */
+typedef int32_t (*gsx_allreduce_fn)(void* user, double* device_buffer, int64_t count);
+gsx_status gsx_set_shard(gsx_handle h, int32_t rank, int32_t world, gsx_allreduce_fn allreduce, void* user);
+typedef struct gsx_shard_info {
+  int32_t rank, world;
+  int32_t n_cap_fronts;          /* fronts of the cap (processed by every rank)            */
+  int32_t n_own_fronts;          /* fronts of this rank's subtrees                         */
+  int32_t cap_level0;            /* first level of the cap in the schedule, -1: no cap     */
+  int32_t n_own_factors;         /* factors this rank linearizes                           */
+  int64_t cap_doubles;           /* size of the per-factorization all-reduce               */
+  double cap_flops, own_flops, total_flops;  /* elimination flop estimates: cap, own subtrees, whole tree */
+} gsx_shard_info;
+/* partition of the current ordering: front_owner[n_fronts] = owning rank or -1 (cap), factor_owned[n_factors] = 1
+ * when this rank linearizes the factor; either array may be NULL */
+gsx_status gsx_get_shard(gsx_handle h, gsx_shard_info* info, int32_t* front_owner, int32_t* factor_owned);
 gsx_status gsx_get_ordering(gsx_handle h, uint64_t* keys_out);
 /* Bayes-tree structure for parity checks: per front the frontal / separator
  * variable indices (CSR) and the parent front (-1 = root).  Pass NULL arrays to

@@ -1,0 +1,111 @@
+"""ONE problem sharded over several ranks (include/gsx.h: gsx_set_shard): the partition on the host, and —
+on the GPU box — world-size 2 and 3 runs whose ranks share the one GPU and exchange over gloo, compared with the
+single-GPU handle on the same inputs.  Tolerances: the sharded solve adds the same numbers in a different order (a cap
+front sums per-rank partial assemblies), so steps agree to 1e-9 relative, LM error traces to 1e-8, and the LM accept /
+reject decisions are identical."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from gtsam_petercdev_amd import _abi as A, _lib, datasets
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("kind", ["pose3", "bal"])
+def test_partition_properties(kind, world):
+    """Host side only: every rank derives the same partition; the cap is closed upwards; what hangs below it is dealt out
+    whole; every factor is linearized by exactly one rank; the Bayes tree itself is the unsharded one."""
+    if kind == "pose3":
+        arr, okind = datasets.synth_manhattan_pose3(3000, seed=2), A.ORDER_ND
+    else:
+        arr, okind = datasets.synth_bal_arrays(40, 2500, 11000, seed=2, long_range=0.3), A.ORDER_SCHUR_ND
+    plain = _lib.ProductBackend(arr, host_only=True)
+    ordering = plain.compute_ordering(okind)
+    plain.set_ordering(ordering)
+    parent, fronts = plain.get_tree()
+    owners, owned = [], []
+    for rank in range(world):
+        be = _lib.ProductBackend(arr, host_only=True)
+        be.set_shard(rank, world, lambda ptr, count: None)
+        be.set_ordering(ordering)
+        p2, f2 = be.get_tree()
+        assert list(p2) == list(parent) and f2 == fronts
+        info, owner, fo = be.shard_info()
+        assert info["rank"] == rank and info["world"] == world
+        assert info["n_own_fronts"] == int((owner == rank).sum()) and info["n_cap_fronts"] == int((owner < 0).sum())
+        assert info["n_own_factors"] == int(fo.sum())
+        owners.append(owner)
+        owned.append(fo)
+    for o in owners[1:]:
+        assert np.array_equal(o, owners[0])
+    owner = owners[0]
+    assert set(owner.tolist()) <= set(range(-1, world))
+    for f, p in enumerate(parent):
+        if p < 0:
+            continue
+        if owner[f] < 0:
+            assert owner[p] < 0                      # the cap is closed upwards
+        elif owner[p] >= 0:
+            assert owner[p] == owner[f]              # a subtree stays whole
+    assert np.array_equal(np.sum(owned, axis=0), np.ones(arr.n_factors, int))   # each factor exactly once
+    # the deal is by cost: no rank is idle when there is more than one subtree
+    if len({f for f, p in enumerate(parent) if owner[f] >= 0 and (p < 0 or owner[p] < 0)}) >= world:
+        assert all((owner == r).any() for r in range(world))
+
+
+def test_set_shard_argument_checks():
+    arr = datasets.synth_manhattan_pose2(50, seed=1)
+    be = _lib.ProductBackend(arr, host_only=True)
+    for rank, world in ((-1, 2), (2, 2), (0, 0)):
+        with pytest.raises(A.GsxError):
+            be.set_shard(rank, world, lambda p, n: None)
+    be.set_ordering(be.compute_ordering(A.ORDER_ND))
+    with pytest.raises(A.GsxError) as ei:
+        be.set_shard(0, 2, lambda p, n: None)       # after the symbolic analysis: too late
+    assert ei.value.status == A.GSX_E_STATE
+
+
+def _run_workers(world):
+    port = 29600 + (os.getpid() % 2000) + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "_shard_worker.py")]
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_solve_matches_single_gpu(world):
+    res = _run_workers(world)
+    assert res["world"] == world and len(res["ranks"]) == world
+    assert res["allreduce_calls"]["n"] > 0
+    for name in res["ranks"][0]:
+        per_rank = [r[name] for r in res["ranks"]]
+        for r in per_rank:
+            assert abs(r["error0"][0] - r["error0"][1]) <= 1e-12 * abs(r["error0"][1]), name
+            assert r["hdiag"] < 1e-12, name
+            for s in r["steps"]:
+                assert s["delta"] < 1e-9, (name, s)
+                assert np.allclose(s["lin"][0], s["lin"][1], rtol=1e-10), (name, s)
+                assert abs(s["trial"][0] - s["trial"][1]) <= 1e-9 * abs(s["trial"][1]), (name, s)
+            for run in r["lm"]:
+                assert run["accepted"][0] == run["accepted"][1], (name, run)
+                assert abs(run["final"][0] - run["final"][1]) <= 1e-8 * abs(run["final"][1]), (name, run)
+                assert run["trace"] < 1e-8 and run["values"] < 1e-7, (name, run)
+                assert run["final"][0] < run["initial"], (name, run)
+            if isinstance(r["gn"], list):
+                assert abs(r["gn"][0] - r["gn"][1]) <= 1e-8 * abs(r["gn"][1]), name
+            assert r["marginal_refused"], name
+        # every rank reports the same numbers: the ranks take the same LM decisions from identical sums
+        for r in per_rank[1:]:
+            assert r["lm"] == per_rank[0]["lm"] and r["steps"] == per_rank[0]["steps"], name
+        # a real split: a cap plus subtrees on every rank
+        assert per_rank[0]["info"]["n_cap_fronts"] >= 1 and len(per_rank[0]["owners"]) == world + 1, name
