@@ -47,6 +47,13 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the N>1 path on a box "
                          "with fewer GPUs than ranks)")
+    ap.add_argument("--shard", action="store_true",
+                    help="N>1: the ranks solve ONE problem together (gsx_set_shard: cap + subtrees, one all-reduce of the "
+                         "cap per factorization) instead of one replica each; strong scaling")
+    ap.add_argument("--shard-share", type=int, default=0, metavar="W",
+                    help="N=1 only: time rank 0's share of a W-way sharded problem with the exchange stubbed out (rank 0 "
+                         "carries the cap's damping, so its system stays positive definite): the compute on the critical "
+                         "path of a W-GPU run, without the all-reduce")
     return ap.parse_args()
 
 
@@ -140,8 +147,25 @@ def main():
         dist = D.init(args.backend, torch.device("cuda", device) if args.backend == "nccl" else None)
     red_dev = "cuda" if (dist is not None and args.backend == "nccl") else "cpu"
 
-    arrays, default_order = make_problem(args.workload, seed=D.replica_seed(42))
+    sharded = (args.shard and world > 1) or args.shard_share > 1
+    arrays, default_order = make_problem(args.workload, seed=42 if sharded else D.replica_seed(42))
     be = _lib.product_backend(arrays, device=device)
+    exchange = {"calls": 0, "doubles": 0, "seconds": 0.0}
+    if sharded:
+        if args.shard_share > 1:
+            inner = lambda ptr, count: None
+            shard_rank, shard_world = 0, args.shard_share
+        else:
+            inner = D.torch_allreduce(dist, torch.device("cuda", device))
+            shard_rank, shard_world = rank, world
+
+        def allreduce(ptr, count):
+            t_ex = time.perf_counter()
+            inner(ptr, count)
+            exchange["seconds"] += time.perf_counter() - t_ex
+            exchange["calls"] += 1
+            exchange["doubles"] += count
+        be.set_shard(shard_rank, shard_world, allreduce)
     okind = {"schur": A.ORDER_SCHUR, "schur_nd": A.ORDER_SCHUR_ND, "mindegree": A.ORDER_MINDEGREE,
              "nd": A.ORDER_ND}[args.ordering or default_order]
     t0 = time.time()
@@ -158,10 +182,10 @@ def main():
     lam = args.lam
 
     def step():
-        be.linearize()
-        be.solve(lam, False, want_delta=False)
-        be.linear_error()
-        be.retract(None, commit=False)
+        # one LM inner iteration without the policy: linearize, H assembly, damped factorization, back-substitution,
+        # both linearized errors, retract, nonlinear error of the trial point — one host synchronisation, as in
+        # gsx_lm_optimize
+        be.lm_trial(True, lam, False)
 
     def barrier():
         if dist is not None:
@@ -173,12 +197,17 @@ def main():
         step()
     be.reset_stats()
     barrier()
+    for k in exchange:
+        exchange[k] = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
     value, ms_step = D.aggregate_throughput(dist, args.steps, elapsed, device=red_dev)
+    if sharded and world > 1:
+        value /= world   # ONE job: its iterations per second, not the sum over replicas
+    exchange_timed = dict(exchange)
     st = be.stats()
     ms_solve = (st["ms_factorize"] + st["ms_backsolve"]) / max(st["n_factorize"], 1)
 
@@ -231,9 +260,13 @@ def main():
     out = {
         "metric": "lm_iterations_per_sec", "value": value, "unit": "LM iterations/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "scaling": "strong" if (sharded and world > 1) else "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
         "config": {"workload": args.workload, "shape": arrays.meta, "ordering": args.ordering or default_order,
-                   "amalgamation": {"relax": relax, "max_frontal_dim": relax_maxf}, "lambda": lam, "replicas": world},
+                   "amalgamation": {"relax": relax, "max_frontal_dim": relax_maxf}, "lambda": lam,
+                   "replicas": 1 if sharded else world,
+                   "parallelism": (f"shard{world}" if world > 1 else f"rank 0 of shard{args.shard_share}, exchange "
+                                   "stubbed") if sharded else f"replicas{world}"},
         "ms_per_linear_solve": ms_solve,
         "phases_ms": phases,
         "factor_leaf_ms": tot_leaf, "factor_small_ms": tot_small, "factor_big_ms": tot_big,
@@ -243,11 +276,19 @@ def main():
         "front_split": split, "kernels": per_kernel, "host_ordering_s": t_order, "host_symbolic_s": t_symbolic,
         "roofline": roofline,
     }
+    if sharded:
+        info, owner, _ = be.shard_info()
+        out["shard"] = dict(info, exchange_calls_per_step=exchange_timed["calls"] / args.steps,
+                            exchange_mb_per_step=8e-6 * exchange_timed["doubles"] / args.steps,
+                            exchange_ms_per_step=1e3 * exchange_timed["seconds"] / args.steps,
+                            fronts_per_rank=[int((owner == r).sum()) for r in range(info["world"])])
+        # the per-kernel table above holds THIS rank's launches against whole-tree algorithmic amounts: not a roofline
+        out["roofline"] = None
     out["config"]["shape"] = {k: (v if not hasattr(v, "tolist") else None) for k, v in arrays.meta.items()
                               if not hasattr(v, "shape")}
 
     # ---- CPU baseline: the oracle ("port", 1 thread) on a bounded sample of the same workload ---------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not sharded and not args.no_cpu_baseline:
         from oracle import oracle as orc
         ob = orc.oracle_backend(arrays)
         ob.set_ordering(ordering)

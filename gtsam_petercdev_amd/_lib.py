@@ -86,6 +86,14 @@ class ProductBackend(A.Backend):
         d = {k: getattr(info, k) for k, _ in ShardInfo._fields_}
         return d, owner[:n.value], owned[:self.arrays.n_factors]
 
+    def lm_trial(self, relinearize=True, lam=0.0, diagonal_damping=False, min_diagonal=1e-6, max_diagonal=1e32):
+        """One LM trial without the policy (gsx_lm_trial): (linear error at 0, at delta, nonlinear error of the trial)."""
+        e0, ed, et = C.c_double(), C.c_double(), C.c_double()
+        self._check(self._fn("lm_trial")(self._h, C.c_int32(int(relinearize)), C.c_double(lam),
+                                         C.c_int32(int(diagonal_damping)), C.c_double(min_diagonal),
+                                         C.c_double(max_diagonal), C.byref(e0), C.byref(ed), C.byref(et)), "lm_trial")
+        return e0.value, ed.value, et.value
+
     def stats(self) -> dict:
         s = A.Stats()
         self._check(self._fn("get_stats")(self._h, C.byref(s)), "get_stats")

@@ -1291,6 +1291,38 @@ gsx_status gsx_lm_iterate(gsx_handle h, const gsx_lm_params* p, double* error, d
   return GSX_OK;
 }
 
+gsx_status gsx_lm_trial(gsx_handle h, int32_t relinearize, double lambda, int32_t diagonal_damping, double min_diagonal,
+                        double max_diagonal, double* lin0, double* lind, double* trial_error) {
+  if (!h || !(lambda >= 0.0)) return GSX_E_INVALID;
+  gsx_status st = ensure_ready(h, true, true);
+  if (st != GSX_OK) return st;
+  if (!relinearize && !h->linearized) {
+    h->err = "linearize first";
+    return GSX_E_STATE;
+  }
+  hipSetDevice(h->device);
+  if (relinearize) dev_linearize(h);
+  if (!h->h_ready) dev_assemble_h(h);
+  dev_damping(h, diagonal_damping, min_diagonal, max_diagonal);
+  dev_factorize(h, lambda);
+  dev_backsolve(h);
+  dev_linear_error(h);
+  dev_retract(h, h->d_delta.p);
+  dev_error(h, h->d_trial.p, SC_TRIAL_ERR);
+  st = readback(h);
+  if (st != GSX_OK) return st;
+  if (h->h_status->n_fail > 0 || h->h_status->n_nonfinite > 0) {
+    h->solved = false;
+    h->err = "indeterminate linear system";
+    return GSX_E_INDETERMINATE;
+  }
+  h->solved = true;
+  if (lin0) *lin0 = h->h_scalars[SC_LIN0];
+  if (lind) *lind = h->h_scalars[SC_LIND];
+  if (trial_error) *trial_error = h->h_scalars[SC_TRIAL_ERR];
+  return GSX_OK;
+}
+
 // NonlinearOptimizer::defaultOptimize — gtsam/nonlinear/NonlinearOptimizer.cpp:62-117
 gsx_status gsx_lm_optimize(gsx_handle h, const gsx_lm_params* p, gsx_lm_result* r) {
   if (!h || !p) return GSX_E_INVALID;

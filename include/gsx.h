@@ -345,6 +345,14 @@ gsx_status gsx_lm_optimize(gsx_handle h, const gsx_lm_params* p, gsx_lm_result* 
 gsx_status gsx_lm_reset(gsx_handle h, const gsx_lm_params* p);
 gsx_status gsx_lm_iterate(gsx_handle h, const gsx_lm_params* p, double* error,
                           double* lambda);
+/* One LM trial without the accept/reject policy — the numeric body of LevenbergMarquardtOptimizer::tryLambda
+ * (gtsam/nonlinear/LevenbergMarquardtOptimizer.cpp:121-230), preceded when relinearize != 0 by the linearization
+ * iterate() does (:252-262): damped solve, linearized error at 0 and at delta, retract into the trial values (the
+ * current values stay), nonlinear error there — with ONE host synchronisation, as inside gsx_lm_optimize.
+ * GSX_E_INDETERMINATE when the damped system cannot be factored. */
+gsx_status gsx_lm_trial(gsx_handle h, int32_t relinearize, double lambda, int32_t diagonal_damping,
+                        double min_diagonal, double max_diagonal, double* linear_error_0,
+                        double* linear_error_delta, double* trial_error);
 gsx_status gsx_gn_optimize(gsx_handle h, int32_t max_iterations, double relative_error_tol,
                            double absolute_error_tol, double error_tol, gsx_lm_result* r);
 /* DoglegOptimizer (gtsam/nonlinear/DoglegOptimizer.cpp:84-121; DoglegOptimizerImpl::Iterate in

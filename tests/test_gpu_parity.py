@@ -654,3 +654,22 @@ def test_planar_slam_parity(gpu, oracle, robust):
     for key in (int(arr.var_keys[0]), int(arr.var_keys[-1]), L(0) if L(0) in set(arr.var_keys.tolist()) else int(arr.var_keys[1])):
         cg, co = gb.marginal_covariance(key), ob.marginal_covariance(key)
         assert np.max(np.abs(cg - co)) <= 1e-7 * np.max(np.abs(co))
+
+
+def test_lm_trial_equals_separate_calls(gpu):
+    """gsx_lm_trial = linearize + damped solve + both linearized errors + retract + trial error in one call."""
+    arr = PROBLEMS["pose3"]
+    a, b = gpu.product_backend(arr), gpu.product_backend(arr)
+    ordering = a.compute_ordering(A.ORDER_ND)
+    a.set_ordering(ordering)
+    b.set_ordering(ordering)
+    for lam, diag in ((1e-3, False), (0.5, True)):
+        e0, ed, et = a.lm_trial(True, lam, diag)
+        b.linearize()
+        b.solve(lam, diag, want_delta=False)
+        f0, fd = b.linear_error()
+        ft = b.retract(None, commit=False)
+        assert (e0, ed, et) == (f0, fd, ft)
+    with pytest.raises(gt.GsxError) as ei:
+        gpu.product_backend(arr).lm_trial(True, 0.0, False)   # no ordering yet
+    assert ei.value.status == A.GSX_E_STATE
