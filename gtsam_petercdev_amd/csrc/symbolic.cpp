@@ -242,7 +242,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
   // sub[f] = flop estimate of f's whole subtree.  Fronts with sub[f] above a share of the total form the cap (an
   // upward-closed set: a parent's subtree contains its children's); what hangs below the cap is a forest of independent
   // subtrees, dealt to the ranks largest first onto the least loaded rank.  The share is chosen among a few candidates
-  // to minimise cap + heaviest rank.  All ranks compute the same partition from the same inputs.
+  // to minimise (weighted) cap + heaviest rank.  All ranks compute the same partition from the same inputs.
   S.owner.assign(nfr, 0);
   std::vector<char> cap(nfr, 0);
   if (S.shard_world > 1) {
@@ -263,7 +263,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     std::vector<char> best_cap;
     double best = -1, best_capc = 0;
     std::vector<double> load(S.shard_world);
-    for (double alpha : {1.0, 2.0, 4.0, 8.0, 16.0, 32.0}) {
+    for (double alpha : {0.51, 1.0, 2.0, 4.0, 8.0, 16.0, 32.0}) {  // (> 1/2: at least the root is cap, the work is split)
       const double tau = total / (S.shard_world * alpha);
       double capc = 0;
       roots.clear();
@@ -283,8 +283,11 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
         load[k] += sub[r];
       }
       const double worst = *std::max_element(load.begin(), load.end());
-      if (best < 0 || capc + worst < best) {
-        best = capc + worst;
+      // a cap flop costs more time than a subtree flop: the cap's few large fronts run one panel step per launch
+      // (latency-bound), the subtrees' many fronts fill the GPU — 2x brackets the measured shares
+      const double est = 2.0 * capc + worst;
+      if (best < 0 || est < best) {
+        best = est;
         best_capc = capc;
         best_cap = cap;
         best_assign = assign;

@@ -3,7 +3,7 @@
 # usage: tools/shard_share.sh OUTDIR
 out=${1:-gpurun_out/shard}
 mkdir -p "$out"
-for wl in pose3_100k pose2_100k; do
+for wl in pose3_100k pose2_100k bal1723; do
   python bench.py --workload $wl --steps 20 --warmup 3 --no-cpu-baseline > "$out/${wl}_n1.json" || exit 1
   for w in 2 4 8; do
     python bench.py --workload $wl --steps 20 --warmup 3 --no-cpu-baseline --shard-share $w > "$out/${wl}_share$w.json" || exit 1
