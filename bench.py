@@ -54,6 +54,11 @@ def parse():
                     help="N=1 only: time rank 0's share of a W-way sharded problem with the exchange stubbed out (rank 0 "
                          "carries the cap's damping, so its system stays positive definite): the compute on the critical "
                          "path of a W-GPU run, without the all-reduce")
+    ap.add_argument("--shard-extra", default="pose3_100k", metavar="WORKLOAD|none",
+                    help="N>1 in the default replica mode: after the timed replicas, rank 0 also starts a separate N-rank "
+                         "`--shard` run of this workload (own processes, hard time limit) and attaches its result under "
+                         "\"shard_run\" — the strong-scaling number next to the weak-scaling headline; 'none' to skip")
+    ap.add_argument("--shard-extra-timeout", type=float, default=240.0)
     return ap.parse_args()
 
 
@@ -130,6 +135,45 @@ def pmc_traffic(kernel, workload):
         return k["fetch_bytes"] + k["write_bytes"], os.path.relpath(path, ROOT)
     except (OSError, KeyError, ValueError):
         return None, None
+
+
+def run_shard_child(world, workload, backend, timeout_s):
+    """The sharded solve as a child job of its own (torchrun, `world` ranks, its own rendezvous port), so that nothing it
+    does — an error, a hang — can take the replica measurement down with it: killed as a process group at the limit."""
+    import signal
+    import subprocess
+    port = int(os.environ.get("MASTER_PORT", "29500")) + 23
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", str(world), "--shard", "--workload", workload, "--steps", "20", "--warmup", "3",
+           "--no-cpu-baseline", "--backend", backend]
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "GROUP_RANK", "ROLE_RANK",
+                        "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT",
+                        "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    t0 = time.perf_counter()
+    try:
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT,
+                                start_new_session=True)
+    except OSError as e:
+        return {"error": f"could not start: {e!r}"}
+    try:
+        so, se = proc.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)   # exactly the group started above
+        except OSError:
+            pass
+        so, se = proc.communicate()
+        return {"error": f"no result within {timeout_s:.0f} s (killed)", "stderr_tail": (se or "")[-400:]}
+    lines = [l for l in (so or "").splitlines() if l.startswith("{")]
+    if proc.returncode != 0 or not lines:
+        return {"error": f"exit code {proc.returncode}", "stderr_tail": (se or "")[-400:]}
+    d = json.loads(lines[-1])
+    return {"workload": workload, "n_gpus": d["n_gpus"], "scaling": d["scaling"], "value": d["value"], "unit": d["unit"],
+            "ms_per_step": d["ms_per_step"], "ms_per_linear_solve": d["ms_per_linear_solve"], "shard": d.get("shard"),
+            "phases_ms": d["phases_ms"], "wall_s": time.perf_counter() - t0}
 
 
 def main():
@@ -310,6 +354,19 @@ def main():
             "phases_s": {k: v / args.cpu_iters for k, v in tm.items()}, "host_cpus": os.cpu_count(),
         }
         out["speedup_vs_cpu_port"] = value / out["cpu_baseline"]["value"]
+    if dist is not None and not sharded and args.shard_extra != "none":
+        # the other ranks wait on the host (a key of the rendezvous store), their GPUs idle, while rank 0's child job runs
+        from torch.distributed.distributed_c10d import _get_default_store
+        store = _get_default_store()
+        if rank == 0:
+            try:
+                out["shard_run"] = run_shard_child(world, args.shard_extra, args.backend, args.shard_extra_timeout)
+            except Exception as e:  # the headline line below must come out whatever happens here
+                out["shard_run"] = {"error": repr(e)}
+            store.set("gsx_shard_extra_done", "1")
+        else:
+            from datetime import timedelta
+            store.wait(["gsx_shard_extra_done"], timedelta(seconds=args.shard_extra_timeout + 120))
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -263,7 +263,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     std::vector<char> best_cap;
     double best = -1, best_capc = 0;
     std::vector<double> load(S.shard_world);
-    for (double alpha : {0.51, 1.0, 2.0, 4.0, 8.0, 16.0, 32.0}) {  // (> 1/2: at least the root is cap, the work is split)
+    for (double alpha : {0.51, 0.71, 1.0, 1.41, 2.0, 2.83, 4.0, 5.66, 8.0, 16.0, 32.0}) {  // (> 1/2: at least the root is cap, the work is split)
       const double tau = total / (S.shard_world * alpha);
       double capc = 0;
       roots.clear();
