@@ -18,6 +18,7 @@ import numpy as np
 GSX_OK, GSX_E_INVALID, GSX_E_NO_DEVICE, GSX_E_BAD_ORDERING, GSX_E_INDETERMINATE, GSX_E_STATE, GSX_E_NOMEM = range(7)
 VAR_VECTOR, VAR_POSE2, VAR_POSE3, VAR_CAMERA = range(4)
 F_LINEAR, F_PRIOR, F_BETWEEN, F_SFM, F_PROJECTION, F_BEARINGRANGE = range(6)
+NOISE_FORMAT_G2O, NOISE_FORMAT_TORO, NOISE_FORMAT_GRAPH, NOISE_FORMAT_COV, NOISE_FORMAT_AUTO = range(5)
 NOISE_UNIT, NOISE_ISOTROPIC, NOISE_DIAGONAL, NOISE_GAUSSIAN = range(4)
 NOISE_ROBUST_HUBER, NOISE_ROBUST_TUKEY, NOISE_ROBUST_CAUCHY, NOISE_BASE_MASK = 1 << 4, 2 << 4, 3 << 4, 15
 ORDER_NATURAL, ORDER_MINDEGREE, ORDER_ND, ORDER_SCHUR, ORDER_SCHUR_ND = range(5)
@@ -140,6 +141,21 @@ class ProblemArrays:
             setattr(self, n, a)
         if self.values is not None:
             self.values = c(self.values, dtype=np.float64)
+
+    def with_factor(self, f_type, var_indices, rows, meas, noise_kind, noise_params=()):
+        """A copy with one more factor appended (NonlinearFactorGraph::add on the lowered arrays), e.g. the prior the
+        reference's examples add after load2D (examples/Pose2SLAMExample_graph.cpp:44-47)."""
+        nm, nn = int(self.f_meas_ptr[-1]), int(self.f_noise_ptr[-1])
+        meas = np.asarray(meas, float).ravel()
+        npar = np.asarray(noise_params, float).ravel()
+        return ProblemArrays(
+            self.var_keys, self.var_types, self.var_dims,
+            np.append(self.f_type, f_type), np.append(self.f_rows, rows),
+            np.append(self.f_key_ptr, self.f_key_ptr[-1] + len(var_indices)), np.append(self.f_vars, var_indices),
+            np.append(self.f_meas_ptr, nm + meas.size), np.concatenate([self.meas[:nm], meas]),
+            np.append(self.f_noise_kind, noise_kind), np.append(self.f_noise_ptr, nn + npar.size),
+            np.concatenate([self.noise[:nn], npar]), None if self.values is None else self.values.copy(),
+            dict(self.meta))
 
     @property
     def n_vars(self):

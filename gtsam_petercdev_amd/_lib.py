@@ -153,6 +153,27 @@ def read_g2o(path: str, is3D: bool = False) -> A.ProblemArrays:
     return _dataset_to_arrays(ds, dict(kind="pose3" if is3D else "pose2", source=str(path)))
 
 
+def load2d(path: str, model_sigmas=None, max_index: int = 0, smart: bool = True,
+           noise_format: int = A.NOISE_FORMAT_AUTO, kernel: int = 0) -> A.ProblemArrays:
+    """load2D of the reference (gsx_load2d, include/gsx.h): TORO / "graph" 2-D files with poses, landmarks, odometry and
+    bearing-range measurements; landmark j has key Symbol('l', j)."""
+    lib = load()
+    lib.gsx_load2d.restype = C.c_int32
+    lib.gsx_dataset_get.restype = C.c_int32
+    lib.gsx_dataset_free.restype = None
+    ds = C.c_void_p()
+    ms = None
+    if model_sigmas is not None:
+        ms = np.ascontiguousarray(model_sigmas, dtype=np.float64)
+        assert ms.size == 3
+    st = lib.gsx_load2d(str(path).encode(), None if ms is None else ms.ctypes.data_as(C.POINTER(C.c_double)),
+                        C.c_int64(max_index), C.c_int32(int(smart)), C.c_int32(noise_format), C.c_int32(kernel),
+                        C.byref(ds))
+    if st != A.GSX_OK:
+        raise A.GsxError(st, "gsx_load2d", str(path))
+    return _dataset_to_arrays(ds, dict(kind="planar", source=str(path)))
+
+
 def read_bal(path: str, priors: bool = False) -> A.ProblemArrays:
     """Native BAL reader (gsx_read_bal, include/gsx.h)."""
     lib = load()

@@ -83,11 +83,120 @@ void so3_expmap(const double* w, double* R) {  // gtsam/geometry/SO3.cpp:61-96, 
   for (int i = 0; i < 9; ++i) R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + a * W[i] + b * WW[i];
 }
 
+// Rot3::Ypr(y, p, r) = Rz(y) Ry(p) Rx(r) (gtsam/geometry/Rot3.h), row-major
+void ypr_to_R(double y, double p, double r, double* R) {
+  const double cy = std::cos(y), sy = std::sin(y), cp = std::cos(p), sp = std::sin(p), cr = std::cos(r), sr = std::sin(r);
+  R[0] = cy * cp; R[1] = cy * sp * sr - sy * cr; R[2] = cy * sp * cr + sy * sr;
+  R[3] = sy * cp; R[4] = sy * sp * sr + cy * cr; R[5] = sy * sp * cr - cy * sr;
+  R[6] = -sp;     R[7] = cp * sr;                R[8] = cp * cr;
+}
+// packed Pose3 states (R row-major, then t)
+std::vector<double> pose3_compose(const std::vector<double>& a, const std::vector<double>& b) {
+  std::vector<double> c(12);
+  for (int r = 0; r < 3; ++r) {
+    for (int k = 0; k < 3; ++k) c[r * 3 + k] = a[r * 3] * b[k] + a[r * 3 + 1] * b[3 + k] + a[r * 3 + 2] * b[6 + k];
+    c[9 + r] = a[9 + r] + a[r * 3] * b[9] + a[r * 3 + 1] * b[10] + a[r * 3 + 2] * b[11];
+  }
+  return c;
+}
+std::vector<double> pose3_inverse(const std::vector<double>& a) {
+  std::vector<double> c(12);
+  for (int r = 0; r < 3; ++r) {
+    for (int k = 0; k < 3; ++k) c[r * 3 + k] = a[k * 3 + r];
+    c[9 + r] = -(a[r] * a[9] + a[3 + r] * a[10] + a[6 + r] * a[11]);
+  }
+  return c;
+}
+
+// createNoiseModel (gtsam/slam/dataset.cpp:216-296) for the six numbers of a 2-D edge; appends kind and parameters.
+// smart: Gaussian::Information / Covariance with smart = true fall through Diagonal -> Isotropic -> Unit when the matrix
+// allows (gtsam/linear/NoiseModel.cpp:98-131, 284-315, 625-634).
+bool emit_noise_2d(const double v[6], int format, bool smart, int kernel, gsx_dataset* D, std::string* err);
+
 struct Edge {
   long long i, j;
   std::vector<double> z;  // measurement in packed state layout
   std::vector<double> R;  // d x d upper factor
 };
+
+bool emit_noise_2d(const double v[6], int format, bool smart, int kernel, gsx_dataset* D, std::string* err) {
+  if (format == GSX_NOISE_FORMAT_AUTO) {
+    if (v[0] != 0.0 && v[1] == 0.0 && v[2] != 0.0 && v[3] != 0.0 && v[4] == 0.0 && v[5] == 0.0) format = GSX_NOISE_FORMAT_GRAPH;
+    else if (v[0] != 0.0 && v[1] == 0.0 && v[2] == 0.0 && v[3] != 0.0 && v[4] == 0.0 && v[5] != 0.0) format = GSX_NOISE_FORMAT_COV;
+    else {
+      *err = "load2D: unrecognized covariance matrix format in dataset file";
+      return false;
+    }
+  }
+  double M[9];
+  if (format == GSX_NOISE_FORMAT_G2O || format == GSX_NOISE_FORMAT_COV) {
+    if (v[0] == 0.0 || v[3] == 0.0 || v[5] == 0.0) {
+      *err = "load2D: not G2O matrix order";
+      return false;
+    }
+    const double m[9] = {v[0], v[1], v[2], v[1], v[3], v[4], v[2], v[4], v[5]};
+    std::copy(m, m + 9, M);
+  } else {
+    if (v[0] == 0.0 || v[2] == 0.0 || v[3] == 0.0) {
+      *err = "load2D: not TORO matrix order";
+      return false;
+    }
+    const double m[9] = {v[0], v[1], v[4], v[1], v[2], v[5], v[4], v[5], v[3]};
+    std::copy(m, m + 9, M);
+  }
+  const bool is_cov = format == GSX_NOISE_FORMAT_GRAPH || format == GSX_NOISE_FORMAT_COV;
+  const bool diagonal = std::abs(M[1]) <= 1e-9 && std::abs(M[2]) <= 1e-9 && std::abs(M[5]) <= 1e-9;  // checkIfDiagonal
+  int kind;
+  std::vector<double> params;
+  if (smart && diagonal) {
+    double var[3] = {M[0], M[4], M[8]};
+    if (!is_cov)
+      for (double& q : var) q = 1.0 / q;  // Precisions -> Variances
+    if (var[0] == var[1] && var[0] == var[2]) {
+      if (std::abs(var[0] - 1.0) < 1e-9) {
+        kind = GSX_NOISE_UNIT;
+      } else {
+        kind = GSX_NOISE_ISOTROPIC;
+        params = {std::sqrt(var[0])};
+      }
+    } else {
+      kind = GSX_NOISE_DIAGONAL;
+      params = {std::sqrt(var[0]), std::sqrt(var[1]), std::sqrt(var[2])};
+    }
+  } else {
+    double I[9];
+    if (is_cov) {  // Information(covariance.inverse(), false)
+      const double det = M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) +
+                         M[2] * (M[3] * M[7] - M[4] * M[6]);
+      if (det == 0.0) {
+        *err = "load2D: singular covariance";
+        return false;
+      }
+      const double a[9] = {M[4] * M[8] - M[5] * M[7], M[2] * M[7] - M[1] * M[8], M[1] * M[5] - M[2] * M[4],
+                           M[5] * M[6] - M[3] * M[8], M[0] * M[8] - M[2] * M[6], M[2] * M[3] - M[0] * M[5],
+                           M[3] * M[7] - M[4] * M[6], M[1] * M[6] - M[0] * M[7], M[0] * M[4] - M[1] * M[3]};
+      for (int k = 0; k < 9; ++k) I[k] = a[k] / det;
+    } else {
+      std::copy(M, M + 9, I);
+    }
+    kind = GSX_NOISE_GAUSSIAN;
+    params.resize(9);
+    if (!chol_upper(I, 3, params.data())) {
+      *err = "load2D: information matrix is not positive definite";
+      return false;
+    }
+  }
+  if (kernel == 1) {  // KernelFunctionTypeHUBER: mEstimator::Huber::Create(1.345)
+    kind |= GSX_NOISE_ROBUST_HUBER;
+    params.push_back(1.345);
+  } else if (kernel == 2) {  // KernelFunctionTypeTUKEY: mEstimator::Tukey::Create(4.6851)
+    kind |= GSX_NOISE_ROBUST_TUKEY;
+    params.push_back(4.6851);
+  }
+  D->f_noise_kind.push_back(kind);
+  D->noise.insert(D->noise.end(), params.begin(), params.end());
+  return true;
+}
 
 }  // namespace
 
@@ -129,6 +238,32 @@ gsx_status gsx_read_g2o(const char* path, int32_t is3d, gsx_dataset** out) {
       quat_to_R(qw, qx, qy, qz, s.data());
       s[9] = x; s[10] = y; s[11] = z;
       states[id] = s;
+    } else if (is3d && tag == "VERTEX3") {
+      // TORO: id x y z roll pitch yaw, R = Rot3::Ypr(yaw, pitch, roll) (dataset.cpp:741-764)
+      long long id;
+      double x, y, z, roll, pitch, yaw;
+      if (!(ss >> id >> x >> y >> z >> roll >> pitch >> yaw)) return GSX_E_INVALID;
+      std::vector<double> s(12);
+      ypr_to_R(yaw, pitch, roll, s.data());
+      s[9] = x; s[10] = y; s[11] = z;
+      states[id] = s;
+    } else if (is3d && tag == "EDGE3") {
+      // TORO: i j x y z roll pitch yaw + 21 upper-triangular information entries, taken as they are (dataset.cpp:829-840)
+      Edge e;
+      double x, y, z, roll, pitch, yaw, up[21];
+      if (!(ss >> e.i >> e.j >> x >> y >> z >> roll >> pitch >> yaw)) return GSX_E_INVALID;
+      for (double& q : up)
+        if (!(ss >> q)) return GSX_E_INVALID;
+      e.z.resize(12);
+      ypr_to_R(yaw, pitch, roll, e.z.data());
+      e.z[9] = x; e.z[10] = y; e.z[11] = z;
+      double m[36];
+      int k = 0;
+      for (int r = 0; r < 6; ++r)
+        for (int c = r; c < 6; ++c) m[r * 6 + c] = m[c * 6 + r] = up[k++];
+      e.R.resize(36);
+      if (!chol_upper(m, 6, e.R.data())) return GSX_E_INVALID;
+      edges.push_back(e);
     } else if (is3d && tag == "EDGE_SE3:QUAT") {
       Edge e;
       double x, y, z, qx, qy, qz, qw, up[21];
@@ -163,6 +298,21 @@ gsx_status gsx_read_g2o(const char* path, int32_t is3d, gsx_dataset** out) {
         states[e.j] = {a[0] + c * e.z[0] - s * e.z[1], a[1] + s * e.z[0] + c * e.z[1], a[2] + e.z[2]};
       }
     }
+  if (is3d) {
+    // The C++ reader leaves poses without a VERTEX line out of the Values (dataset.cpp:929-931); files of edges only
+    // (examples/Data/sphere2500.txt) are read by the reference's MATLAB loader, which starts at the origin and chains
+    // the successive odometry edges (matlab/+gtsam/load3D.m:21-53) — done here for the poses that are missing.
+    bool missing = false;
+    for (const Edge& e : edges) missing = missing || !states.count(e.i) || !states.count(e.j);
+    if (missing) {
+      if (!states.count(0)) states[0] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+      for (const Edge& e : edges) {
+        if (e.j == e.i + 1 && states.count(e.i) && !states.count(e.j)) states[e.j] = pose3_compose(states[e.i], e.z);
+        else if (e.i == e.j + 1 && states.count(e.j) && !states.count(e.i))
+          states[e.i] = pose3_compose(states[e.j], pose3_inverse(e.z));
+      }
+    }
+  }
   if (states.empty()) return GSX_E_INVALID;
   gsx_dataset* D = new gsx_dataset();
   std::map<long long, int> index;
@@ -205,6 +355,124 @@ gsx_status gsx_read_g2o(const char* path, int32_t is3d, gsx_dataset** out) {
   else
     for (double var : {1e-6, 1e-6, 1e-8}) D->noise.push_back(std::sqrt(var));
   D->f_noise_ptr.push_back((int64_t)D->noise.size());
+  *out = D;
+  return GSX_OK;
+}
+
+// load2D — gtsam/slam/dataset.cpp:505-570
+gsx_status gsx_load2d(const char* path, const double* model_sigmas, int64_t max_index, int32_t smart, int32_t noise_format,
+                      int32_t kernel, gsx_dataset** out) {
+  if (!path || !out || noise_format < GSX_NOISE_FORMAT_G2O || noise_format > GSX_NOISE_FORMAT_AUTO || kernel < 0 ||
+      kernel > 2 || max_index < 0)
+    return GSX_E_INVALID;
+  std::ifstream in(path);
+  if (!in) return GSX_E_INVALID;
+  const uint64_t lbase = (uint64_t)'l' << 56;  // L(j), gtsam/inference/Symbol.h
+  const unsigned long long mi = (unsigned long long)max_index;
+  struct Rec {
+    int kind;  // 0 between, 1 bearing-range
+    unsigned long long i, j;
+    double z[3], v[6];
+  };
+  std::map<uint64_t, std::vector<double>> states;  // key -> packed state (3: pose, 2: landmark)
+  std::vector<Rec> recs;
+  std::string line;
+  // first pass: vertices; second (here: recorded in file order): factors — dataset.cpp:512-527
+  while (std::getline(in, line)) {
+    std::istringstream ss(line);
+    std::string tag;
+    if (!(ss >> tag)) continue;
+    if (tag == "VERTEX2" || tag == "VERTEX_SE2" || tag == "VERTEX") {
+      unsigned long long id;
+      double x, y, th;
+      if (!(ss >> id >> x >> y >> th)) return GSX_E_INVALID;
+      if (!mi || id <= mi) states[id] = {x, y, th};
+    } else if (tag == "VERTEX_XY") {
+      unsigned long long id;
+      double x, y;
+      if (!(ss >> id >> x >> y)) return GSX_E_INVALID;
+      if (!mi || id <= mi) states[lbase | id] = {x, y};
+    } else if (tag == "EDGE2" || tag == "EDGE" || tag == "EDGE_SE2" || tag == "ODOMETRY") {
+      Rec r{};
+      r.kind = 0;
+      if (!(ss >> r.i >> r.j >> r.z[0] >> r.z[1] >> r.z[2])) return GSX_E_INVALID;
+      for (double& q : r.v) ss >> q;   // (as the reference: a short line leaves zeros, which the format check rejects)
+      if (mi && (r.i > mi || r.j > mi)) continue;
+      recs.push_back(r);
+    } else if (tag == "BR" || tag == "LANDMARK") {
+      Rec r{};
+      r.kind = 1;
+      if (!(ss >> r.i >> r.j)) return GSX_E_INVALID;
+      double bearing, range, bstd, rstd;
+      if (tag == "BR") {
+        if (!(ss >> bearing >> range >> bstd >> rstd)) return GSX_E_INVALID;
+      } else {
+        // a landmark sighting (x, y) + covariance (v1 v2 v3), converted to bearing-range (dataset.cpp:463-481)
+        double lx, ly, v1, v2, v3;
+        if (!(ss >> lx >> ly >> v1 >> v2 >> v3)) return GSX_E_INVALID;
+        bearing = std::atan2(ly, lx);
+        range = std::sqrt(lx * lx + ly * ly);
+        if (std::abs(v1 - v3) < 1e-4) {
+          bstd = std::sqrt(v1 / 10.0);
+          rstd = std::sqrt(v1);
+        } else {
+          bstd = rstd = 1;
+        }
+      }
+      if (mi && r.i > mi) continue;
+      r.z[0] = bearing; r.z[1] = range; r.v[0] = bstd; r.v[1] = rstd;
+      recs.push_back(r);
+    }
+  }
+  // variables referenced but not declared: odometry / sighting from the first pose that sees them (dataset.cpp:540-563)
+  for (const Rec& r : recs) {
+    if (!states.count(r.i)) states[r.i] = {0.0, 0.0, 0.0};
+    const std::vector<double> a = states[r.i];
+    const double c = std::cos(a[2]), s = std::sin(a[2]);
+    if (r.kind == 0) {
+      if (!states.count(r.j)) states[r.j] = {a[0] + c * r.z[0] - s * r.z[1], a[1] + s * r.z[0] + c * r.z[1], a[2] + r.z[2]};
+    } else if (!states.count(lbase | r.j)) {
+      const double lx = r.z[1] * std::cos(r.z[0]), ly = r.z[1] * std::sin(r.z[0]);
+      states[lbase | r.j] = {a[0] + c * lx - s * ly, a[1] + s * lx + c * ly};
+    }
+  }
+  if (states.empty()) return GSX_E_INVALID;
+  gsx_dataset* D = new gsx_dataset();
+  std::map<uint64_t, int> index;
+  for (const auto& kv : states) {
+    index[kv.first] = (int)D->var_keys.size();
+    D->var_keys.push_back(kv.first);
+    const bool pose = kv.second.size() == 3;
+    D->var_types.push_back(pose ? GSX_VAR_POSE2 : GSX_VAR_VECTOR);
+    D->var_dims.push_back(pose ? 3 : 2);
+    D->values.insert(D->values.end(), kv.second.begin(), kv.second.end());
+  }
+  D->f_key_ptr.push_back(0);
+  D->f_meas_ptr.push_back(0);
+  D->f_noise_ptr.push_back(0);
+  for (const Rec& r : recs) {
+    const bool between = r.kind == 0;
+    D->f_type.push_back(between ? GSX_F_BETWEEN : GSX_F_BEARINGRANGE);
+    D->f_rows.push_back(between ? 3 : 2);
+    D->f_vars.push_back(index[r.i]);
+    D->f_vars.push_back(index[between ? (uint64_t)r.j : (lbase | r.j)]);
+    D->f_key_ptr.push_back((int32_t)D->f_vars.size());
+    D->meas.insert(D->meas.end(), r.z, r.z + (between ? 3 : 2));
+    D->f_meas_ptr.push_back((int64_t)D->meas.size());
+    if (!between) {
+      D->f_noise_kind.push_back(GSX_NOISE_DIAGONAL);  // Diagonal::Sigmas(bearing_std, range_std), not smart
+      D->noise.push_back(r.v[0]);
+      D->noise.push_back(r.v[1]);
+    } else if (model_sigmas) {  // "If this is not null, will use instead of parsed model" (dataset.cpp:348-349)
+      D->f_noise_kind.push_back(GSX_NOISE_DIAGONAL);
+      D->noise.insert(D->noise.end(), model_sigmas, model_sigmas + 3);
+    } else if (!emit_noise_2d(r.v, noise_format, smart != 0, kernel, D, &D->err)) {
+      std::fprintf(stderr, "gsx_load2d: %s\n", D->err.c_str());
+      delete D;
+      return GSX_E_INVALID;
+    }
+    D->f_noise_ptr.push_back((int64_t)D->noise.size());
+  }
   *out = D;
   return GSX_OK;
 }

@@ -236,9 +236,25 @@ typedef struct gsx_stats {
  *   gsx_read_bal   SfmData::FromBalFile gtsam/sfm/SfmData.cpp:189-245 + openGL2gtsam
  *                  :79-85; graph of examples/SFMExample_bal.cpp:55-68 (add_priors != 0
  *                  appends its two priors)
+ *                  3-D also takes TORO's VERTEX3 / EDGE3 (roll pitch yaw, information as written: :741-764,
+ *                  :829-840); poses of a 3-D file that have no VERTEX line are chained from the successive odometry
+ *                  edges starting at the origin, as the reference's MATLAB loader does for such files
+ *                  (matlab/+gtsam/load3D.m:21-53; examples/Data/sphere2500.txt)
+ *   gsx_load2d     load2D gtsam/slam/dataset.cpp:505-570: TORO / "graph" 2-D files — VERTEX2|VERTEX_SE2|VERTEX,
+ *                  VERTEX_XY landmarks (keys L(j)), EDGE2|EDGE|EDGE_SE2|ODOMETRY between factors, BR / LANDMARK
+ *                  bearing-range factors (:452-496); undeclared variables are created from the odometry / the first
+ *                  sighting (:540-563); no prior is added.  noise_format as enum NoiseFormat (dataset.h:65-71, AUTO
+ *                  guesses GRAPH or COV, :219-231); smart != 0 lets a diagonal matrix become a Diagonal / Isotropic /
+ *                  Unit model (NoiseModel.cpp:98-131); kernel 0/1/2 = none / Huber(1.345) / Tukey(4.6851) (:276-292);
+ *                  model_sigmas (3 doubles or NULL) replaces the models of the file (:348-349); max_index as there
+ *                  (0 = all).  The sampler (addNoise) is not offered.
  * The pointers handed out by gsx_dataset_get stay valid until gsx_dataset_free. */
+enum { GSX_NOISE_FORMAT_G2O = 0, GSX_NOISE_FORMAT_TORO = 1, GSX_NOISE_FORMAT_GRAPH = 2, GSX_NOISE_FORMAT_COV = 3,
+       GSX_NOISE_FORMAT_AUTO = 4 };
 typedef struct gsx_dataset gsx_dataset;
 gsx_status gsx_read_g2o(const char* path, int32_t is3d, gsx_dataset** out);
+gsx_status gsx_load2d(const char* path, const double* model_sigmas, int64_t max_index, int32_t smart,
+                      int32_t noise_format, int32_t kernel, gsx_dataset** out);
 gsx_status gsx_read_bal(const char* path, int32_t add_priors, gsx_dataset** out);
 gsx_status gsx_dataset_get(const gsx_dataset* d, gsx_problem_desc* desc, const double** values, int64_t* n_values);
 void gsx_dataset_free(gsx_dataset* d);

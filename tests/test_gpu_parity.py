@@ -673,3 +673,21 @@ def test_lm_trial_equals_separate_calls(gpu):
     with pytest.raises(gt.GsxError) as ei:
         gpu.product_backend(arr).lm_trial(True, 0.0, False)   # no ordering yet
     assert ei.value.status == A.GSX_E_STATE
+
+
+def test_toro_example_runs_match_oracle(gpu, oracle, golden_dir):
+    """The reference's example drivers on its own TORO / "graph" data (w100.graph, example.graph with bearing-range
+    factors, sphere2500.txt): LM on the device against the oracle — same accept/reject trace, final error to 1e-6."""
+    from tests.test_oracle_golden import toro_example_problems
+    for name, arr, kind in toro_example_problems(golden_dir):
+        gb, ob = gpu.product_backend(arr), oracle.oracle_backend(arr)
+        ordering = gb.compute_ordering(kind)
+        gb.set_ordering(ordering)
+        ob.set_ordering(ordering)
+        assert abs(gb.error() - ob.error()) <= 1e-11 * abs(ob.error()), name
+        p = A.lm_params_legacy()
+        p.max_iterations = 12 if name == "sphere2500" else 100
+        rg, ro = gb.lm_optimize(p), ob.lm_optimize(p)
+        assert np.array_equal(rg["trace_accepted"], ro["trace_accepted"]), name
+        assert abs(rg["final_error"] - ro["final_error"]) <= 1e-6 * ro["final_error"], name
+        assert rg["final_error"] < 0.25 * rg["initial_error"], name

@@ -263,3 +263,96 @@ def test_native_g2o_writer_round_trips(lib, golden_dir, tmp_path, name, is3d):
     py = tmp_path / "python.g2o"
     datasets.write_g2o(str(py), arr, arr.values)
     _same_arrays(back, _lib.read_g2o(str(py), is3d), noise_tol=1e-9)
+
+
+# ---- TORO / "graph" formats (gsx_load2d, VERTEX3 / EDGE3) -------------------------------------------------------------
+def test_load2D_w100(golden_dir):
+    """gtsam/slam/tests/testDataset.cpp:90-101 (dataSet, load2D): 300 factors, 100 values, the first factor
+    BetweenFactor<Pose2>(1, 0, Pose2(-0.99879, 0.0417574, -0.00818381), Unit(3)) — the file's covariance in TORO layout
+    is the identity, which the smart model turns into Unit."""
+    arr = _lib.load2d(os.path.join(golden_dir, "w100.graph"))
+    assert arr.n_factors == 300 and arr.n_vars == 100
+    assert np.all(arr.f_type == A.F_BETWEEN) and np.all(arr.var_types == A.VAR_POSE2)
+    assert arr.var_keys[arr.f_vars[:2]].tolist() == [1, 0]
+    assert np.allclose(arr.meas[:3], [-0.99879, 0.0417574, -0.00818381], atol=0)
+    assert arr.f_noise_kind[0] == A.NOISE_UNIT and arr.f_noise_ptr[1] == 0
+    # parseVariables<Pose2>: the poses of the file (VERTEX2 1 0.995595 0.0837204 0.0146728 is the second line)
+    assert np.allclose(arr.values[3:6], [0.995595, 0.0837204, 0.0146728], atol=0)
+    # the model of examples/Pose2SLAMExample_graph.cpp:38-40 replaces the file's
+    sig = [0.05, 0.05, 5.0 * np.pi / 180.0]
+    arr2 = _lib.load2d(os.path.join(golden_dir, "w100.graph"), model_sigmas=sig)
+    assert np.all(arr2.f_noise_kind == A.NOISE_DIAGONAL) and np.allclose(arr2.noise[:3], sig, atol=0)
+    # maxIndex (dataset.cpp:364-366): edges touching a pose above it are dropped
+    arr3 = _lib.load2d(os.path.join(golden_dir, "w100.graph"), max_index=5)
+    assert arr3.n_vars == 6 and np.all(arr3.var_keys[arr3.f_vars] <= 5) and 5 <= arr3.n_factors < 300
+
+
+def test_load2D_noise_formats(tmp_path):
+    """createNoiseModel (dataset.cpp:216-296): the four layouts, the AUTO guess, smart models, robust kernels."""
+    f = tmp_path / "t.graph"
+    v = "4 0 9 16 0 0"   # TORO layout: ff fs ss rr fr sr -> diag(4, 9, 16)
+    f.write_text(f"VERTEX2 0 0 0 0\nVERTEX2 1 1 0 0\nEDGE2 0 1 1 0 0 {v}\n")
+    a = _lib.load2d(str(f))                                   # AUTO -> GRAPH: a covariance
+    assert a.f_noise_kind[0] == A.NOISE_DIAGONAL and np.allclose(a.noise[:3], [2, 3, 4])
+    a = _lib.load2d(str(f), noise_format=A.NOISE_FORMAT_TORO)  # the same numbers as information
+    assert a.f_noise_kind[0] == A.NOISE_DIAGONAL and np.allclose(a.noise[:3], [1 / 2, 1 / 3, 1 / 4])
+    a = _lib.load2d(str(f), noise_format=A.NOISE_FORMAT_TORO, smart=False)
+    assert a.f_noise_kind[0] == A.NOISE_GAUSSIAN and np.allclose(a.noise[:9].reshape(3, 3), np.diag([2.0, 3, 4]))
+    a = _lib.load2d(str(f), kernel=1)
+    assert a.f_noise_kind[0] == (A.NOISE_DIAGONAL | A.NOISE_ROBUST_HUBER) and np.allclose(a.noise[:4], [2, 3, 4, 1.345])
+    f.write_text("EDGE2 0 1 1 0 0 2 0.5 0 3 0 4\n")          # G2O layout I11 I12 I13 I22 I23 I33, not diagonal
+    with pytest.raises(A.GsxError):
+        _lib.load2d(str(f))                                   # AUTO cannot tell
+    a = _lib.load2d(str(f), noise_format=A.NOISE_FORMAT_G2O)
+    R = a.noise[:9].reshape(3, 3)
+    assert a.f_noise_kind[0] == A.NOISE_GAUSSIAN and np.allclose(R.T @ R, [[2, 0.5, 0], [0.5, 3, 0], [0, 0, 4]])
+    assert a.n_vars == 2 and np.allclose(a.values, [0, 0, 0, 1, 0, 0])   # both poses from the odometry
+    a = _lib.load2d(str(f), noise_format=A.NOISE_FORMAT_COV)
+    R = a.noise[:9].reshape(3, 3)
+    assert np.allclose(np.linalg.inv(R.T @ R), [[2, 0.5, 0], [0.5, 3, 0], [0, 0, 4]])
+    f.write_text("EDGE2 0 1 1 0 0 1 0 0 1 0 1\n")            # COV layout, identity
+    a = _lib.load2d(str(f))
+    assert a.f_noise_kind[0] == A.NOISE_UNIT
+
+
+def test_load2D_bearing_range(golden_dir):
+    """examples/Data/example.graph (matlab/gtsam_examples/PlanarSLAMExample_graph.m): 95 poses, 94 odometry edges, 422 BR
+    lines -> BearingRangeFactor<Pose2, Point2> with Diagonal(bearing_std, range_std), landmarks keyed L(j) and created
+    from their first sighting (dataset.cpp:452-496, 547-563)."""
+    arr = _lib.load2d(os.path.join(golden_dir, "example.graph"))
+    nb, nbr = int((arr.f_type == A.F_BETWEEN).sum()), int((arr.f_type == A.F_BEARINGRANGE).sum())
+    assert (nb, nbr) == (94, 422) and int((arr.var_types == A.VAR_POSE2).sum()) == 95
+    lm = arr.var_types == A.VAR_VECTOR
+    assert lm.sum() > 0 and np.all(arr.var_keys[lm] >> np.uint64(56) == ord("l")) and np.all(arr.var_dims[lm] == 2)
+    k = int(np.argmax(arr.f_type == A.F_BEARINGRANGE))        # "BR 0 144 0.185182458717 9.13212526936 0.0349 0.1"
+    vs = arr.f_vars[arr.f_key_ptr[k]:arr.f_key_ptr[k + 1]]
+    assert int(arr.var_keys[vs[0]]) == 0 and int(arr.var_keys[vs[1]]) == (ord("l") << 56) + 144
+    assert np.allclose(arr.meas[arr.f_meas_ptr[k]:arr.f_meas_ptr[k + 1]], [0.185182458717, 9.13212526936], atol=0)
+    assert arr.f_noise_kind[k] == A.NOISE_DIAGONAL
+    assert np.allclose(arr.noise[arr.f_noise_ptr[k]:arr.f_noise_ptr[k + 1]], [0.0349, 0.1], atol=0)
+    # landmark 144 sits where pose 0 saw it
+    x, y, th = arr.values[:3]
+    off = int(np.sum(np.where(arr.var_types[:vs[1]] == A.VAR_POSE2, 3, 2)))
+    assert np.allclose(arr.values[off:off + 2], [x + 9.13212526936 * np.cos(th + 0.185182458717),
+                                                 y + 9.13212526936 * np.sin(th + 0.185182458717)])
+
+
+def test_read_toro_3d_sphere2500(golden_dir):
+    """examples/Data/sphere2500.txt: 4949 EDGE3 lines and no vertices (process_shonan_timing_results.py:179 gives the
+    counts); measurement = Pose3(Rot3::Ypr(yaw, pitch, roll), t), information as written (dataset.cpp:829-840); the
+    initial estimate chains the successive odometry from the origin (matlab/+gtsam/load3D.m:21-53)."""
+    arr = _lib.read_g2o(os.path.join(golden_dir, "sphere2500.txt"), is3D=True)
+    assert arr.n_vars == 2500 and arr.n_factors == 4949 + 1     # + the anchoring prior of the g2o examples
+    # EDGE3 0 1 0.341895 -0.0416997 0.0330394 -0.00305942 0.00822248 0.1802  10 0 0 0 0 0 10 ...
+    R = arr.meas[:9].reshape(3, 3)
+    r, p, y = -0.00305942, 0.00822248, 0.1802
+    Rz = np.array([[np.cos(y), -np.sin(y), 0], [np.sin(y), np.cos(y), 0], [0, 0, 1]])
+    Ry = np.array([[np.cos(p), 0, np.sin(p)], [0, 1, 0], [-np.sin(p), 0, np.cos(p)]])
+    Rx = np.array([[1, 0, 0], [0, np.cos(r), -np.sin(r)], [0, np.sin(r), np.cos(r)]])
+    assert np.allclose(R, Rz @ Ry @ Rx, atol=1e-15) and np.allclose(arr.meas[9:12], [0.341895, -0.0416997, 0.0330394])
+    Rn = arr.noise[:36].reshape(6, 6)
+    assert np.allclose(Rn.T @ Rn, np.diag([10.0, 10, 10, 100, 100, 25]))
+    # pose 1 = origin * first measurement; every pose got a value with a proper rotation
+    assert np.allclose(arr.values[:12], [1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0]) and np.allclose(arr.values[12:24], arr.meas[:12])
+    Rs = arr.values.reshape(2500, 12)[:, :9].reshape(2500, 3, 3)
+    assert np.allclose(Rs @ Rs.transpose(0, 2, 1), np.eye(3), atol=1e-9)
