@@ -377,6 +377,16 @@ class Backend:
                                                     C.c_int64(d * d)), "marginal_covariance")
         return out.reshape(d, d).T  # column-major
 
+    def joint_marginal_covariance(self, keys) -> np.ndarray:
+        """Marginals::jointMarginalCovariance(keys): the D x D joint covariance, blocks in the order of `keys`."""
+        ks = np.ascontiguousarray(keys, dtype=np.uint64)
+        D = int(sum(int(self.arrays.var_dims[int(np.searchsorted(self.arrays.var_keys, k))]) for k in ks))
+        out = np.zeros(D * D)
+        self._check(self._fn("joint_marginal_covariance")(self._h, ks.ctypes.data_as(_p(C.c_uint64)), C.c_int32(ks.size),
+                                                          out.ctypes.data_as(_p(C.c_double)), C.c_int64(D * D)),
+                    "joint_marginal_covariance")
+        return out.reshape(D, D)
+
     def dogleg_optimize(self, delta_initial=1.0, max_iterations=100, relative_error_tol=1e-5, absolute_error_tol=1e-5,
                         error_tol=0.0, trace_cap=4096):
         """DoglegOptimizer (ONE_STEP_PER_ITERATION); trace_lambda / final_lambda carry the trust-region radius."""

@@ -156,7 +156,8 @@ void launch_vec_axpby(double* out, double alpha, const double* a, double beta, c
 // variable's unit columns up the path of cliques from its own clique to the root, Sigma_vv = sum over the path of y_F' y_F.
 // path[0..npath): front ids, child to root; (loc, dA): the variable's rows inside path[0]; lds_doubles = 2 max_n dA.
 void launch_marginal_path(const DevSymbolic& S, const int* path, int npath, int loc, int dA, int max_n, const double* arena,
-                          double* out, hipStream_t st);
+                          double* out, double* Y, int64_t n_tan, hipStream_t st);
+void launch_joint_cross(const double* Ya, const double* Yb, int64_t n_tan, int dA, int dB, double* out, hipStream_t st);
 void launch_set_scalar(double* scalars, int slot, double v, hipStream_t st);
 void launch_begin_factorization(double* scalars, double lambda, DevStatus* status, hipStream_t st);
 // dense unit kernel for gsx_cholesky_partial: in-place lower partial Cholesky of an n x n

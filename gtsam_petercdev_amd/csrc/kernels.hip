@@ -811,8 +811,11 @@ void launch_make_damping(int n, const double* hdiag, int diagonal, double mind, 
 // y_F = L11^-1 w_F, w_S -= L21 y_F, Sigma += y_F' y_F, and w_S moves to the parent's rows through the child's row map.
 // One workgroup; w lives in LDS (two buffers of max_n x dA).  (The reference gets the same block by eliminating the
 // Bayes tree down to a marginal factor and inverting its information: gtsam/nonlinear/Marginals.cpp:107-136.)
+// With Y != nullptr the columns y = (L^-1)_{:,v} themselves are kept (Y[g + c * n_tan], zero off the path: the caller
+// clears Y): the joint covariance of several variables is then Y_a' Y_b (joint_cross_kernel).
 __global__ void __launch_bounds__(256) marginal_path_kernel(DevSymbolic S, const int* path, int npath, int loc, int dA,
-                                                            int max_n, const double* arena, double* out) {
+                                                            int max_n, const double* arena, double* out, double* Y,
+                                                            i64 n_tan) {
   extern __shared__ double mw[];
   double* w = mw;                        // (n - 1) x dA, column-major, ld = max_n
   double* wn = mw + (size_t)max_n * dA;  // the parent's
@@ -850,6 +853,13 @@ __global__ void __launch_bounds__(256) marginal_path_kernel(DevSymbolic S, const
       for (int r = 0; r < F; ++r) acc += w[r + a * max_n] * w[r + b * max_n];
       sig[e] += acc;
     }
+    if (Y) {
+      const int* gi = S.gidx + S.gidx_ptr[f];
+      for (int e = tid; e < F * dA; e += nt) {
+        const int r = e % F, c = e / F;
+        Y[gi[r] + (i64)c * n_tan] = w[r + c * max_n];
+      }
+    }
     if (pi + 1 < npath) {
       const int np = S.fr_N[path[pi + 1]];
       for (int e = tid; e < max_n * dA; e += nt) wn[e] = 0.0;
@@ -870,14 +880,28 @@ __global__ void __launch_bounds__(256) marginal_path_kernel(DevSymbolic S, const
   }
   for (int e = tid; e < dA * dA; e += nt) out[e] = sig[e];
 }
+// out (dA x dB, column-major) = Ya' Yb over the n_tan rows: one workgroup per entry
+__global__ void __launch_bounds__(256) joint_cross_kernel(const double* Ya, const double* Yb, i64 n_tan, int dA, double* out) {
+  const int a = blockIdx.x % dA, b = blockIdx.x / dA;
+  const double* pa = Ya + (i64)a * n_tan;
+  const double* pb = Yb + (i64)b * n_tan;
+  double acc = 0;
+  for (i64 i = threadIdx.x; i < n_tan; i += blockDim.x) acc += pa[i] * pb[i];
+  const double s = block_sum(acc);
+  if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+void launch_joint_cross(const double* Ya, const double* Yb, int64_t n_tan, int dA, int dB, double* out, hipStream_t st) {
+  joint_cross_kernel<<<dA * dB, 256, 0, st>>>(Ya, Yb, n_tan, dA, out);
+}
 void launch_marginal_path(const DevSymbolic& S, const int* path, int npath, int loc, int dA, int max_n, const double* arena,
-                          double* out, hipStream_t st) {
+                          double* out, double* Y, int64_t n_tan, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
     hipFuncSetAttribute((const void*)marginal_path_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
     attr = true;
   }
-  marginal_path_kernel<<<1, 256, (size_t)2 * max_n * dA * sizeof(double), st>>>(S, path, npath, loc, dA, max_n, arena, out);
+  marginal_path_kernel<<<1, 256, (size_t)2 * max_n * dA * sizeof(double), st>>>(S, path, npath, loc, dA, max_n, arena, out,
+                                                                                Y, n_tan);
 }
 
 // ---- Dogleg helpers -------------------------------------------------------------------------------------------

@@ -1558,25 +1558,15 @@ gsx_status gsx_dogleg_optimize(gsx_handle h, double delta_initial, int32_t max_i
 
 // Marginals::marginalCovariance(key) — gtsam/nonlinear/Marginals.cpp:107-136 — from the undamped factorization of the
 // current linearization (the block of H^-1 in the variable's tangent space), out: dA x dA column-major.
-gsx_status gsx_marginal_covariance(gsx_handle h, uint64_t key, double* out, int64_t n_out) {
-  if (!h || !out) return GSX_E_INVALID;
+namespace {
+// the undamped factorization of the current linearization, resident in the arena (shared by the marginal entry points)
+gsx_status marginals_prepare(gsx_handle h) {
   gsx_status st = ensure_ready(h, true, true);
   if (st != GSX_OK) return st;
   if (h->sharded()) {
     h->err = "marginals are not available on a sharded handle";
     return GSX_E_STATE;
   }
-  int v = -1;
-  {
-    auto it = std::lower_bound(h->P.keys.begin(), h->P.keys.end(), key);
-    if (it == h->P.keys.end() || *it != key) {
-      h->err = "marginal of a key that is not a variable of the graph";
-      return GSX_E_INVALID;
-    }
-    v = (int)(it - h->P.keys.begin());
-  }
-  const int dA = h->P.dims[v];
-  if (n_out != (int64_t)dA * dA || dA > 16) return GSX_E_INVALID;
   hipSetDevice(h->device);
   if (!h->linearized) dev_linearize(h);
   if (!h->h_ready) dev_assemble_h(h);
@@ -1592,6 +1582,88 @@ gsx_status gsx_marginal_covariance(gsx_handle h, uint64_t key, double* out, int6
     }
     h->solved = false;  // the back-substitution of a previous solve no longer matches the arena
   }
+  return GSX_OK;
+}
+int find_var(gsx_handle h, uint64_t key) {
+  auto it = std::lower_bound(h->P.keys.begin(), h->P.keys.end(), key);
+  return (it == h->P.keys.end() || *it != key) ? -1 : (int)(it - h->P.keys.begin());
+}
+}  // namespace
+
+// Marginals::jointMarginalCovariance — gtsam/nonlinear/Marginals.cpp:138-189 (there: eliminate down to the joint, take
+// the information, invert).  Here: the columns (L^-1)_{:,v} of every requested variable are kept, and block (a, b) of
+// the joint covariance is their product.
+gsx_status gsx_joint_marginal_covariance(gsx_handle h, const uint64_t* keys, int32_t n_keys, double* out, int64_t n_out) {
+  if (!h || !keys || !out || n_keys < 1 || n_keys > 64) return GSX_E_INVALID;
+  gsx_status st = marginals_prepare(h);
+  if (st != GSX_OK) return st;
+  const Symbolic& S = h->S;
+  std::vector<int> vars(n_keys), offs(n_keys + 1, 0);
+  for (int k = 0; k < n_keys; ++k) {
+    vars[k] = find_var(h, keys[k]);
+    if (vars[k] < 0 || h->P.dims[vars[k]] > 16) {
+      h->err = "joint marginal of a key that is not a variable of the graph";
+      return GSX_E_INVALID;
+    }
+    for (int q = 0; q < k; ++q)
+      if (vars[q] == vars[k]) return GSX_E_INVALID;
+    offs[k + 1] = offs[k] + h->P.dims[vars[k]];
+  }
+  const int D = offs[n_keys];
+  if (n_out != (int64_t)D * D) return GSX_E_INVALID;
+  const int64_t nt = std::max<int64_t>(h->P.tan_size, 1);
+  DevBuf<double> d_Y, d_blk, d_sig;
+  DevBuf<int> d_path;
+  HIPCHK(h, d_Y.alloc((size_t)nt * D));
+  HIPCHK(h, d_blk.alloc((size_t)D * D));
+  HIPCHK(h, d_sig.alloc(256));
+  HIPCHK(h, hipMemsetAsync(d_Y.p, 0, (size_t)nt * D * sizeof(double), h->stream));
+  for (int k = 0; k < n_keys; ++k) {
+    const int v = vars[k], dA = h->P.dims[v];
+    std::vector<int> path;
+    int max_n = 0;
+    for (int f = S.front_of_var[v]; f >= 0; f = S.parent[f]) {
+      path.push_back(f);
+      max_n = std::max(max_n, S.N[f]);
+    }
+    if ((size_t)2 * max_n * dA * sizeof(double) > 160 * 1024 - 4096 - 4096) {
+      h->err = "marginal: the cliques on the path to the root are too large for the one-workgroup kernel";
+      return GSX_E_NOMEM;
+    }
+    HIPCHK(h, d_path.upload(path, h->stream));
+    launch_marginal_path(h->DS, d_path.p, (int)path.size(), S.h_loc[v], dA, max_n, h->d_arena.p, d_sig.p,
+                         d_Y.p + (size_t)offs[k] * nt, nt, h->stream);
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // (d_path is reused)
+  }
+  std::vector<double> blk((size_t)16 * 16);
+  for (int a = 0; a < n_keys; ++a)
+    for (int b = a; b < n_keys; ++b) {
+      const int dA = offs[a + 1] - offs[a], dB = offs[b + 1] - offs[b];
+      launch_joint_cross(d_Y.p + (size_t)offs[a] * nt, d_Y.p + (size_t)offs[b] * nt, nt, dA, dB, d_blk.p, h->stream);
+      HIPCHK(h, hipMemcpyAsync(blk.data(), d_blk.p, (size_t)dA * dB * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      for (int i = 0; i < dA; ++i)
+        for (int j = 0; j < dB; ++j) {
+          const double x = blk[i + (size_t)j * dA];
+          out[(size_t)(offs[a] + i) * D + offs[b] + j] = x;
+          out[(size_t)(offs[b] + j) * D + offs[a] + i] = x;
+        }
+    }
+  HIPCHK(h, hipGetLastError());
+  return GSX_OK;
+}
+
+gsx_status gsx_marginal_covariance(gsx_handle h, uint64_t key, double* out, int64_t n_out) {
+  if (!h || !out) return GSX_E_INVALID;
+  const int v = find_var(h, key);
+  if (v < 0) {
+    h->err = "marginal of a key that is not a variable of the graph";
+    return GSX_E_INVALID;
+  }
+  const int dA = h->P.dims[v];
+  if (n_out != (int64_t)dA * dA || dA > 16) return GSX_E_INVALID;
+  gsx_status st = marginals_prepare(h);
+  if (st != GSX_OK) return st;
   const Symbolic& S = h->S;
   std::vector<int> path;
   int max_n = 0;
@@ -1607,7 +1679,8 @@ gsx_status gsx_marginal_covariance(gsx_handle h, uint64_t key, double* out, int6
   DevBuf<double> d_out;
   HIPCHK(h, d_path.upload(path, h->stream));
   HIPCHK(h, d_out.alloc((size_t)dA * dA));
-  launch_marginal_path(h->DS, d_path.p, (int)path.size(), S.h_loc[v], dA, max_n, h->d_arena.p, d_out.p, h->stream);
+  launch_marginal_path(h->DS, d_path.p, (int)path.size(), S.h_loc[v], dA, max_n, h->d_arena.p, d_out.p, nullptr, 0,
+                       h->stream);
   HIPCHK(h, hipMemcpyAsync(out, d_out.p, (size_t)dA * dA * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipGetLastError());

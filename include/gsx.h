@@ -379,6 +379,10 @@ gsx_status gsx_dogleg_optimize(gsx_handle h, double delta_initial, int32_t max_i
 /* Marginals::marginalCovariance(key) (gtsam/nonlinear/Marginals.cpp:107-136): the dA x dA block of H^-1 of the current
  * linearization in the variable's tangent space (column-major), from the undamped factorization on the device. */
 gsx_status gsx_marginal_covariance(gsx_handle h, uint64_t key, double* out, int64_t n_out);
+/* Marginals::jointMarginalCovariance(variables) (gtsam/nonlinear/Marginals.cpp:138-189): the joint covariance of up to 64
+ * variables, D x D row-major with D = sum of their dimensions, blocks in the order of `keys` (the reference returns
+ * them sorted by key: pass sorted keys for the same layout). */
+gsx_status gsx_joint_marginal_covariance(gsx_handle h, const uint64_t* keys, int32_t n_keys, double* out, int64_t n_out);
 /* DoglegOptimizerImpl::ComputeDoglegPoint (DoglegOptimizerImpl.cpp:26-86) on plain vectors (host). */
 gsx_status gsx_dogleg_point(double delta, const double* dx_u, const double* dx_n, int64_t n, double* out);
 

@@ -1404,16 +1404,22 @@ int orc_gn_optimize(void* h, int32_t max_iterations, double rel, double abs_, do
 }
 // Marginals::marginalCovariance — gtsam/nonlinear/Marginals.cpp:107-136: the inverse of the variable's marginal
 // information; restated densely (the block of H^-1, H = sum A'A of the current linearization) — for test-sized problems.
-int orc_marginal_covariance(void* h, uint64_t key, double* out, int64_t n_out) {
+// joint version: D x D row-major, blocks in the order of `keys` (Marginals::jointMarginalCovariance,
+// gtsam/nonlinear/Marginals.cpp:138-189, returns them sorted by key)
+int orc_joint_marginal_covariance(void* h, const uint64_t* keys, int32_t n_keys, double* out, int64_t n_out) {
   Problem& P = *(Problem*)h;
   if (!P.linearized) return GSX_E_STATE;
-  int v = -1;
-  for (int i = 0; i < P.n_vars; ++i)
-    if (P.keys[i] == key) v = i;
-  if (v < 0) return GSX_E_INVALID;
-  const int d = P.dims[v];
+  std::vector<int64_t> idx;  // global tangent indices of the requested scalars
+  for (int q = 0; q < n_keys; ++q) {
+    int v = -1;
+    for (int i = 0; i < P.n_vars; ++i)
+      if (P.keys[i] == keys[q]) v = i;
+    if (v < 0) return GSX_E_INVALID;
+    for (int c = 0; c < P.dims[v]; ++c) idx.push_back(P.tan_off[v] + c);
+  }
+  const int64_t D = (int64_t)idx.size();
   const int64_t N = P.tan_size;
-  if (n_out != (int64_t)d * d || N > 6000) return GSX_E_INVALID;
+  if (n_out != D * D || N > 6000) return GSX_E_INVALID;
   orc::Vec H((size_t)N * N, 0.0);
   for (const orc::LinFactor& L : P.linear) {
     const int m = L.rows;
@@ -1427,7 +1433,7 @@ int orc_marginal_covariance(void* h, uint64_t key, double* out, int64_t n_out) {
         H[(size_t)cols[a] * N + cols[b]] += s;
       }
   }
-  // in-place Cholesky H = G G' (lower), then solve for the unit columns of the variable
+  // in-place Cholesky H = G G' (lower), then solve for the unit columns of the requested scalars
   for (int64_t j = 0; j < N; ++j) {
     double s = H[j * N + j];
     for (int64_t k = 0; k < j; ++k) s -= H[j * N + k] * H[j * N + k];
@@ -1440,11 +1446,9 @@ int orc_marginal_covariance(void* h, uint64_t key, double* out, int64_t n_out) {
       H[i * N + j] = t / g;
     }
   }
-  const int64_t o = P.tan_off[v];
-  std::vector<orc::Vec> y(d, orc::Vec(N, 0.0));
-  for (int c = 0; c < d; ++c) {
-    orc::Vec& x = y[c];
-    x[o + c] = 1.0;
+  for (int64_t c = 0; c < D; ++c) {
+    orc::Vec x(N, 0.0);
+    x[idx[c]] = 1.0;
     for (int64_t i = 0; i < N; ++i) {  // G z = e
       double t = x[i];
       for (int64_t k = 0; k < i; ++k) t -= H[i * N + k] * x[k];
@@ -1455,10 +1459,12 @@ int orc_marginal_covariance(void* h, uint64_t key, double* out, int64_t n_out) {
       for (int64_t k = i + 1; k < N; ++k) t -= H[k * N + i] * x[k];
       x[i] = t / H[i * N + i];
     }
+    for (int64_t a = 0; a < D; ++a) out[a * D + c] = x[idx[a]];
   }
-  for (int a = 0; a < d; ++a)
-    for (int b = 0; b < d; ++b) out[a + b * d] = y[b][o + a];
   return GSX_OK;
+}
+int orc_marginal_covariance(void* h, uint64_t key, double* out, int64_t n_out) {
+  return orc_joint_marginal_covariance(h, &key, 1, out, n_out);  // (symmetric: row- and column-major agree)
 }
 int orc_dogleg_optimize(void* h, double delta_initial, int32_t max_iterations, double rel, double abs_, double errtol,
                         gsx_lm_result* r) {

@@ -691,3 +691,28 @@ def test_toro_example_runs_match_oracle(gpu, oracle, golden_dir):
         assert np.array_equal(rg["trace_accepted"], ro["trace_accepted"]), name
         assert abs(rg["final_error"] - ro["final_error"]) <= 1e-6 * ro["final_error"], name
         assert rg["final_error"] < 0.25 * rg["initial_error"], name
+
+
+def test_planarSLAMjointMarginals(gpu):
+    """tests/testMarginals.cpp:109-157 through the HIP path, for several elimination orders."""
+    from tests.test_oracle_golden import planar_slam_joint_marginals_check
+    planar_slam_joint_marginals_check(gpu.product_backend, [[1, 2, 3, 11, 12], [11, 12, 1, 2, 3], [3, 12, 2, 11, 1]])
+
+
+@pytest.mark.parametrize("name", ["bal_small", "pose3", "bal_bigfront"])
+def test_joint_marginal_matches_oracle(gpu, oracle, name):
+    """Joint covariances of variables in different subtrees / the same clique / leaf and root, against the oracle's dense
+    inverse, with relaxed amalgamation."""
+    arr = PROBLEMS[name]
+    gb, ob = gpu.product_backend(arr), oracle.oracle_backend(arr)
+    ordering = gb.compute_ordering(A.ORDER_SCHUR_ND if name.startswith("bal") else A.ORDER_ND)
+    gb.set_amalgamation(0.5, 128)
+    gb.set_ordering(ordering)
+    ob.set_ordering(ordering)
+    gb.linearize()
+    ob.linearize()
+    keys = [int(ordering[0]), int(ordering[1]), int(ordering[len(ordering) // 2]), int(ordering[-1]), int(ordering[-2])]
+    Jg, Jo = gb.joint_marginal_covariance(keys), ob.joint_marginal_covariance(keys)
+    assert np.max(np.abs(Jg - Jo)) <= 1e-7 * np.max(np.abs(Jo))
+    with pytest.raises(gt.GsxError):
+        gb.joint_marginal_covariance([keys[0], keys[0]])

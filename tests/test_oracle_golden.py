@@ -762,6 +762,44 @@ def test_BearingRangeFactor2D(orc):
     bearing_range_check(orc.oracle_backend, [[1, 2, 3, 11, 12]])
 
 
+PLANAR_SLAM_JOINT_L2X1X3 = np.array([  # tests/testMarginals.cpp:111-120, order (l2, x1, x3), tolerance 1e-6
+    [0.293871159514111, -0.104516127560770, 0.090000180000270, -0.000000000000000, -0.020000000000000, 0.151935669757191, -0.104516127560770, -0.050967744878460],
+    [-0.104516127560770, 0.391935664055174, 0.000000000000000, 0.090000180000270, 0.040000000000000, 0.007741936219615, 0.351935664055174, 0.056129031890193],
+    [0.090000180000270, 0.000000000000000, 0.090000180000270, -0.000000000000000, 0.000000000000000, 0.090000180000270, 0.000000000000000, 0.000000000000000],
+    [-0.000000000000000, 0.090000180000270, -0.000000000000000, 0.090000180000270, 0.000000000000000, -0.000000000000000, 0.090000180000270, 0.000000000000000],
+    [-0.020000000000000, 0.040000000000000, 0.000000000000000, 0.000000000000000, 0.010000000000000, 0.000000000000000, 0.040000000000000, 0.010000000000000],
+    [0.151935669757191, 0.007741936219615, 0.090000180000270, -0.000000000000000, 0.000000000000000, 0.160967924878730, 0.007741936219615, 0.004516127560770],
+    [-0.104516127560770, 0.351935664055174, 0.000000000000000, 0.090000180000270, 0.040000000000000, 0.007741936219615, 0.351935664055174, 0.056129031890193],
+    [-0.050967744878460, 0.056129031890193, 0.000000000000000, 0.000000000000000, 0.010000000000000, 0.004516127560770, 0.056129031890193, 0.027741936219615]])
+
+
+def planar_slam_joint_marginals_check(backend_factory, orderings):
+    """Marginals::jointMarginalCovariance on the planar-SLAM example: 3 variables, 2 variables, 1 variable
+    (tests/testMarginals.cpp:109-157; the expected blocks to 1e-6)."""
+    g, v = planar_slam_nonlinear_graph()
+    arrays = g.to_arrays(v)
+    for ordering in orderings:
+        be = backend_factory(arrays)
+        be.set_ordering(ordering)
+        be.linearize()
+        J = be.joint_marginal_covariance([12, 1, 3])
+        assert J.shape == (8, 8) and np.allclose(J, PLANAR_SLAM_JOINT_L2X1X3, atol=1e-6), ordering
+        assert np.allclose(J, J.T, atol=1e-15)
+        J2 = be.joint_marginal_covariance([12, 1])
+        assert np.allclose(J2, PLANAR_SLAM_JOINT_L2X1X3[:5, :5], atol=1e-6), ordering
+        J1 = be.joint_marginal_covariance([1])
+        assert np.allclose(J1, PLANAR_SLAM_MARGINALS[1], atol=1e-6), ordering
+        # the diagonal blocks are the single-variable marginals, whatever the order of the request
+        Jr = be.joint_marginal_covariance([3, 12, 1])
+        assert np.allclose(Jr[:3, :3], be.marginal_covariance(3), atol=1e-12)
+        assert np.allclose(Jr[3:5, 3:5], be.marginal_covariance(12), atol=1e-12)
+        assert np.allclose(Jr[:3, 3:5], J[5:8, 0:2], atol=1e-12)
+
+
+def test_planarSLAMjointMarginals(orc):
+    planar_slam_joint_marginals_check(orc.oracle_backend, [[1, 2, 3, 11, 12]])
+
+
 def test_planarSLAMmarginals(orc):
     """The reference's expected marginal covariances (tests/testMarginals.cpp:76-107)."""
     planar_slam_marginals_check(orc.oracle_backend, [[1, 2, 3, 11, 12]])
