@@ -707,3 +707,54 @@ class GaussNewtonOptimizer(_OptimizerBase):
     def optimize(self) -> Values:
         self.result = self.backend.gn_optimize(*self._p)
         return self.values()
+
+
+class JointMarginal:
+    """gtsam/nonlinear/Marginals.h:140-190: blocks of a joint covariance by key; keys sorted as the reference returns them."""
+
+    def __init__(self, matrix, keys, dims):
+        self._m, self._keys = matrix, list(keys)
+        self._off = dict(zip(self._keys, np.concatenate([[0], np.cumsum(dims)[:-1]]).astype(int)))
+        self._dim = dict(zip(self._keys, dims))
+
+    def at(self, iVariable, jVariable):
+        i, j = self._off[iVariable], self._off[jVariable]
+        return self._m[i:i + self._dim[iVariable], j:j + self._dim[jVariable]]
+
+    __call__ = at
+
+    def fullMatrix(self):
+        return self._m
+
+    def keys(self):
+        return list(self._keys)
+
+
+class Marginals:
+    """gtsam/nonlinear/Marginals.h:32-138 on the device factorization: Marginals(graph, solution).marginalCovariance(key),
+    .marginalInformation(key), .jointMarginalCovariance(keys), .jointMarginalInformation(keys).  (The reference's
+    CHOLESKY / QR switch has no counterpart: the Bayes tree here is always the Cholesky one.)"""
+
+    def __init__(self, graph, solution, ordering=None, backend_factory=None, orderingType="COLAMD"):
+        self.arrays = graph.to_arrays(solution)
+        self.backend = _make_backend(self.arrays, backend_factory)
+        if ordering is None:
+            kind = {"COLAMD": A.ORDER_MINDEGREE, "METIS": A.ORDER_ND, "NATURAL": A.ORDER_NATURAL}[orderingType]
+            ordering = self.backend.compute_ordering(kind)
+        self.backend.set_ordering([int(k) for k in ordering])
+        self.backend.linearize()
+
+    def marginalCovariance(self, key):
+        return self.backend.marginal_covariance(key)
+
+    def marginalInformation(self, key):
+        return np.linalg.inv(self.marginalCovariance(key))
+
+    def jointMarginalCovariance(self, variables) -> JointMarginal:
+        keys = sorted(int(k) for k in variables)
+        dims = [int(self.arrays.var_dims[int(np.searchsorted(self.arrays.var_keys, np.uint64(k)))]) for k in keys]
+        return JointMarginal(self.backend.joint_marginal_covariance(keys), keys, dims)
+
+    def jointMarginalInformation(self, variables) -> JointMarginal:
+        j = self.jointMarginalCovariance(variables)
+        return JointMarginal(np.linalg.inv(j.fullMatrix()), j.keys(), [j._dim[k] for k in j.keys()])

@@ -798,6 +798,31 @@ def planar_slam_joint_marginals_check(backend_factory, orderings):
 
 def test_planarSLAMjointMarginals(orc):
     planar_slam_joint_marginals_check(orc.oracle_backend, [[1, 2, 3, 11, 12]])
+    # the class mirror, with the reference's own symbols (blocks come back sorted by key: l2 < x1 < x3)
+    from gtsam_petercdev_amd.graph import Marginals, BearingRangeFactor
+    g = NonlinearFactorGraph()
+    x1, x2, x3, l1, l2 = X(1), X(2), X(3), L(1), L(2)
+    g.add(PriorFactor(x1, Pose2(0.0, 0.0, 0.0), noiseModel.Diagonal.Sigmas([0.3, 0.3, 0.1])))
+    odo = noiseModel.Diagonal.Sigmas([0.2, 0.2, 0.1])
+    g.add(BetweenFactor(x1, x2, Pose2(2.0, 0.0, 0.0), odo))
+    g.add(BetweenFactor(x2, x3, Pose2(2.0, 0.0, 0.0), odo))
+    meas = noiseModel.Diagonal.Sigmas([0.1, 0.2])
+    g.add(BearingRangeFactor(x1, l1, math.radians(45), math.sqrt(8.0), meas))
+    g.add(BearingRangeFactor(x2, l1, math.radians(90), 2.0, meas))
+    g.add(BearingRangeFactor(x3, l2, math.radians(90), 2.0, meas))
+    v = Values()
+    for k, p in ((x1, Pose2(0.0, 0.0, 0.0)), (x2, Pose2(2.0, 0.0, 0.0)), (x3, Pose2(4.0, 0.0, 0.0))):
+        v.insert(k, p)
+    v.insert(l1, Point2(2.0, 2.0))
+    v.insert(l2, Point2(4.0, 2.0))
+    m = Marginals(g, v, ordering=[x1, x2, x3, l1, l2], backend_factory=orc.oracle_backend)
+    assert np.allclose(m.marginalCovariance(x2), PLANAR_SLAM_MARGINALS[2], atol=1e-8)
+    joint = m.jointMarginalCovariance([x1, l2, x3])
+    assert joint.keys() == [l2, x1, x3]
+    E = PLANAR_SLAM_JOINT_L2X1X3
+    assert np.allclose(joint(l2, l2), E[0:2, 0:2], atol=1e-6) and np.allclose(joint(x1, l2), E[2:5, 0:2], atol=1e-6)
+    assert np.allclose(joint(x3, l2), E[5:8, 0:2], atol=1e-6) and np.allclose(joint(x1, x3), E[2:5, 5:8], atol=1e-6)
+    assert np.allclose(joint.fullMatrix(), E, atol=1e-6)
 
 
 def test_planarSLAMmarginals(orc):
