@@ -199,6 +199,32 @@ def write_g2o(path: str, arrays: A.ProblemArrays, packed_values) -> None:
         raise A.GsxError(st, "gsx_write_g2o", str(path))
 
 
+def save2d(path: str, arrays: A.ProblemArrays, packed_values, model_sigmas) -> None:
+    """save2D of the reference (gsx_save2d, include/gsx.h): TORO VERTEX2 / EDGE2 file."""
+    lib = load()
+    lib.gsx_save2d.restype = C.c_int32
+    vals = np.ascontiguousarray(packed_values, dtype=np.float64)
+    ms = np.ascontiguousarray(model_sigmas, dtype=np.float64)
+    assert ms.size == 3
+    desc = arrays.desc()
+    st = lib.gsx_save2d(C.byref(desc), vals.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(vals.size),
+                        ms.ctypes.data_as(C.POINTER(C.c_double)), str(path).encode())
+    if st != A.GSX_OK:
+        raise A.GsxError(st, "gsx_save2d", str(path))
+
+
+def write_bal(path: str, arrays: A.ProblemArrays, packed_values) -> None:
+    """writeBALfromValues of the reference (gsx_write_bal, include/gsx.h)."""
+    lib = load()
+    lib.gsx_write_bal.restype = C.c_int32
+    vals = np.ascontiguousarray(packed_values, dtype=np.float64)
+    desc = arrays.desc()
+    st = lib.gsx_write_bal(C.byref(desc), vals.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(vals.size),
+                           str(path).encode())
+    if st != A.GSX_OK:
+        raise A.GsxError(st, "gsx_write_bal", str(path))
+
+
 def dogleg_point(delta: float, dx_u, dx_n) -> np.ndarray:
     """DoglegOptimizerImpl::ComputeDoglegPoint (gsx_dogleg_point, host)."""
     u = np.ascontiguousarray(dx_u, dtype=np.float64)

@@ -83,6 +83,32 @@ void so3_expmap(const double* w, double* R) {  // gtsam/geometry/SO3.cpp:61-96, 
   for (int i = 0; i < 9; ++i) R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + a * W[i] + b * WW[i];
 }
 
+// Rodrigues vector of a rotation matrix (row-major) — Rot3::Logmap; through the unit quaternion, which stays accurate
+// near 0 and near pi
+void so3_logmap(const double* R, double* w) {
+  double q[4];  // (w, x, y, z)
+  const double tr = R[0] + R[4] + R[8];
+  if (tr > 0) {
+    const double s = std::sqrt(tr + 1.0) * 2;
+    q[0] = 0.25 * s; q[1] = (R[7] - R[5]) / s; q[2] = (R[2] - R[6]) / s; q[3] = (R[3] - R[1]) / s;
+  } else {
+    int i = 0;
+    if (R[4] > R[0]) i = 1;
+    if (R[8] > R[i * 4]) i = 2;
+    const int j = (i + 1) % 3, k = (i + 2) % 3;
+    const double s = std::sqrt(1.0 + R[i * 4] - R[j * 4] - R[k * 4]) * 2;
+    q[0] = (R[k * 3 + j] - R[j * 3 + k]) / s;
+    q[1 + i] = 0.25 * s;
+    q[1 + j] = (R[j * 3 + i] + R[i * 3 + j]) / s;
+    q[1 + k] = (R[k * 3 + i] + R[i * 3 + k]) / s;
+  }
+  if (q[0] < 0)
+    for (double& x : q) x = -x;
+  const double n = std::sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const double scale = n < 1e-12 ? 2.0 : 2.0 * std::atan2(n, q[0]) / n;
+  w[0] = scale * q[1]; w[1] = scale * q[2]; w[2] = scale * q[3];
+}
+
 // Rot3::Ypr(y, p, r) = Rz(y) Ry(p) Rx(r) (gtsam/geometry/Rot3.h), row-major
 void ypr_to_R(double y, double p, double r, double* R) {
   const double cy = std::cos(y), sy = std::sin(y), cp = std::cos(p), sp = std::sin(p), cr = std::cos(r), sr = std::sin(r);
@@ -598,6 +624,99 @@ void gsx_dataset_free(gsx_dataset* D) { delete D; }
 // EDGE_SE3:QUAT for the between factors with the upper triangle of the information matrix (3-D: permuted back to the
 // file's (t, R) order).  Priors and other factor types are not part of the format.  17 significant digits: the file
 // reads back to the same doubles.
+// save2D — gtsam/slam/dataset.cpp:587-617: VERTEX2 lines for the Pose2 values, and for every BetweenFactor<Pose2> an
+// EDGE2 line with the keys swapped and the measurement inverted, all with the information R'R of the ONE model handed in,
+// in TORO order (the reference does not use the factors' own models either).
+gsx_status gsx_save2d(const gsx_problem_desc* d, const double* values, int64_t n_values, const double* model_sigmas,
+                      const char* path) {
+  if (!d || !values || !path || !model_sigmas) return GSX_E_INVALID;
+  std::vector<int64_t> soff(d->n_vars + 1, 0);
+  for (int v = 0; v < d->n_vars; ++v) {
+    const int t = d->var_types[v];
+    soff[v + 1] = soff[v] + (t == GSX_VAR_POSE2 ? 3 : (t == GSX_VAR_POSE3 ? 12 : (t == GSX_VAR_CAMERA ? 17 : d->var_dims[v])));
+  }
+  if (soff[d->n_vars] != n_values) return GSX_E_INVALID;
+  FILE* fh = std::fopen(path, "w");
+  if (!fh) return GSX_E_INVALID;
+  for (int v = 0; v < d->n_vars; ++v)
+    if (d->var_types[v] == GSX_VAR_POSE2) {
+      const double* s = values + soff[v];
+      std::fprintf(fh, "VERTEX2 %llu %.17g %.17g %.17g\n", (unsigned long long)d->var_keys[v], s[0], s[1],
+                   std::atan2(std::sin(s[2]), std::cos(s[2])));
+    }
+  const double i0 = 1.0 / (model_sigmas[0] * model_sigmas[0]), i1 = 1.0 / (model_sigmas[1] * model_sigmas[1]),
+               i2 = 1.0 / (model_sigmas[2] * model_sigmas[2]);
+  for (int f = 0; f < d->n_factors; ++f) {
+    if (d->f_type[f] != GSX_F_BETWEEN || d->f_rows[f] != 3) continue;
+    const int a = d->f_vars[d->f_key_ptr[f]], b = d->f_vars[d->f_key_ptr[f] + 1];
+    if (d->var_types[a] != GSX_VAR_POSE2) continue;
+    const double* z = d->meas + d->f_meas_ptr[f];
+    const double c = std::cos(z[2]), s = std::sin(z[2]);
+    // Pose2::inverse: (-R' t, -theta)
+    std::fprintf(fh, "EDGE2 %llu %llu %.17g %.17g %.17g %.17g 0 %.17g %.17g 0 0\n", (unsigned long long)d->var_keys[b],
+                 (unsigned long long)d->var_keys[a], -(c * z[0] + s * z[1]), -(-s * z[0] + c * z[1]),
+                 std::atan2(-s, c), i0, i1, i2);
+  }
+  std::fclose(fh);
+  return GSX_OK;
+}
+
+// writeBAL / writeBALfromValues — gtsam/sfm/SfmData.cpp:249-377: the cameras and points of `values` and the
+// observations of the GeneralSFMFactors, grouped by point in file order of the factors; pose back to the OpenGL
+// convention (gtsam2openGL, :88-99), rotation as its Rodrigues vector, measurement (u, -v).  17 significant digits
+// (the reference writes its stream's default 6).
+gsx_status gsx_write_bal(const gsx_problem_desc* d, const double* values, int64_t n_values, const char* path) {
+  if (!d || !values || !path) return GSX_E_INVALID;
+  std::vector<int64_t> soff(d->n_vars + 1, 0);
+  std::vector<int> cam_id(d->n_vars, -1), pt_id(d->n_vars, -1);
+  int nc = 0, np = 0;
+  for (int v = 0; v < d->n_vars; ++v) {
+    const int t = d->var_types[v];
+    soff[v + 1] = soff[v] + (t == GSX_VAR_POSE2 ? 3 : (t == GSX_VAR_POSE3 ? 12 : (t == GSX_VAR_CAMERA ? 17 : d->var_dims[v])));
+    if (t == GSX_VAR_CAMERA) cam_id[v] = nc++;
+    else if (t == GSX_VAR_VECTOR && d->var_dims[v] == 3) pt_id[v] = np++;
+  }
+  if (soff[d->n_vars] != n_values || nc == 0 || np == 0) return GSX_E_INVALID;
+  std::vector<std::vector<int>> track(np);  // point -> SFM factors, in factor order
+  long long nobs = 0;
+  for (int f = 0; f < d->n_factors; ++f) {
+    if (d->f_type[f] != GSX_F_SFM) continue;
+    const int p = pt_id[d->f_vars[d->f_key_ptr[f] + 1]];
+    if (p < 0 || cam_id[d->f_vars[d->f_key_ptr[f]]] < 0) return GSX_E_INVALID;
+    track[p].push_back(f);
+    ++nobs;
+  }
+  FILE* fh = std::fopen(path, "w");
+  if (!fh) return GSX_E_INVALID;
+  std::fprintf(fh, "%d %d %lld\n\n", nc, np, nobs);
+  for (int p = 0; p < np; ++p)
+    for (int f : track[p]) {
+      const double* z = d->meas + d->f_meas_ptr[f];
+      std::fprintf(fh, "%d %d %.17g %.17g\n", cam_id[d->f_vars[d->f_key_ptr[f]]], p, z[0], -z[1]);
+    }
+  std::fprintf(fh, "\n");
+  for (int v = 0; v < d->n_vars; ++v) {
+    if (cam_id[v] < 0) continue;
+    const double* s = values + soff[v];
+    // cRw_openGL = R90 * wRc' with R90 = diag(1, -1, -1); t_openGL = cRw_openGL * (-t)
+    double R[9], t[3];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) R[r * 3 + c] = (r == 0 ? 1.0 : -1.0) * s[c * 3 + r];
+    for (int r = 0; r < 3; ++r) t[r] = -(R[r * 3] * s[9] + R[r * 3 + 1] * s[10] + R[r * 3 + 2] * s[11]);
+    double w[3];
+    so3_logmap(R, w);
+    std::fprintf(fh, "%.17g\n%.17g\n%.17g\n%.17g\n%.17g\n%.17g\n%.17g\n%.17g\n%.17g\n\n", w[0], w[1], w[2], t[0], t[1], t[2],
+                 s[12], s[13], s[14]);
+  }
+  for (int v = 0; v < d->n_vars; ++v) {
+    if (pt_id[v] < 0) continue;
+    const double* s = values + soff[v];
+    std::fprintf(fh, "%.17g\n%.17g\n%.17g\n\n", s[0], s[1], s[2]);
+  }
+  std::fclose(fh);
+  return GSX_OK;
+}
+
 gsx_status gsx_write_g2o(const gsx_problem_desc* d, const double* values, int64_t n_values, const char* path) {
   if (!d || !values || !path) return GSX_E_INVALID;
   std::vector<int64_t> soff(d->n_vars + 1, 0);

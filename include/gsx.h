@@ -261,6 +261,15 @@ void gsx_dataset_free(gsx_dataset* d);
 /* writeG2o (gtsam/slam/dataset.cpp:636-735): the Pose2 / Pose3 variables and the between factors of a problem with the
  * given packed Values, in g2o format (17 significant digits). */
 gsx_status gsx_write_g2o(const gsx_problem_desc* desc, const double* values, int64_t n_values, const char* path);
+/* save2D (gtsam/slam/dataset.cpp:587-617): VERTEX2 lines for the Pose2 values; for every BetweenFactor<Pose2> an EDGE2
+ * line with the keys swapped and the measurement inverted, carrying the information of the ONE Diagonal model handed in
+ * (3 sigmas) in TORO order — as the reference, which ignores the factors' own models there. */
+gsx_status gsx_save2d(const gsx_problem_desc* desc, const double* values, int64_t n_values, const double* model_sigmas,
+                      const char* path);
+/* writeBAL / writeBALfromValues (gtsam/sfm/SfmData.cpp:249-377): cameras and points of `values`, the observations of the
+ * GSX_F_SFM factors grouped by point; poses back in the OpenGL convention (gtsam2openGL :88-99), rotations as Rodrigues
+ * vectors, measurements (u, -v); 17 significant digits. */
+gsx_status gsx_write_bal(const gsx_problem_desc* desc, const double* values, int64_t n_values, const char* path);
 
 /* ---- lifecycle ------------------------------------------------------------ */
 gsx_status gsx_create(const gsx_problem_desc* desc, int32_t device, gsx_handle* out);

@@ -356,3 +356,43 @@ def test_read_toro_3d_sphere2500(golden_dir):
     assert np.allclose(arr.values[:12], [1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0]) and np.allclose(arr.values[12:24], arr.meas[:12])
     Rs = arr.values.reshape(2500, 12)[:, :9].reshape(2500, 3, 3)
     assert np.allclose(Rs @ Rs.transpose(0, 2, 1), np.eye(3), atol=1e-9)
+
+
+def test_save2D_round_trip(golden_dir, tmp_path):
+    """save2D (dataset.cpp:587-617): VERTEX2 + EDGE2 with swapped keys, inverted measurement and the one model's
+    information in TORO order; read back with load2D(TORO) every edge is the inverse of the original."""
+    arr = _lib.load2d(os.path.join(golden_dir, "w100.graph"))
+    sig = [0.05, 0.1, 0.02]
+    out = tmp_path / "w100_saved.graph"
+    _lib.save2d(str(out), arr, arr.values, sig)
+    lines = out.read_text().splitlines()
+    assert sum(l.startswith("VERTEX2 ") for l in lines) == 100 and sum(l.startswith("EDGE2 ") for l in lines) == 300
+    back = _lib.load2d(str(out), noise_format=A.NOISE_FORMAT_TORO)
+    assert back.n_vars == 100 and back.n_factors == 300 and np.allclose(back.values, arr.values, atol=1e-15)
+    assert np.all(back.f_noise_kind == A.NOISE_DIAGONAL) and np.allclose(back.noise[:3], sig, rtol=1e-14)
+    for f in (0, 7, 299):
+        a, b = arr.f_vars[2 * f:2 * f + 2]
+        assert back.f_vars[2 * f:2 * f + 2].tolist() == [b, a]
+        x, y, th = arr.meas[3 * f:3 * f + 3]
+        c, s = np.cos(th), np.sin(th)
+        assert np.allclose(back.meas[3 * f:3 * f + 3], [-(c * x + s * y), -(-s * x + c * y), -th], atol=1e-15)
+
+
+def test_writeBAL_round_trip(golden_dir, tmp_path):
+    """writeBAL (SfmData.cpp:249-326): write the dubrovnik fixture from its lowered arrays, read it back: same cameras,
+    points and measurements (to the `float` the reader keeps: 1e-6), observations grouped by point."""
+    src = os.path.join(golden_dir, "dubrovnik-3-7-pre.txt")
+    arr = _lib.read_bal(src)
+    out = tmp_path / "dub.txt"
+    _lib.write_bal(str(out), arr, arr.values)
+    head = out.read_text().split()[:3]
+    assert [int(x) for x in head] == [3, 7, int((arr.f_type == A.F_SFM).sum())]
+    back = _lib.read_bal(str(out))
+    assert back.n_vars == arr.n_vars and back.n_factors == arr.n_factors
+    assert np.array_equal(back.var_keys, arr.var_keys) and np.array_equal(back.f_vars, arr.f_vars)
+    assert np.allclose(back.values, arr.values, rtol=0, atol=2e-6 * max(1.0, np.max(np.abs(arr.values))))
+    assert np.allclose(back.meas, arr.meas, rtol=1e-6)
+    # the optimisation problem is the same one: SFMExample_bal's initial error (examples/SFMExample_bal.cpp)
+    cams = back.values[:17 * 3].reshape(3, 17)
+    R = cams[:, :9].reshape(3, 3, 3)
+    assert np.allclose(R @ R.transpose(0, 2, 1), np.eye(3), atol=1e-12)
