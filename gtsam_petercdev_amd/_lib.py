@@ -46,6 +46,11 @@ class ShardInfo(C.Structure):
                 ("cap_flops", C.c_double), ("own_flops", C.c_double), ("total_flops", C.c_double)]
 
 
+class PartialStats(C.Structure):
+    _fields_ = [("n_factors_relinearized", C.c_int32), ("n_panels_reassembled", C.c_int32),
+                ("n_fronts_reeliminated", C.c_int32), ("n_fronts", C.c_int32)]
+
+
 class ProductBackend(A.Backend):
     def __init__(self, arrays: A.ProblemArrays, device: int = 0, host_only: bool = False):
         """host_only=True skips the upload of the initial values: only the host-side entry points
@@ -85,6 +90,21 @@ class ProductBackend(A.Backend):
         self._check(self._fn("get_shard")(self._h, C.byref(info), ip(owner), ip(owned)), "get_shard")
         d = {k: getattr(info, k) for k, _ in ShardInfo._fields_}
         return d, owner[:n.value], owned[:self.arrays.n_factors]
+
+    def relinearize_partial(self, keys, states=None) -> dict:
+        """gsx_relinearize_partial (include/gsx.h): move the variables `keys` to `states` (their packed states one after the
+        other; None = the handle's values are already current), re-linearize their factors and re-eliminate only the
+        cliques that hold them and their ancestors.  Returns the counts of what was redone."""
+        ks = np.ascontiguousarray(keys, dtype=np.uint64)
+        st = PartialStats()
+        if states is None:
+            sp, ns = None, 0
+        else:
+            sv = np.ascontiguousarray(states, dtype=np.float64)
+            sp, ns = sv.ctypes.data_as(C.POINTER(C.c_double)), sv.size
+        self._check(self._fn("relinearize_partial")(self._h, ks.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int32(ks.size),
+                                                    sp, C.c_int64(ns), C.byref(st)), "relinearize_partial")
+        return {k: getattr(st, k) for k, _ in PartialStats._fields_}
 
     def lm_trial(self, relinearize=True, lam=0.0, diagonal_damping=False, min_diagonal=1e-6, max_diagonal=1e32):
         """One LM trial without the policy (gsx_lm_trial): (linear error at 0, at delta, nonlinear error of the trial)."""

@@ -81,6 +81,9 @@ struct Symbolic {
   std::vector<int> gm_task, gm_slot, gm_nslots;   // multi-segment task -> first slot, number of slots
   std::vector<int> gm_lvl_ptr;                    // level -> multi-task range
   int g_max_slots = 0;                            // scratch slots needed (x 128 doubles), reused per level
+  // for partial re-elimination (gsx_relinearize_partial): variable -> factors CSR, gather task -> destination front
+  std::vector<int> vf_ptr, vf;
+  std::vector<int> gt_front;
   // sharding of ONE problem over the GPUs of a node (gsx_set_shard): the fronts whose subtree is cheaper than a share of
   // the whole tree form independent subtrees dealt to the ranks; the rest — the top of the tree, the "cap" — is
   // assembled from every rank's contributions with one all-reduce and factored by all ranks alike.

@@ -78,6 +78,9 @@ constexpr int kXScalars = 16;
 constexpr unsigned kXFact = 1u << 12, kXLin = 1u << 13;
 void launch_shard_pack(const double* scalars, const DevStatus* status, unsigned dirty, double* x, hipStream_t st);
 void launch_shard_unpack(const double* x, unsigned dirty, double* scalars, DevStatus* status, hipStream_t st);
+// states of `n` variables (packed one after the other in `src`, variable i at src_off[i]) into the values vector
+void launch_scatter_states(const DevProblem& P, const int* vars, const int* src_off, int n, const double* src,
+                           double* values, hipStream_t st);
 void launch_mask_copy(const double* in, const unsigned char* mask, int64_t n, double* out, hipStream_t st);
 
 enum { SC_LAMBDA = 0, SC_ERR = 1, SC_LIN0 = 2, SC_LIND = 3, SC_TRIAL_ERR = 4, SC_DOT0 = 5, SC_DOT1 = 6, SC_DOT2 = 7,

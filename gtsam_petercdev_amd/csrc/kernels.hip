@@ -1003,6 +1003,24 @@ void launch_mask_copy(const double* in, const unsigned char* mask, int64_t n, do
   if (n > 0) mask_copy_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(in, mask, n, out);
 }
 
+__device__ inline int state_len(int type, int dim) {
+  return type == GSX_VAR_POSE2 ? 3 : (type == GSX_VAR_POSE3 ? 12 : (type == GSX_VAR_CAMERA ? 17 : dim));
+}
+__global__ void scatter_states_kernel(DevProblem P, const int* vars, const int* src_off, int n, const double* src,
+                                      double* values) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int v = vars[i];
+  const int len = state_len(P.var_type[v], P.var_dim[v]);
+  const double* s = src + src_off[i];
+  double* d = values + P.var_state_off[v];
+  for (int k = 0; k < len; ++k) d[k] = s[k];
+}
+void launch_scatter_states(const DevProblem& P, const int* vars, const int* src_off, int n, const double* src,
+                           double* values, hipStream_t st) {
+  if (n > 0) scatter_states_kernel<<<(n + 255) / 256, 256, 0, st>>>(P, vars, src_off, n, src, values);
+}
+
 __global__ void set_scalar_kernel(double* scalars, int slot, double v) { scalars[slot] = v; }
 void launch_set_scalar(double* scalars, int slot, double v, hipStream_t st) {
   set_scalar_kernel<<<1, 1, 0, st>>>(scalars, slot, v);

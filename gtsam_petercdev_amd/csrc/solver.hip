@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <array>
 #include <map>
 #include <string>
 #include <vector>
@@ -42,6 +43,15 @@ struct DevBuf {
   hipError_t upload(const std::vector<Tp>& v, hipStream_t st) {
     hipError_t e = alloc(v.size() ? v.size() : 1);
     if (e != hipSuccess) return e;
+    if (v.empty()) return hipSuccess;
+    return hipMemcpyAsync(p, v.data(), v.size() * sizeof(Tp), hipMemcpyHostToDevice, st);
+  }
+  // reuse the allocation when it is large enough (scratch tables rebuilt at every call)
+  hipError_t stage(const std::vector<Tp>& v, hipStream_t st) {
+    if (v.size() > n || !p) {
+      hipError_t e = alloc(std::max<size_t>(std::max<size_t>(v.size(), 2 * n), 64));
+      if (e != hipSuccess) return e;
+    }
     if (v.empty()) return hipSuccess;
     return hipMemcpyAsync(p, v.data(), v.size() * sizeof(Tp), hipMemcpyHostToDevice, st);
   }
@@ -144,6 +154,20 @@ struct gsx_context {
   Timer timers[PH_COUNT];
   int profiling = 0;
   int64_t n_cheirality = 0;
+  // host copies of the launch tables, for the filtered plans of gsx_relinearize_partial
+  std::vector<LeafRec> h_leaf_recs;
+  std::vector<GatherSeg> h_gsegs;
+  std::vector<int> hv_list, hv_group_of_var, hv_pos;
+  std::vector<int> fr_sched_pos, fr_group;        // front -> position in the schedule; launch group / big-desc index
+  std::vector<int> fr_seg_ptr, fr_segs, seg_level; // destination front -> its gather segments; segment -> level
+  std::vector<int> fr_gm_ptr, fr_gms, gm_level;    // ... and its multi-segment combine entries
+  struct PartialScratch {                          // device tables of gsx_relinearize_partial, reused between calls
+    DevBuf<int> marked, src_off, lists[6], hv, ids, gm_task, gm_slot, gm_nslots;
+    DevBuf<double> states;
+    DevBuf<LeafRec> leaf;
+    DevBuf<BigDesc> big;
+    DevBuf<GatherSeg> segs;
+  } ps;
   // sharding (gsx_set_shard)
   int shard_rank = 0, shard_world = 1;
   gsx_allreduce_fn shard_cb = nullptr;
@@ -396,6 +420,7 @@ gsx_status upload_symbolic(gsx_context* c) {
                           S.fvar_ptr[f], f, 0, 0};
     }
     c->leaf_base = b;
+    c->h_leaf_recs = lr;
     HIPCHK(c, c->d_leaf_recs.upload(lr, st));
   }
   HIPCHK(c, c->d_H.alloc(std::max<int64_t>(S.h_size, 1)));
@@ -436,6 +461,14 @@ gsx_status upload_symbolic(gsx_context* c) {
     emit(light, 64, 1, false);
     emit(heavy, 256, 4, false);
     emit(huge, 64, 1, true);
+    c->hv_list = hv;
+    c->hv_group_of_var.assign(P.n_vars, -1);
+    c->hv_pos.assign(P.n_vars, -1);
+    for (size_t g = 0; g < c->hgroups.size(); ++g)
+      for (int k = c->hgroups[g].begin; k < c->hgroups[g].begin + c->hgroups[g].count; ++k) {
+        c->hv_group_of_var[hv[k]] = (int)g;
+        c->hv_pos[hv[k]] = k;
+      }
     HIPCHK(c, c->d_hvars.upload(hv, st));
   }
   // ---- factorization launch plan ---------------------------------------------------------------------
@@ -531,6 +564,35 @@ gsx_status upload_symbolic(gsx_context* c) {
       }
     }
   }
+  // front -> where it sits in the launch plan (for the filtered plans of gsx_relinearize_partial)
+  c->fr_sched_pos.assign(S.n_fronts, -1);
+  c->fr_group.assign(S.n_fronts, -1);
+  for (size_t k = 0; k < S.sched.size(); ++k) c->fr_sched_pos[S.sched[k]] = (int)k;
+  for (int l = 0; l < S.n_levels; ++l) {
+    for (size_t g = 0; g < c->leaf_launch[l].size(); ++g)
+      for (int k = c->leaf_launch[l][g].begin; k < c->leaf_launch[l][g].begin + c->leaf_launch[l][g].count; ++k)
+        c->fr_group[S.sched[k]] = (int)g;
+    for (size_t g = 0; g < c->small_launch[l].size(); ++g)
+      for (int k = c->small_launch[l][g].begin; k < c->small_launch[l][g].begin + c->small_launch[l][g].count; ++k)
+        c->fr_group[S.sched[k]] = (int)g;
+  }
+  for (size_t k = 0; k < c->big_descs.size(); ++k) c->fr_group[c->big_descs[k].front] = (int)k;
+  {
+    auto csr = [&](const std::vector<int>& task_of, const std::vector<int>& lvl_ptr, std::vector<int>& ptr,
+                   std::vector<int>& items, std::vector<int>& level_of) {
+      ptr.assign(S.n_fronts + 1, 0);
+      level_of.assign(task_of.size(), 0);
+      for (int l = 0; l < S.n_levels; ++l)
+        for (int i = lvl_ptr[l]; i < lvl_ptr[l + 1]; ++i) level_of[i] = l;
+      for (int t : task_of) ptr[S.gt_front[t] + 1]++;
+      for (int f = 0; f < S.n_fronts; ++f) ptr[f + 1] += ptr[f];
+      items.resize(task_of.size());
+      std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+      for (size_t i = 0; i < task_of.size(); ++i) items[fill[S.gt_front[task_of[i]]]++] = (int)i;
+    };
+    csr(S.gseg_task, S.gseg_lvl_ptr, c->fr_seg_ptr, c->fr_segs, c->seg_level);
+    csr(S.gm_task, S.gm_lvl_ptr, c->fr_gm_ptr, c->fr_gms, c->gm_level);
+  }
   HIPCHK(c, c->d_big.upload(c->big_descs, st));
   {
     // gather sources as absolute arena offsets + leading dimension (no dependent metadata loads in the kernel)
@@ -555,6 +617,7 @@ gsx_status upload_symbolic(gsx_context* c) {
     HIPCHK(c, c->d_gt_ld.upload(S.gt_ld, st));
     HIPCHK(c, c->d_gt_dims.upload(S.gt_dims, st));
     HIPCHK(c, c->d_gsrcs.upload(srcs, st));
+    c->h_gsegs = segs;
     HIPCHK(c, c->d_gsegs.upload(segs, st));
     HIPCHK(c, c->d_gm_task.upload(S.gm_task, st));
     HIPCHK(c, c->d_gm_slot.upload(S.gm_slot, st));
@@ -1186,14 +1249,22 @@ gsx_status gsx_solve(gsx_handle h, double lambda, int32_t diagonal_damping, doub
   }
   hipSetDevice(h->device);
   if (!h->h_ready) dev_assemble_h(h);
-  dev_damping(h, diagonal_damping, min_diagonal, max_diagonal);
-  dev_factorize(h, lambda);
+  // (the undamped factorization of this very linearization may already be resident: after gsx_relinearize_partial,
+  // a marginal query or a previous lambda = 0 solve; then only the back-substitution runs)
+  if (!(lambda == 0.0 && h->fact_valid && h->fact_lambda == 0.0)) {
+    dev_damping(h, diagonal_damping, min_diagonal, max_diagonal);
+    dev_factorize(h, lambda);
+  } else {
+    launch_begin_factorization(h->d_scalars.p, 0.0, h->d_status.p, h->stream);  // status reset for the substitution
+    h->sc_dirty |= kXFact;
+  }
   dev_backsolve(h);
   st = readback(h);
   if (st != GSX_OK) return st;
   if (h->h_status->n_fail > 0 || h->h_status->n_nonfinite > 0) {
     if (bad_key) *bad_key = failing_key(h);
     h->solved = false;
+    h->fact_valid = false;
     h->err = "indeterminate linear system";
     return GSX_E_INDETERMINATE;
   }
@@ -1313,6 +1384,7 @@ gsx_status gsx_lm_trial(gsx_handle h, int32_t relinearize, double lambda, int32_
   if (st != GSX_OK) return st;
   if (h->h_status->n_fail > 0 || h->h_status->n_nonfinite > 0) {
     h->solved = false;
+    h->fact_valid = false;
     h->err = "indeterminate linear system";
     return GSX_E_INDETERMINATE;
   }
@@ -1558,6 +1630,270 @@ gsx_status gsx_dogleg_optimize(gsx_handle h, double delta_initial, int32_t max_i
 
 // Marginals::marginalCovariance(key) — gtsam/nonlinear/Marginals.cpp:107-136 — from the undamped factorization of the
 // current linearization (the block of H^-1 in the variable's tangent space), out: dA x dA column-major.
+// ---- partial relinearization and re-elimination on a fixed graph ---------------------------------------------------
+// The step at the heart of iSAM2's update (gtsam/nonlinear/ISAM2.cpp:419-484 relinearize the marked variables' factors,
+// :725-783 re-eliminate the top of the tree that contains them), on a fixed structure: the Bayes tree, its
+// factorization and every clean subtree's Schur complement stay resident in HBM; only what the moved variables touch
+// is redone — their factors' Jacobians, the H panels of those factors' variables, and the cliques holding them plus all
+// ancestors (a re-done clique is re-assembled from H and from ALL its children, whose stored contributions are intact).
+gsx_status gsx_relinearize_partial(gsx_handle h, const uint64_t* keys, int32_t n_keys, const double* states,
+                                   int64_t n_states, gsx_partial_stats* out) {
+  if (!h || (n_keys > 0 && !keys) || n_keys < 0) return GSX_E_INVALID;
+  gsx_status st = ensure_ready(h, true, true);
+  if (st != GSX_OK) return st;
+  if (h->sharded()) {
+    h->err = "partial re-elimination is not available on a sharded handle";
+    return GSX_E_STATE;
+  }
+  if (!h->linearized || !h->h_ready || !h->fact_valid || h->fact_lambda != 0.0) {
+    h->err = "gsx_relinearize_partial needs the resident undamped factorization of the current linearization "
+             "(gsx_linearize + gsx_solve with lambda = 0 first)";
+    return GSX_E_STATE;
+  }
+  hipSetDevice(h->device);
+  const HostProblem& P = h->P;
+  const Symbolic& S = h->S;
+  hipStream_t sm = h->stream;
+  // marked variables, and their new states
+  std::vector<int> marked(n_keys), src_off(n_keys);
+  std::vector<char> is_marked(P.n_vars, 0);
+  int64_t need = 0;
+  for (int k = 0; k < n_keys; ++k) {
+    auto it = std::lower_bound(P.keys.begin(), P.keys.end(), keys[k]);
+    if (it == P.keys.end() || *it != keys[k]) {
+      h->err = "gsx_relinearize_partial: a key is not a variable of the graph";
+      return GSX_E_INVALID;
+    }
+    const int v = (int)(it - P.keys.begin());
+    if (is_marked[v]) return GSX_E_INVALID;
+    is_marked[v] = 1;
+    marked[k] = v;
+    src_off[k] = (int)need;
+    need += (v + 1 < P.n_vars ? P.state_off[v + 1] : (int)P.state_size) - P.state_off[v];
+  }
+  if (states && n_states != need) return GSX_E_INVALID;
+  gsx_context::PartialScratch& ps = h->ps;
+  if (states && n_keys > 0) {
+    HIPCHK(h, ps.marked.stage(marked, sm));
+    HIPCHK(h, ps.src_off.stage(src_off, sm));
+    HIPCHK(h, ps.states.stage(std::vector<double>(states, states + need), sm));
+    launch_scatter_states(h->DP, ps.marked.p, ps.src_off.p, n_keys, ps.states.p, h->d_values.p, sm);
+    h->values_synced = true;
+  }
+  // what is dirty: factors touching a marked variable; the H panels of all their variables; those variables' cliques and
+  // every ancestor.  (Everything below is driven by the dirty lists, not by the size of the graph.)
+  std::vector<char> f_dirty(P.n_factors, 0), v_dirty(P.n_vars, 0), fr_dirty(S.n_fronts, 0);
+  std::vector<int> dfac, dvar, dfr;
+  for (int v : marked)
+    for (int k = S.vf_ptr[v]; k < S.vf_ptr[v + 1]; ++k) {
+      const int f = S.vf[k];
+      if (f_dirty[f]) continue;
+      f_dirty[f] = 1;
+      dfac.push_back(f);
+      for (int q = P.f_key_ptr[f]; q < P.f_key_ptr[f + 1]; ++q) {
+        const int u = P.f_vars[q];
+        if (!v_dirty[u]) {
+          v_dirty[u] = 1;
+          dvar.push_back(u);
+        }
+      }
+    }
+  for (int v : dvar)
+    for (int f = S.front_of_var[v]; f >= 0 && !fr_dirty[f]; f = S.parent[f]) {
+      fr_dirty[f] = 1;
+      dfr.push_back(f);
+    }
+  if (dfac.empty()) {
+    if (out) *out = gsx_partial_stats{0, 0, 0, S.n_fronts};
+    return GSX_OK;
+  }
+  {
+    // When most of the extend-add work of the tree is dirty anyway (the big cliques near the root carry most gather
+    // segments), filtering costs more on the host than it saves on the device: take the full path — same bits.
+    int64_t dseg = 0;
+    for (int f : dfr) dseg += h->fr_seg_ptr[f + 1] - h->fr_seg_ptr[f];
+    if ((dseg * 10 > (int64_t)h->h_gsegs.size() * 3 && (int64_t)dfr.size() * 20 > S.n_fronts) ||
+        (int64_t)dfr.size() * 100 > (int64_t)S.n_fronts * 15) {
+      if (out) *out = gsx_partial_stats{P.n_factors, P.n_vars, S.n_fronts, S.n_fronts};
+      dev_linearize(h);
+      dev_assemble_h(h);
+      dev_damping(h, 0, 0, 0);
+      dev_factorize(h, 0.0);
+      st = readback(h);
+      if (st != GSX_OK) return st;
+      if (h->h_status->n_fail > 0) {
+        h->fact_valid = false;
+        h->err = "indeterminate linear system";
+        return GSX_E_INDETERMINATE;
+      }
+      return GSX_OK;
+    }
+  }
+  if (out) *out = gsx_partial_stats{(int)dfac.size(), (int)dvar.size(), (int)dfr.size(), S.n_fronts};
+  // 1. the dirty factors' Jacobians (graph order inside each family, as in the full lists)
+  {
+    std::sort(dfac.begin(), dfac.end());
+    std::vector<int> lists[6];
+    for (int f : dfac) {
+      const int t = P.f_type[f];
+      const int vt = P.types[P.f_vars[P.f_key_ptr[f]]];
+      if (t == GSX_F_SFM) lists[0].push_back(f);
+      else if (t == GSX_F_PROJECTION) lists[4].push_back(f);
+      else if (t == GSX_F_BEARINGRANGE) lists[5].push_back(f);
+      else if (t == GSX_F_BETWEEN && vt == GSX_VAR_POSE2) lists[1].push_back(f);
+      else if (t == GSX_F_BETWEEN && vt == GSX_VAR_POSE3) lists[2].push_back(f);
+      else if (t != GSX_F_LINEAR) lists[3].push_back(f);
+    }
+    const int* lp[6];
+    int cnt[6];
+    for (int k = 0; k < 6; ++k) {
+      HIPCHK(h, ps.lists[k].stage(lists[k], sm));
+      lp[k] = ps.lists[k].p;
+      cnt[k] = (int)lists[k].size();
+    }
+    timer_begin(h, PH_LINEARIZE);
+    launch_linearize(h->DP, lp, cnt, h->d_values.p, h->d_jac.p, h->d_status.p, sm);
+    timer_end(h, PH_LINEARIZE);
+  }
+  // 2. the H panels of their variables, group by group with the groups' own launch shapes
+  {
+    std::sort(dvar.begin(), dvar.end(), [&](int a, int b) { return h->hv_pos[a] < h->hv_pos[b]; });
+    std::vector<std::pair<int, int>> ranges(h->hgroups.size(), {0, 0});
+    for (size_t i = 0; i < dvar.size(); ++i) {
+      std::pair<int, int>& r = ranges[h->hv_group_of_var[dvar[i]]];
+      if (!r.second) r.first = (int)i;
+      r.second++;
+    }
+    HIPCHK(h, ps.hv.stage(dvar, sm));
+    timer_begin(h, PH_ASSEMBLE_H);
+    for (size_t g = 0; g < h->hgroups.size(); ++g)
+      if (ranges[g].second)
+        launch_assemble_h_group(h->DP, h->DS, ps.hv.p + ranges[g].first, ranges[g].second, h->hgroups[g].threads,
+                                h->hgroups[g].lds, h->hgroups[g].global, h->d_jac.p, h->d_H.p, sm);
+    timer_end(h, PH_ASSEMBLE_H);
+    h->hdiag_ready = false;
+  }
+  // 3. the dirty cliques, level by level, in the order and with the launch shapes of the full schedule
+  {
+    std::sort(dfr.begin(), dfr.end(), [&](int a, int b) { return h->fr_sched_pos[a] < h->fr_sched_pos[b]; });
+    std::vector<LeafRec> leaf;
+    std::vector<int> ids;
+    std::vector<BigDesc> big;
+    std::vector<GatherSeg> segs;
+    std::vector<int> gm_task, gm_slot, gm_nslots;
+    struct LevelPlan {
+      std::vector<std::array<int, 4>> leaf;   // begin, count, max_panel, threads
+      std::vector<std::array<int, 4>> small;  // begin, count, max_n, threads
+      int big_begin = 0, big_count = 0, steps = 0;
+      std::vector<int> pairs;
+      std::vector<int> seg_idx, gm_idx;
+      int seg0 = 0, nseg = 0, m0 = 0, nm = 0;
+    };
+    std::vector<LevelPlan> plan(S.n_levels);
+    int big_max_n = 0, big_max_nfv = 0;
+    {
+      int last_level = -1, last_cls = -1, last_group = -1;
+      for (int f : dfr) {  // schedule order: level, then class, then launch group
+        const int l = S.level[f], cls = S.cls[f], g = h->fr_group[f];
+        LevelPlan& L = plan[l];
+        const bool same = l == last_level && cls == last_cls && (cls == 2 || g == last_group);
+        if (cls == 0) {
+          const SmallLaunch& sl = h->leaf_launch[l][g];
+          if (!same) L.leaf.push_back({(int)leaf.size(), 0, sl.max_panel, sl.threads});
+          L.leaf.back()[1]++;
+          leaf.push_back(h->h_leaf_recs[h->fr_sched_pos[f] - h->leaf_base]);
+        } else if (cls == 1) {
+          const SmallLaunch& sl = h->small_launch[l][g];
+          if (!same) L.small.push_back({(int)ids.size(), 0, sl.max_n, sl.threads});
+          L.small.back()[1]++;
+          ids.push_back(f);
+        } else {
+          if (!L.big_count) L.big_begin = (int)big.size();
+          const BigDesc& d = h->big_descs[g];
+          big.push_back(d);
+          L.big_count++;
+          L.steps = std::max(L.steps, (d.F + kTile - 1) / kTile);
+          big_max_n = std::max(big_max_n, d.N);
+          big_max_nfv = std::max(big_max_nfv, S.nfrontal_vars[f]);
+          // its gather segments (sources: ALL its children, clean or not), at the level the full schedule runs them
+          for (int k = h->fr_seg_ptr[f]; k < h->fr_seg_ptr[f + 1]; ++k)
+            plan[h->seg_level[h->fr_segs[k]]].seg_idx.push_back(h->fr_segs[k]);
+          for (int k = h->fr_gm_ptr[f]; k < h->fr_gm_ptr[f + 1]; ++k)
+            plan[h->gm_level[h->fr_gms[k]]].gm_idx.push_back(h->fr_gms[k]);
+        }
+        last_level = l;
+        last_cls = cls;
+        last_group = g;
+      }
+    }
+    for (int l = 0; l < S.n_levels; ++l) {
+      LevelPlan& L = plan[l];
+      L.pairs.assign(L.steps, 0);
+      for (int k = L.big_begin; k < L.big_begin + L.big_count; ++k)
+        for (int kb = 0; kb * kTile < big[k].F; ++kb) {
+          const int c0 = kb * kTile, w = std::min(kTile, big[k].F - c0), nt = (big[k].N - (c0 + w) + kTile - 1) / kTile;
+          L.pairs[kb] = std::max(L.pairs[kb], nt * (nt + 1) / 2);
+        }
+      // (no particular order is needed: every segment adds into its own destination block or its own scratch slot)
+      L.seg0 = (int)segs.size();
+      for (int i : L.seg_idx) segs.push_back(h->h_gsegs[i]);
+      L.nseg = (int)L.seg_idx.size();
+      L.m0 = (int)gm_task.size();
+      for (int i : L.gm_idx) {
+        gm_task.push_back(S.gm_task[i]);
+        gm_slot.push_back(S.gm_slot[i]);
+        gm_nslots.push_back(S.gm_nslots[i]);
+      }
+      L.nm = (int)L.gm_idx.size();
+    }
+    HIPCHK(h, ps.leaf.stage(leaf, sm));
+    HIPCHK(h, ps.ids.stage(ids, sm));
+    HIPCHK(h, ps.big.stage(big, sm));
+    HIPCHK(h, ps.segs.stage(segs, sm));
+    HIPCHK(h, ps.gm_task.stage(gm_task, sm));
+    HIPCHK(h, ps.gm_slot.stage(gm_slot, sm));
+    HIPCHK(h, ps.gm_nslots.stage(gm_nslots, sm));
+    GatherArgs GA = h->GA;
+    GA.segs = ps.segs.p;
+    GA.gm_task = ps.gm_task.p;
+    GA.gm_slot = ps.gm_slot.p;
+    GA.gm_nslots = ps.gm_nslots.p;
+    h->sc_dirty |= kXFact;
+    timer_begin(h, PH_FACTORIZE);
+    launch_begin_factorization(h->d_scalars.p, 0.0, h->d_status.p, sm);
+    dev_damping(h, 0, 0, 0);
+    if (!big.empty())
+      launch_big_init(h->DP, h->DS, ps.big.p, (int)big.size(), big_max_n, big_max_nfv, h->d_H.p, h->d_damp.p,
+                      h->d_scalars.p, h->d_arena.p, sm);
+    for (int l = 0; l < S.n_levels; ++l) {
+      const LevelPlan& L = plan[l];
+      for (const auto& g : L.leaf)
+        launch_front_leaf(h->DP, h->DS, ps.leaf.p + g[0], g[1], g[2], g[3], h->d_H.p, h->d_damp.p, h->d_scalars.p,
+                          h->d_arena.p, h->d_status.p, sm);
+      for (const auto& g : L.small)
+        launch_front_small(h->DP, h->DS, ps.ids.p + g[0], g[1], g[2], g[3], h->d_H.p, h->d_damp.p, h->d_scalars.p,
+                           h->d_arena.p, h->d_status.p, sm);
+      if (l == 0 && L.nseg) launch_big_gather(GA, L.seg0, L.nseg, L.m0, L.nm, h->d_arena.p, sm);  // gather group 0
+      if (L.big_count) {
+        if (l > 0 && L.nseg) launch_big_gather(GA, L.seg0, L.nseg, L.m0, L.nm, h->d_arena.p, sm);
+        launch_big_potrf0(ps.big.p + L.big_begin, L.big_count, h->d_arena.p, h->d_status.p, sm);
+        for (int kb = 0; kb < L.steps; ++kb)
+          launch_big_step(ps.big.p + L.big_begin, L.big_count, kb, L.pairs[kb], h->d_arena.p, h->d_status.p, sm);
+      }
+    }
+    timer_end(h, PH_FACTORIZE);
+  }
+  h->solved = false;
+  st = readback(h);  // (also keeps the temporary tables alive until the launches have run)
+  if (st != GSX_OK) return st;
+  if (h->h_status->n_fail > 0) {
+    h->fact_valid = false;
+    h->err = "indeterminate linear system";
+    return GSX_E_INDETERMINATE;
+  }
+  return GSX_OK;
+}
+
 namespace {
 // the undamped factorization of the current linearization, resident in the arena (shared by the marginal entry points)
 gsx_status marginals_prepare(gsx_handle h) {

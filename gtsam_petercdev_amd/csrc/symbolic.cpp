@@ -48,6 +48,8 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     for (int f = 0; f < m; ++f)
       for (int k = P.f_key_ptr[f]; k < P.f_key_ptr[f + 1]; ++k) vf[fill[P.f_vars[k]]++] = f;
   }
+  S.vf_ptr = vf_ptr;
+  S.vf = vf;
   // ---- elimination tree (nodes are elimination positions) -------------------------------------
   std::vector<int> eparent(n, -1), ancestor(n, -1), prevCol(m, -1);
   std::vector<int> ech_ptr(n + 1, 0);
@@ -543,7 +545,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
   // ---- gather tasks for big parents ------------------------------------------------------------------------
   {
     struct Contribution {
-      int level;
+      int level, front;
       int64_t dst;
       int ld, dims, child, loc, loc2;   // loc2 >= 0: lean child, product form (rows loc.., rows loc2.. of its L panel)
     };
@@ -588,6 +590,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
             // a subtree's contribution to a cap front goes in with the first cap level, before the exchange; the cap
             // fronts' own contributions follow level by level after it, the same on every rank
             c.level = (S.owner[p] < 0 && S.owner[ch] >= 0) ? S.cap_level0 : S.level[p];
+            c.front = p;
             c.dst = S.off[p] + poff[b] + (int64_t)poff[a] * S.N[p];
             c.ld = S.N[p];
             c.dims = dim[b] | (dim[a] << 8) | ((a == b) ? (1 << 16) : 0);
@@ -620,6 +623,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
         S.gt_dst.push_back(cs[i].dst);
         S.gt_ld.push_back(cs[i].ld);
         S.gt_dims.push_back(cs[i].dims);
+        S.gt_front.push_back(cs[i].front);
         S.gt_ptr.push_back((int64_t)i);
         S.gt_lvl_ptr[cs[i].level + 1]++;
       }

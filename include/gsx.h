@@ -392,6 +392,25 @@ gsx_status gsx_marginal_covariance(gsx_handle h, uint64_t key, double* out, int6
  * variables, D x D row-major with D = sum of their dimensions, blocks in the order of `keys` (the reference returns
  * them sorted by key: pass sorted keys for the same layout). */
 gsx_status gsx_joint_marginal_covariance(gsx_handle h, const uint64_t* keys, int32_t n_keys, double* out, int64_t n_out);
+
+/* ---- partial relinearization / re-elimination on a fixed graph (first step) ----------------------
+ * The numeric core of an iSAM2 update (gtsam/nonlinear/ISAM2.cpp:419-484: relinearize the factors of the variables
+ * whose linearization point moved; :725-783: re-eliminate the part of the Bayes tree that contains them) on a FIXED
+ * structure: graph, ordering and Bayes tree stay as they are; the factorization and every untouched subtree's Schur
+ * complement stay resident in HBM.  Given the moved variables (`keys`; `states` = their new packed states one after the
+ * other in that order, or NULL when the handle's values are already current) the call re-linearizes only the factors
+ * touching them, re-assembles only the H panels of those factors' variables, and re-eliminates only the cliques holding
+ * those variables and their ancestors.  The result is bit-identical to a full gsx_linearize + gsx_solve(lambda = 0)
+ * factorization at the same values.  Needs the resident undamped factorization of the current linearization
+ * (GSX_E_STATE otherwise); follow with gsx_solve(h, 0, ...) — which then only back-substitutes — or the marginal queries.
+ * When most of the tree is dirty anyway the call takes the full path (same bits; the stats then report everything).
+ * Not here yet: adding factors / variables (tree surgery with constrained re-ordering) and the partial ("wildfire")
+ * back-substitution. */
+typedef struct gsx_partial_stats {
+  int32_t n_factors_relinearized, n_panels_reassembled, n_fronts_reeliminated, n_fronts;
+} gsx_partial_stats;
+gsx_status gsx_relinearize_partial(gsx_handle h, const uint64_t* keys, int32_t n_keys, const double* states,
+                                   int64_t n_states, gsx_partial_stats* out);
 /* DoglegOptimizerImpl::ComputeDoglegPoint (DoglegOptimizerImpl.cpp:26-86) on plain vectors (host). */
 gsx_status gsx_dogleg_point(double delta, const double* dx_u, const double* dx_n, int64_t n, double* out);
 

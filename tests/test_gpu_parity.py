@@ -716,3 +716,90 @@ def test_joint_marginal_matches_oracle(gpu, oracle, name):
     assert np.max(np.abs(Jg - Jo)) <= 1e-7 * np.max(np.abs(Jo))
     with pytest.raises(gt.GsxError):
         gb.joint_marginal_covariance([keys[0], keys[0]])
+
+
+# ---- partial relinearization / re-elimination (gsx_relinearize_partial) -------------------------------------------
+def _state_slices(arr):
+    off = np.concatenate([[0], np.cumsum(arr.state_dims())])
+    return off
+
+
+@pytest.mark.parametrize("name", ["pose3", "pose2", "bal_small", "bal_bigfront", "visual_slam"])
+@pytest.mark.parametrize("relax", [0.0, 0.5])
+def test_partial_reelimination_is_bit_identical(gpu, name, relax):
+    """Move a few variables, redo only what they touch: the factorization, the solution, the Jacobians and a marginal are
+    bit for bit those of a full relinearization + elimination at the same values; several updates in a row; what was
+    redone is a fraction of the tree."""
+    arr = _visual_slam_arrays() if name == "visual_slam" else PROBLEMS[name]
+    kind = A.ORDER_SCHUR_ND if name.startswith("bal") or name == "visual_slam" else A.ORDER_ND
+    P, F = gpu.product_backend(arr), gpu.product_backend(arr)
+    ordering = P.compute_ordering(kind)
+    for be in (P, F):
+        be.set_amalgamation(relax, 128)
+        be.set_ordering(ordering)
+    with pytest.raises(gt.GsxError) as ei:
+        P.relinearize_partial([int(arr.var_keys[0])])      # nothing resident yet
+    assert ei.value.status == A.GSX_E_STATE
+    P.linearize()
+    d0 = P.solve(0.0, False)
+    # where a Gauss-Newton step would move everything
+    F.linearize()
+    F.solve(0.0, False)
+    F.retract(None, commit=True)
+    x0, x1 = arr.values.copy(), F.get_values()
+    off = _state_slices(arr)
+    rng = np.random.default_rng(7)
+    current = x0.copy()
+    for round_ in range(3):
+        n_move = max(1, arr.n_vars // (40 if round_ < 2 else 6))
+        # a stretch of consecutive variables (one region of the trajectory / a few cameras) first, scattered sets after
+        idx = np.arange(n_move) if round_ == 0 else np.sort(rng.choice(arr.n_vars, n_move, replace=False))
+        target = x0 if round_ == 2 else x1        # two sets forward to the Gauss-Newton point, then a large set back
+        states = np.concatenate([target[off[i]:off[i + 1]] for i in idx])
+        for i in idx:
+            current[off[i]:off[i + 1]] = target[off[i]:off[i + 1]]
+        stats = P.relinearize_partial(arr.var_keys[idx], states)
+        assert 0 < stats["n_fronts_reeliminated"] <= stats["n_fronts"]
+        # (a set that dirties most of a small tree takes the full path inside the call: same bits)
+        dp = P.solve(0.0, False)
+        F.set_values(current)
+        F.linearize()
+        df = F.solve(0.0, False)
+        assert np.array_equal(P.get_values(), current)
+        assert np.array_equal(P.jacobians(), F.jacobians()), (name, round_)
+        assert np.array_equal(dp, df), (name, round_, float(np.max(np.abs(dp - df))))
+        assert np.array_equal(P.hessian_diagonal(), F.hessian_diagonal())
+        k = int(arr.var_keys[idx[0]])
+        assert np.array_equal(P.marginal_covariance(k), F.marginal_covariance(k))
+    assert not np.array_equal(dp, d0)
+    with pytest.raises(gt.GsxError):
+        P.relinearize_partial([int(arr.var_keys[0]), int(arr.var_keys[0])])
+
+
+def test_partial_reelimination_touches_a_fraction(gpu):
+    """3000 poses, the 10 most recent ones move (an iSAM2-style update): a few dozen of the ~700 cliques are redone, the
+    result is bit for bit the full one, and a second update on top of the first stays exact."""
+    arr = datasets.synth_manhattan_pose3(3000, seed=9)
+    P, F = gpu.product_backend(arr), gpu.product_backend(arr)
+    ordering = P.compute_ordering(A.ORDER_ND)
+    for be in (P, F):
+        be.set_ordering(ordering)
+    P.linearize()
+    P.solve(0.0, False)
+    F.linearize()
+    F.solve(0.0, False)
+    F.retract(None, commit=True)
+    x1 = F.get_values()
+    off = _state_slices(arr)
+    current = arr.values.copy()
+    for idx in (np.arange(arr.n_vars - 10, arr.n_vars), np.arange(1500, 1520)):
+        states = np.concatenate([x1[off[i]:off[i + 1]] for i in idx])
+        for i in idx:
+            current[off[i]:off[i + 1]] = x1[off[i]:off[i + 1]]
+        stats = P.relinearize_partial(arr.var_keys[idx], states)
+        assert stats["n_fronts_reeliminated"] < 0.15 * stats["n_fronts"], stats
+        assert stats["n_factors_relinearized"] < 0.05 * arr.n_factors, stats
+        dp = P.solve(0.0, False)
+        F.set_values(current)
+        F.linearize()
+        assert np.array_equal(dp, F.solve(0.0, False))
