@@ -803,3 +803,55 @@ def test_partial_reelimination_touches_a_fraction(gpu):
         F.set_values(current)
         F.linearize()
         assert np.array_equal(dp, F.solve(0.0, False))
+
+
+def test_empty_and_ragged_inputs(gpu, oracle):
+    """Edge inputs: an empty graph (the reference's optimizers return at once: NonlinearOptimizer.cpp:75-83, error 0); a
+    variable that no factor touches next to a well-posed part (indeterminate at lambda = 0 with ITS key, solvable once
+    damped); factors of different row counts and noise kinds on one variable."""
+    g, v = NonlinearFactorGraph(), Values()
+    arr = g.to_arrays(v)
+    for be in (gpu.product_backend(arr), oracle.oracle_backend(arr)):
+        be.set_ordering([])
+        assert be.error() == 0.0
+        r = be.lm_optimize(A.lm_params_legacy())
+        assert r["iterations"] == 0 and r["final_error"] == 0.0
+        assert be.get_values().size == 0
+    # a loose variable
+    g = NonlinearFactorGraph()
+    g.addPrior(1, Pose2(0., 0., 0.), noiseModel.Isotropic.Sigma(3, 0.1))
+    g.add(BetweenFactor(1, 2, Pose2(1., 0., 0.), noiseModel.Isotropic.Sigma(3, 0.2)))
+    v = Values()
+    v.insert(1, Pose2(0.1, 0., 0.))
+    v.insert(2, Pose2(1.2, 0.1, 0.))
+    v.insert(9, Point2(3.0, 4.0))        # nobody measures it
+    arr = g.to_arrays(v)
+    gb, ob = gpu.product_backend(arr), oracle.oracle_backend(arr)
+    for be in (gb, ob):
+        be.set_ordering([9, 1, 2])
+        be.linearize()
+        with pytest.raises(gt.IndeterminantLinearSystemException) as ei:
+            be.solve(0.0)
+        assert ei.value.key == 9
+    assert relerr(gb.solve(1e-3), ob.solve(1e-3)) < 1e-10   # lambda I makes it positive definite
+    assert np.allclose(gb.solve(1e-3)[-2:], 0.0)            # (tangent order follows the keys 1, 2, 9: the loose one is last)
+    # ragged: priors of 2 and 3 rows, unit / diagonal / full Gaussian noise on the same landmark and pose
+    g = NonlinearFactorGraph()
+    g.addPrior(1, Pose2(0., 0., 0.), noiseModel.Diagonal.Sigmas([0.1, 0.2, 0.05]))
+    g.addPrior(5, Point2(1.0, 1.0), noiseModel.Unit.Create(2))
+    g.addPrior(5, Point2(1.2, 0.9), noiseModel.Gaussian.Covariance(np.array([[0.04, 0.01], [0.01, 0.09]])))
+    from gtsam_petercdev_amd.graph import BearingRangeFactor
+    g.add(BearingRangeFactor(1, 5, 0.7, 1.5, noiseModel.Isotropic.Sigma(2, 0.1)))
+    v = Values()
+    v.insert(1, Pose2(0.05, -0.02, 0.01))
+    v.insert(5, Point2(0.8, 1.3))
+    arr = g.to_arrays(v)
+    gb, ob = gpu.product_backend(arr), oracle.oracle_backend(arr)
+    for be in (gb, ob):
+        be.set_ordering([5, 1])
+        be.linearize()
+    assert np.max(np.abs(gb.jacobians() - ob.jacobians())) < 1e-12
+    assert relerr(gb.solve(0.0), ob.solve(0.0)) < 1e-11
+    rg, ro = gb.lm_optimize(A.lm_params_legacy()), ob.lm_optimize(A.lm_params_legacy())
+    assert np.array_equal(rg["trace_accepted"], ro["trace_accepted"])
+    assert abs(rg["final_error"] - ro["final_error"]) <= 1e-9 * max(ro["final_error"], 1e-12)
