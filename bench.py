@@ -237,6 +237,23 @@ def main():
         torch.cuda.synchronize()
         be.synchronize()
 
+    shard_check = None
+    if sharded and world > 1:
+        # the sharded trial against the plain single-GPU one on the same inputs (rank 0 runs the reference handle)
+        e_sh = be.lm_trial(True, lam, False)
+        if rank == 0:
+            ref = _lib.product_backend(arrays, device=device)
+            ref.set_amalgamation(relax, relax_maxf)
+            ref.set_ordering(ordering)
+            e_ref = ref.lm_trial(True, lam, False)
+            ref.synchronize()
+            t_ref = time.perf_counter()
+            for _ in range(5):   # (the other ranks wait at their next collective meanwhile)
+                ref.lm_trial(True, lam, False)
+            ref.synchronize()
+            single_gpu_ms = 1e3 * (time.perf_counter() - t_ref) / 5
+            ref.close()
+            shard_check = (max(abs(a - b) / max(abs(b), 1e-300) for a, b in zip(e_sh, e_ref)), single_gpu_ms)
     for _ in range(args.warmup):
         step()
     be.reset_stats()
@@ -322,7 +339,8 @@ def main():
     }
     if sharded:
         info, owner, _ = be.shard_info()
-        out["shard"] = dict(info, exchange_calls_per_step=exchange_timed["calls"] / args.steps,
+        out["shard"] = dict(info, trial_vs_single_gpu_max_rel_diff=shard_check[0] if shard_check else None,
+                            single_gpu_ms_per_step=shard_check[1] if shard_check else None, exchange_calls_per_step=exchange_timed["calls"] / args.steps,
                             exchange_mb_per_step=8e-6 * exchange_timed["doubles"] / args.steps,
                             exchange_ms_per_step=1e3 * exchange_timed["seconds"] / args.steps,
                             fronts_per_rank=[int((owner == r).sum()) for r in range(info["world"])])
