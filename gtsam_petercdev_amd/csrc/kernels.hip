@@ -37,6 +37,7 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 // total in thread 0 of the block (fixed summation order => deterministic)
+typedef double v4d __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ i64 readlane_i64(i64 v, int src_lane) {  // src_lane must be wave-uniform
   int lo = (int)(v & 0xFFFFFFFFll), hi = (int)(v >> 32);
   lo = __builtin_amdgcn_readlane(lo, src_lane);
@@ -759,6 +760,95 @@ __global__ void assemble_h_global_kernel(DevProblem P, DevSymbolic S, const int*
   }
 }
 
+// Variables that are the LAST-eliminated one of all their factors (the cameras of a bundle adjustment under a Schur
+// ordering) have a panel of just their own d x d block and the rhs row: panel = [J_A | b]' [J_A] summed over the factors —
+// a (d+1) x K by K x d product with K = all the factors' rows, i.e. matrix-core work.  One workgroup of 4 waves per
+// variable; a wave walks a contiguous quarter of the factor list, one v_mfma_f64_16x16x4 per four factor rows (two 2-row
+// SFM factors per instruction; other row counts one factor at a time), the operand X[k][i] = column i of [J_A | b] at
+// factor row k being BOTH the A and the B operand of the instruction (A[i][k] and B[k][j] share the lane layout).  Loads
+// of kU steps are issued before their products.  The four partial 16 x 16 tiles are added in wave order: deterministic.
+// (Reference: JacobianFactor::updateHessian, gtsam/linear/JacobianFactor.cpp:586-624.)
+__global__ void __launch_bounds__(256) assemble_h_diag_kernel(DevProblem P, DevSymbolic S, const int* vars, const double* jac,
+                                                              double* H) {
+  __shared__ double red[4][256];
+  const int v = vars[blockIdx.x];
+  const int d = P.var_dim[v], rows = d + 1;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const int uw = __builtin_amdgcn_readfirstlane(wave);
+  const i64 t0 = S.term_ptr[v];
+  const int nf = (int)((S.term_ptr[v + 1] - t0) >> 1);  // two terms (diagonal, rhs) per factor
+  const int chunk = (((nf + 3) >> 2) + 1) & ~1;         // even: 2-row factors pair up inside a wave's share
+  const int f0 = uw * chunk, f1 = min(nf, f0 + chunk);
+  v4d acc = {0.0, 0.0, 0.0, 0.0};
+  constexpr int kU = 4;
+  for (int base = f0; base < f1; base += 64) {
+    const int nblk = min(64, f1 - base);
+    // a factor per lane: where its [A b] starts, its rows, the column of this variable and of b
+    i64 r_jac = 0;
+    int r_m = 0, r_ca = 0, r_cb = 0;
+    if (lane < nblk) {
+      const TermRec a = S.terms[t0 + 2 * (i64)(base + lane)];
+      const TermRec b = S.terms[t0 + 2 * (i64)(base + lane) + 1];
+      r_jac = a.jac;
+      r_m = a.m;
+      r_ca = a.colA;
+      r_cb = b.colB;
+    }
+    int q = 0;
+    while (q < nblk) {
+      double x[kU];
+      int used = 0;
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        x[u] = 0.0;
+        if (q < nblk) {  // wave-uniform
+          const int m0 = __builtin_amdgcn_readlane(r_m, q);
+          const bool pair = m0 == 2 && q + 1 < nblk && __builtin_amdgcn_readlane(r_m, min(q + 1, 63)) == 2;
+          if (m0 <= 4) {
+            // rows lk (and, paired, rows of the next factor in k slots 2, 3)
+            // (v_readlane takes a wave-uniform lane: fetch both factors' records, then choose per lane)
+            const int q1 = min(q + 1, 63);
+            const i64 offA = readlane_i64(r_jac, q), offB = readlane_i64(r_jac, q1);
+            const int caA = __builtin_amdgcn_readlane(r_ca, q), caB = __builtin_amdgcn_readlane(r_ca, q1);
+            const int cbA = __builtin_amdgcn_readlane(r_cb, q), cbB = __builtin_amdgcn_readlane(r_cb, q1);
+            const bool second = pair && lk >= 2;
+            const int r = second ? lk - 2 : lk;
+            const i64 off = second ? offB : offA;
+            const int col = li < d ? (second ? caB : caA) + li : (second ? cbB : cbA);
+            if (li <= d && r < m0) x[u] = jac[off + (i64)col * m0 + r];
+            q += pair ? 2 : 1;
+            used = u + 1;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u)
+        if (u < used) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u], x[u], acc, 0, 0, 0);
+      if (q < nblk && __builtin_amdgcn_readlane(r_m, q) > 4) {
+        // a taller factor (a 9-row camera prior): four of its rows per instruction
+        const i64 off = readlane_i64(r_jac, q);
+        const int m = __builtin_amdgcn_readlane(r_m, q);
+        const int col = li < d ? __builtin_amdgcn_readlane(r_ca, q) + li : __builtin_amdgcn_readlane(r_cb, q);
+        for (int r0 = 0; r0 < m; r0 += 4) {
+          const int r = r0 + lk;
+          const double xv = (li <= d && r < m) ? jac[off + (i64)col * m + r] : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xv, xv, acc, 0, 0, 0);
+        }
+        ++q;
+      }
+    }
+  }
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq) red[wave][(lk + 4 * qq) * 16 + li] = acc[qq];
+  __syncthreads();
+  double* out = H + S.h_off[v];
+  for (int e = threadIdx.x; e < 256; e += blockDim.x) {
+    const int i = e >> 4, j = e & 15;  // entry (i, j) of X'X: i = row of the panel (d = the rhs row), j = column
+    if (i <= d && j < d) out[i + j * rows] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+  }
+}
+
 static int g_max_lds = -1;
 int max_dynamic_lds() {
   if (g_max_lds < 0) {
@@ -778,6 +868,10 @@ void launch_assemble_h_group(const DevProblem& P, const DevSymbolic& S, const in
     attr = true;
   }
   if (!count) return;
+  if (threads == 0) {  // (mode of the group: variables whose panel is their own block + rhs — matrix-core kernel)
+    assemble_h_diag_kernel<<<count, 256, 0, st>>>(P, S, vars, jac, H);
+    return;
+  }
   if (global) assemble_h_global_kernel<<<count, 64, 0, st>>>(P, S, vars, jac, H);
   else assemble_h_kernel<<<count, threads, lds_bytes, st>>>(P, S, vars, jac, H);
 }
@@ -1055,7 +1149,6 @@ __device__ unsigned long long g_stamp[8];
 #define STAMP_BEGIN
 #define STAMP_ADD(slot)
 #endif
-typedef double v4d __attribute__((ext_vector_type(4)));
 template <int PB>
 __device__ inline int lds_partial_cholesky_t(double* L, int n, int F) {
   const int tid = threadIdx.x, nt = blockDim.x;

@@ -431,12 +431,14 @@ gsx_status upload_symbolic(gsx_context* c) {
       int v, psize;
       int64_t terms;
     };
-    std::vector<VI> light, heavy, huge;
+    std::vector<VI> light, heavy, huge, diag;
     for (int v = 0; v < P.n_vars; ++v) {
       if (!S.scheduled[S.front_of_var[v]]) continue;  // another rank's subtree
       const int psize = S.h_rows[v] * P.dims[v];
       const int64_t terms = S.term_ptr[v + 1] - S.term_ptr[v];
-      if (terms >= 96 && (int64_t)psize * 4 * 8 <= 48 * 1024) heavy.push_back({v, psize, terms});
+      // no later neighbour through any factor (panel = own block + rhs) and many factors: the matrix-core kernel
+      if (terms >= 64 && S.h_rows[v] == P.dims[v] + 1 && P.dims[v] <= 15) diag.push_back({v, psize, terms});
+      else if (terms >= 96 && (int64_t)psize * 4 * 8 <= 48 * 1024) heavy.push_back({v, psize, terms});
       else if ((int64_t)psize * 8 <= 48 * 1024) light.push_back({v, psize, terms});
       else huge.push_back({v, psize, terms});
     }
@@ -461,6 +463,10 @@ gsx_status upload_symbolic(gsx_context* c) {
     emit(light, 64, 1, false);
     emit(heavy, 256, 4, false);
     emit(huge, 64, 1, true);
+    if (!diag.empty()) {  // threads == 0 marks the group for launch_assemble_h_group
+      c->hgroups.push_back({(int)hv.size(), (int)diag.size(), 0, 0, false});
+      for (const VI& x : diag) hv.push_back(x.v);
+    }
     c->hv_list = hv;
     c->hv_group_of_var.assign(P.n_vars, -1);
     c->hv_pos.assign(P.n_vars, -1);
