@@ -849,6 +849,89 @@ __global__ void __launch_bounds__(256) assemble_h_diag_kernel(DevProblem P, DevS
   }
 }
 
+// "Star" variables: every factor of the variable is a binary factor with a LATER-eliminated partner and all factors
+// have the same shape (the landmarks of a bundle adjustment: (camera, point) factors of 2 rows).  The panel is then
+// one off-diagonal block per factor, each written exactly once, plus the variable's own block and the rhs row summed
+// over the factors.  One wave per variable, four variables per workgroup, no LDS: ALL output entries of up to 64
+// factors are spread flat over the lanes (entry -> factor, row, column by two integer divisions; the factor's record
+// comes from the lane that loaded it, ds_bpermute), so the lanes stay busy where the term-by-term kernel keeps 27 / 9 /
+// 3 of 64 active; the d*d + d entries of the own block and the rhs are accumulated by one lane each over the factors in
+// list order: deterministic.  2-row factors load a column as one 16-byte pair.
+__global__ void __launch_bounds__(256) assemble_h_star_kernel(DevProblem P, DevSymbolic S, const int* vars, int count,
+                                                              const double* jac, double* H) {
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (w >= count) return;
+  const int v = vars[w];
+  const int d = P.var_dim[v], rows = S.h_rows[v];
+  const i64 t0 = S.term_ptr[v];
+  const int nf = (int)((S.term_ptr[v + 1] - t0) / 3);  // (diagonal, partner block, rhs) per factor
+  double* panel = H + S.h_off[v];
+  const TermRec a0 = S.terms[t0], b0 = S.terms[t0 + 1], c0 = S.terms[t0 + 2];  // the common shape
+  const int m = a0.m, colA = a0.colA, colB = b0.colB, dB = b0.dB, colR = c0.colB;
+  const int nper = dB * d, nown = d * d + d;
+  // this lane's entry of the own block / rhs row: columns (ci, cj) of the factor's [A b], destination
+  int ci = 0, cj = 0, odst = 0;
+  if (lane < d * d) {
+    const int i = lane % d, j = lane / d;
+    ci = colA + i; cj = colA + j; odst = i + j * rows;
+  } else if (lane < nown) {
+    const int j = lane - d * d;
+    ci = colR; cj = colA + j; odst = (rows - 1) + j * rows;
+  }
+  double own = 0.0;
+  const float rnper = 1.0f / (float)nper, rdB = 1.0f / (float)dB;
+  for (int fb = 0; fb < nf; fb += 64) {
+    const int nfb = min(64, nf - fb);
+    i64 r_jac = 0;
+    int r_dst = 0;
+    if (lane < nfb) {
+      r_jac = S.terms[t0 + 3 * (i64)(fb + lane)].jac;
+      r_dst = S.terms[t0 + 3 * (i64)(fb + lane) + 1].dst;
+    }
+    // partner blocks: entry e -> factor q, row i of the partner's dB, column j of this variable's d
+    const int total = nfb * nper;
+    for (int e0 = 0; e0 < total; e0 += 64) {
+      const int e = e0 + lane;
+      const bool on = e < total;
+      int q, rem, i, j;
+      divmod_small(on ? e : 0, nper, rnper, q, rem);
+      divmod_small(rem, dB, rdB, j, i);
+      const int lo = __shfl((int)(r_jac & 0xffffffff), q), hi = __shfl((int)(r_jac >> 32), q);
+      const i64 joff = ((i64)hi << 32) | (unsigned)lo;
+      const int dst = __shfl(r_dst, q);
+      if (on) {
+        const double* Jf = jac + joff;
+        double acc;
+        if (m == 2 && (joff & 1) == 0) {
+          const double2 x = reinterpret_cast<const double2*>(Jf)[colB + i];
+          const double2 y = reinterpret_cast<const double2*>(Jf)[colA + j];
+          acc = x.x * y.x + x.y * y.y;
+        } else {
+          acc = 0.0;
+          for (int r = 0; r < m; ++r) acc += Jf[(colB + i) * m + r] * Jf[(colA + j) * m + r];
+        }
+        panel[dst + i + j * rows] = acc;
+      }
+    }
+    // own block and rhs row: one lane per entry, over the factors of the chunk in list order
+    for (int q = 0; q < nfb; ++q) {
+      const i64 joff = readlane_i64(r_jac, q);
+      if (lane < nown) {
+        const double* Jf = jac + joff;
+        if (m == 2 && (joff & 1) == 0) {
+          const double2 x = reinterpret_cast<const double2*>(Jf)[ci];
+          const double2 y = reinterpret_cast<const double2*>(Jf)[cj];
+          own += x.x * y.x + x.y * y.y;
+        } else {
+          for (int r = 0; r < m; ++r) own += Jf[ci * m + r] * Jf[cj * m + r];
+        }
+      }
+    }
+  }
+  if (lane < nown) panel[odst] = own;
+}
+
 static int g_max_lds = -1;
 int max_dynamic_lds() {
   if (g_max_lds < 0) {
@@ -870,6 +953,10 @@ void launch_assemble_h_group(const DevProblem& P, const DevSymbolic& S, const in
   if (!count) return;
   if (threads == 0) {  // (mode of the group: variables whose panel is their own block + rhs — matrix-core kernel)
     assemble_h_diag_kernel<<<count, 256, 0, st>>>(P, S, vars, jac, H);
+    return;
+  }
+  if (threads == -1) {  // (mode: star variables, a wave each)
+    assemble_h_star_kernel<<<(count + 3) / 4, 256, 0, st>>>(P, S, vars, count, jac, H);
     return;
   }
   if (global) assemble_h_global_kernel<<<count, 64, 0, st>>>(P, S, vars, jac, H);

@@ -431,11 +431,35 @@ gsx_status upload_symbolic(gsx_context* c) {
       int v, psize;
       int64_t terms;
     };
-    std::vector<VI> light, heavy, huge, diag;
+    std::vector<VI> light, heavy, huge, diag, star;
+    // a "star" variable: all its factors are binary with a later-eliminated partner, all of one shape (three terms
+    // each: own block, partner block, rhs — with equal rows, columns and partner dimension)
+    std::vector<int> star_dst;
+    auto is_star = [&](int v) {
+      const int64_t tb = S.term_ptr[v], te = S.term_ptr[v + 1];
+      if (te - tb < 3 || (te - tb) % 3 != 0 || P.dims[v] > 7) return false;
+      star_dst.clear();
+      for (int64_t t = tb; t < te; t += 3) {
+        star_dst.push_back(S.t_dst[t + 1]);
+        if (S.t_dst[t] != 0 || S.t_dst[t + 2] != S.h_rows[v] - 1 || S.t_dB[t + 2] != 1) return false;
+        if (S.t_dst[t + 1] == 0 || S.t_dst[t + 1] == S.h_rows[v] - 1) return false;
+        if (S.t_m[t] != S.t_m[tb] || S.t_colA[t] != S.t_colA[tb] || S.t_colB[t + 1] != S.t_colB[tb + 1] ||
+            S.t_dB[t + 1] != S.t_dB[tb + 1] || S.t_colB[t + 2] != S.t_colB[tb + 2] || S.t_jac[t] != S.t_jac[t + 1] ||
+            S.t_jac[t] != S.t_jac[t + 2])
+          return false;
+      }
+      // every partner block is written by exactly one factor (two factors to the same partner would have to be summed)
+      std::sort(star_dst.begin(), star_dst.end());
+      return std::adjacent_find(star_dst.begin(), star_dst.end()) == star_dst.end();
+    };
     for (int v = 0; v < P.n_vars; ++v) {
       if (!S.scheduled[S.front_of_var[v]]) continue;  // another rank's subtree
       const int psize = S.h_rows[v] * P.dims[v];
       const int64_t terms = S.term_ptr[v + 1] - S.term_ptr[v];
+      if (is_star(v)) {
+        star.push_back({v, psize, terms});
+        continue;
+      }
       // no later neighbour through any factor (panel = own block + rhs) and many factors: the matrix-core kernel
       if (terms >= 64 && S.h_rows[v] == P.dims[v] + 1 && P.dims[v] <= 15) diag.push_back({v, psize, terms});
       else if (terms >= 96 && (int64_t)psize * 4 * 8 <= 48 * 1024) heavy.push_back({v, psize, terms});
@@ -463,6 +487,10 @@ gsx_status upload_symbolic(gsx_context* c) {
     emit(light, 64, 1, false);
     emit(heavy, 256, 4, false);
     emit(huge, 64, 1, true);
+    if (!star.empty()) {  // threads == -1 marks the group
+      c->hgroups.push_back({(int)hv.size(), (int)star.size(), -1, 0, false});
+      for (const VI& x : star) hv.push_back(x.v);
+    }
     if (!diag.empty()) {  // threads == 0 marks the group for launch_assemble_h_group
       c->hgroups.push_back({(int)hv.size(), (int)diag.size(), 0, 0, false});
       for (const VI& x : diag) hv.push_back(x.v);
