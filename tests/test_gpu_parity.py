@@ -855,3 +855,38 @@ def test_empty_and_ragged_inputs(gpu, oracle):
     rg, ro = gb.lm_optimize(A.lm_params_legacy()), ob.lm_optimize(A.lm_params_legacy())
     assert np.array_equal(rg["trace_accepted"], ro["trace_accepted"])
     assert abs(rg["final_error"] - ro["final_error"]) <= 1e-9 * max(ro["final_error"], 1e-12)
+
+
+def test_assembly_kernel_corner_shapes(gpu, oracle):
+    """The specialised H-assembly kernels at their edges: a landmark seen by 80 cameras (two record chunks of the star
+    kernel), a landmark observed twice by the same camera (NOT a star: the two partner blocks must be summed — generic
+    kernel), cameras with > 64 factors including the 9-row prior (matrix-core kernel, tall-factor branch)."""
+    rng = np.random.default_rng(3)
+    base = datasets.synth_bal_arrays(80, 3, 150, seed=21, long_range=1.0, priors=True)
+    # ... and every camera that does not see landmark 0 yet gets an observation of it: > 64 factors on that landmark
+    n_sfm = int((base.f_type == A.F_SFM).sum())
+    cams_of = lambda a, lm: set(a.f_vars[0:2 * n_sfm:2][a.f_vars[1:2 * n_sfm:2] == lm].tolist())
+    lm0 = 80
+    z = base.meas[base.f_meas_ptr[0]:base.f_meas_ptr[1]]
+    for c in sorted(set(range(80)) - cams_of(base, lm0)):
+        base = base.with_factor(A.F_SFM, [c, lm0], 2, z + rng.normal(0, 2.0, 2), int(base.f_noise_kind[0]),
+                                base.noise[base.f_noise_ptr[0]:base.f_noise_ptr[1]])
+    assert base.n_factors - 152 + len(cams_of(base, lm0)) > 64
+    wide = datasets.synth_bal_arrays(4, 200, 760, seed=22, long_range=1.0, priors=True)   # ~190 factors per camera
+    # duplicate an observation: camera c sees landmark l twice
+    sfm = np.nonzero(wide.f_type == A.F_SFM)[0]
+    f = int(sfm[5])
+    kp = wide.f_key_ptr[f]
+    dup = wide.with_factor(A.F_SFM, wide.f_vars[kp:kp + 2], 2,
+                           wide.meas[wide.f_meas_ptr[f]:wide.f_meas_ptr[f + 1]] + rng.normal(0, 0.5, 2),
+                           int(wide.f_noise_kind[f]), wide.noise[wide.f_noise_ptr[f]:wide.f_noise_ptr[f + 1]])
+    for arr in (base, wide, dup):
+        gb, ob = gpu.product_backend(arr), oracle.oracle_backend(arr)
+        ordering = gb.compute_ordering(A.ORDER_SCHUR)
+        gb.set_ordering(ordering)
+        ob.set_ordering(ordering)
+        gb.linearize()
+        ob.linearize()
+        assert relerr(gb.hessian_diagonal(), ob.hessian_diagonal()) < 1e-12
+        for lam, diag in ((1e-3, False), (1.0, True)):
+            assert relerr(gb.solve(lam, diag), ob.solve(lam, diag)) < 1e-8
