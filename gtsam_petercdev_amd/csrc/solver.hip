@@ -168,6 +168,13 @@ struct gsx_context {
     DevBuf<BigDesc> big;
     DevBuf<GatherSeg> segs;
   } ps;
+  // side streams: the size groups of one level are independent launches, each far from filling the GPU and bound by the
+  // latency of one front — they run side by side (fork from / join into the main stream with events)
+  static constexpr int kSide = 8;
+  hipStream_t side[kSide] = {};
+  hipEvent_t side_done[kSide] = {};
+  hipEvent_t side_start = nullptr;
+  bool side_ready = false;
   // sharding (gsx_set_shard)
   int shard_rank = 0, shard_world = 1;
   gsx_allreduce_fn shard_cb = nullptr;
@@ -678,6 +685,35 @@ gsx_status upload_symbolic(gsx_context* c) {
   return GSX_OK;
 }
 
+// fork: side streams wait for everything queued on the main stream so far; join: the main stream waits for the first n
+bool side_fork(gsx_context* c) {
+  if (!c->side_ready) {
+    for (int i = 0; i < gsx_context::kSide; ++i) {
+      if (hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) != hipSuccess) return false;
+      if (hipEventCreateWithFlags(&c->side_done[i], hipEventDisableTiming) != hipSuccess) return false;
+    }
+    if (hipEventCreateWithFlags(&c->side_start, hipEventDisableTiming) != hipSuccess) return false;
+    c->side_ready = true;
+  }
+  hipEventRecord(c->side_start, c->stream);
+  return true;
+}
+hipStream_t side_stream(gsx_context* c, int i, unsigned* used) {
+  const int k = i % gsx_context::kSide;
+  if (!((*used >> k) & 1u)) {
+    hipStreamWaitEvent(c->side[k], c->side_start, 0);
+    *used |= 1u << k;
+  }
+  return c->side[k];
+}
+void side_join(gsx_context* c, unsigned used) {
+  for (int k = 0; k < gsx_context::kSide; ++k)
+    if ((used >> k) & 1u) {
+      hipEventRecord(c->side_done[k], c->side[k]);
+      hipStreamWaitEvent(c->stream, c->side_done[k], 0);
+    }
+}
+
 // in-place sum of device memory over the ranks of a sharded problem (gsx_set_shard); a failure is latched and reported
 // by the next readback
 void shard_allreduce(gsx_context* c, double* dptr, int64_t n) {
@@ -745,18 +781,33 @@ void dev_factorize(gsx_context* c, double lambda) {
     launch_big_init(c->DP, c->DS, c->d_big.p, (int)c->big_descs.size(), c->big_max_n, c->big_max_nfv, c->d_H.p,
                     c->d_damp.p, c->d_scalars.p, c->d_arena.p, c->stream);
   for (int l = 0; l < S.n_levels; ++l) {
+    // The leaf / small (LDS) launches of a level are independent of each other.  Few, GPU-filling ones (the landmark
+    // cliques of a bundle adjustment) go one after the other; many partly-filled ones (the size groups of a pose
+    // graph's lower levels, each bound by the latency of its slowest front) run side by side.
+    const size_t n_groups = c->leaf_launch[l].size() + c->small_launch[l].size();
+    int max_count = 0;
+    for (const SmallLaunch& sl : c->leaf_launch[l]) max_count = std::max(max_count, sl.count);
+    for (const SmallLaunch& sl : c->small_launch[l]) max_count = std::max(max_count, sl.count);
+    // (a fork + join costs ~85 us of cross-queue event latency, measured: only worth it for many groups)
+    const bool side = !c->profiling && n_groups >= 4 && max_count < 16384 && side_fork(c);
+    unsigned used = 0;
+    int gi = 0;
     for (const SmallLaunch& sl : c->leaf_launch[l]) {
       if (c->profiling) timer_begin(c, PH_FACTOR_LEAF);
       launch_front_leaf(c->DP, c->DS, c->d_leaf_recs.p + (sl.begin - c->leaf_base), sl.count, sl.max_panel, sl.threads, c->d_H.p,
-                        c->d_damp.p, c->d_scalars.p, c->d_arena.p, c->d_status.p, c->stream);
+                        c->d_damp.p, c->d_scalars.p, c->d_arena.p, c->d_status.p,
+                        side ? side_stream(c, gi++, &used) : c->stream);
       if (c->profiling) timer_end(c, PH_FACTOR_LEAF);
     }
-    for (const SmallLaunch& sl : c->small_launch[l]) {
+    // (largest fronts first: they are the longest launches and land on different hardware queues)
+    for (size_t k = c->small_launch[l].size(); k-- > 0;) {
+      const SmallLaunch& sl = c->small_launch[l][k];
       if (c->profiling) timer_begin(c, PH_FACTOR_SMALL);
       launch_front_small(c->DP, c->DS, c->d_sched.p + sl.begin, sl.count, sl.max_n, sl.threads, c->d_H.p, c->d_damp.p,
-                         c->d_scalars.p, c->d_arena.p, c->d_status.p, c->stream);
+                         c->d_scalars.p, c->d_arena.p, c->d_status.p, side ? side_stream(c, gi++, &used) : c->stream);
       if (c->profiling) timer_end(c, PH_FACTOR_SMALL);
     }
+    if (side) side_join(c, used);
     if (l == 0 && S.gseg_lvl_ptr[1] > S.gseg_lvl_ptr[0]) {
       // gather group 0: the product-form contributions of all lean leaves to all big fronts (symbolic.cpp)
       if (c->profiling) timer_begin(c, PH_K_GATHER);
@@ -808,17 +859,24 @@ void dev_backsolve(gsx_context* c) {
                        c->d_delta.p, c->d_status.p, c->stream);
       if (c->profiling) timer_end(c, PH_K_BACKSOLVE);
     } else {
+      // (the cliques of a level only read their parents' solution: their launches are independent — side by side)
+      // — measured: the launches of a back-substitution level are too short (20-50 us each) to pay for the ~85 us of
+      // cross-queue event latency of a fork + join; kept on the main stream
+      const bool side = false;
+      unsigned used = 0;
+      int gi = 0;
       if (B.count) {
         int maxn = 0;
         for (int k = se; k < S.lvl_ptr[l + 1]; ++k) maxn = std::max(maxn, S.N[S.sched[k]]);
         if (c->profiling) timer_begin(c, PH_K_BACKSOLVE);
         launch_backsolve(c->DS, c->d_sched.p + se, S.lvl_ptr[l + 1] - se, 1024, maxn, c->d_arena.p, c->d_delta.p,
-                         c->d_status.p, c->stream);
+                         c->d_status.p, side ? side_stream(c, gi++, &used) : c->stream);
         if (c->profiling) timer_end(c, PH_K_BACKSOLVE);
       }
       for (const SmallLaunch& sl : c->small_launch[l])
         launch_backsolve(c->DS, c->d_sched.p + sl.begin, sl.count, sl.max_n <= 48 ? 64 : 256, sl.max_n, c->d_arena.p,
-                         c->d_delta.p, c->d_status.p, c->stream);
+                         c->d_delta.p, c->d_status.p, side ? side_stream(c, gi++, &used) : c->stream);
+      if (side) side_join(c, used);
     }
     // all leaf-kernel cliques of the level in one launch (a wave each)
     if (S.lvl_leaf_end[l] > S.lvl_ptr[l])
@@ -1056,6 +1114,14 @@ gsx_status gsx_destroy(gsx_handle h) {
         hipEventDestroy(ev.first);
         hipEventDestroy(ev.second);
       }
+    }
+    if (h->side_ready) {
+      for (int i = 0; i < gsx_context::kSide; ++i) {
+        hipStreamSynchronize(h->side[i]);
+        hipStreamDestroy(h->side[i]);
+        hipEventDestroy(h->side_done[i]);
+      }
+      hipEventDestroy(h->side_start);
     }
     if (h->h_scalars) hipHostFree(h->h_scalars);
     if (h->h_status) hipHostFree(h->h_status);
