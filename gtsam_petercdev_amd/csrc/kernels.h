@@ -103,6 +103,9 @@ void launch_linear_error(const DevProblem& P, const double* jac, const double* d
 void launch_retract(const DevProblem& P, const double* values, const double* delta, double* out, hipStream_t st);
 void launch_assemble_h_group(const DevProblem& P, const DevSymbolic& S, const int* vars, int count, int threads,
                              int lds_bytes, bool global, const double* jac, double* H, hipStream_t st);
+// star variables in bundles (first position in vars, count) of one shape and <= 64 factors: a wave per bundle
+void launch_assemble_h_star_bundles(const DevProblem& P, const DevSymbolic& S, const int* vars, const int2* bundles,
+                                    int count, const double* jac, double* H, hipStream_t st);
 void launch_hessian_diag(const DevProblem& P, const DevSymbolic& S, const double* H, double* diag, hipStream_t st);
 void launch_make_damping(int n, const double* hdiag, int diagonal, double mind, double maxd, double* damp,
                          hipStream_t st);

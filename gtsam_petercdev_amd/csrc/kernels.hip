@@ -932,6 +932,130 @@ __global__ void __launch_bounds__(256) assemble_h_star_kernel(DevProblem P, DevS
   if (lane < nown) panel[odst] = own;
 }
 
+// The same work for a BUNDLE of up to kStarVars consecutive star variables of one shape with at most 64 factors between
+// them, one wave per bundle.  A wave of assemble_h_star_kernel walks four dependent load levels (variable tables ->
+// term records -> Jacobians -> stores) for ONE variable and is bound by that chain times the number of waves; here the
+// four levels are walked once per bundle, with all the bundle's records fetched by one load instruction per level and
+// all its partner-block entries flat over the lanes.  Entry for entry the arithmetic is that of the one-variable
+// kernel (which gsx_relinearize_partial keeps using on its filtered lists): same bits.
+constexpr int kStarVars = 5;  // kStarVars * (d*d + d) own entries must fit a wave (d = 3: 60 lanes)
+__global__ void __launch_bounds__(256) assemble_h_star_bundle_kernel(DevProblem P, DevSymbolic S, const int* vars,
+                                                                    const int2* bundles, int count, const double* jac,
+                                                                    double* H) {
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (w >= count) return;
+  const int2 bd = bundles[w];  // first variable (position in vars), number of variables
+  const int nv = bd.y;
+  // level 1: the variables' tables, a variable per lane
+  int s_v = 0, s_rows = 0, s_nf = 0;
+  i64 s_t0 = 0, s_hoff = 0;
+  if (lane < nv) {
+    s_v = vars[bd.x + lane];
+    s_rows = S.h_rows[s_v];
+    s_t0 = S.term_ptr[s_v];
+    s_nf = (int)((S.term_ptr[s_v + 1] - s_t0) / 3);
+    s_hoff = S.h_off[s_v];
+  }
+  // first factor of each variable in the bundle's factor numbering (exclusive prefix sum over <= kStarVars lanes)
+  int s_first = 0, nft = 0;
+#pragma unroll
+  for (int k = 0; k < kStarVars; ++k) {
+    const int c = __builtin_amdgcn_readlane(s_nf, k);
+    if (lane == k) s_first = nft;
+    nft += (k < nv) ? c : 0;
+  }
+  const int d = P.var_dim[__builtin_amdgcn_readfirstlane(s_v)];
+  // level 2: the factors' records, a factor per lane (nft <= 64), and the common shape from the first factor
+  int f_slot = 0;
+#pragma unroll
+  for (int k = 1; k < kStarVars; ++k)
+    if (k < nv && lane >= __builtin_amdgcn_readlane(s_first, k)) f_slot = k;
+  i64 r_jac = 0;
+  int r_dst = 0;
+  {
+    const i64 t0s = ((i64)__shfl((int)(s_t0 >> 32), f_slot) << 32) | (unsigned)__shfl((int)(s_t0 & 0xffffffff), f_slot);
+    const int fl = lane - __shfl(s_first, f_slot);
+    if (lane < nft) {
+      r_jac = S.terms[t0s + 3 * (i64)fl].jac;
+      r_dst = S.terms[t0s + 3 * (i64)fl + 1].dst;
+    }
+  }
+  const i64 t00 = readlane_i64(s_t0, 0);
+  const TermRec a0 = S.terms[t00], b0 = S.terms[t00 + 1], c0t = S.terms[t00 + 2];
+  const int m = a0.m, colA = a0.colA, colB = b0.colB, dB = b0.dB, colR = c0t.colB;
+  const int nper = dB * d, nown = d * d + d;
+  const int f_rows = __shfl(s_rows, f_slot);
+  const i64 f_hoff = ((i64)__shfl((int)(s_hoff >> 32), f_slot) << 32) | (unsigned)__shfl((int)(s_hoff & 0xffffffff), f_slot);
+  // level 3: partner blocks, all entries of all factors flat over the lanes
+  const float rnper = 1.0f / (float)nper, rdB = 1.0f / (float)dB;
+  const int total = nft * nper;
+  for (int e0 = 0; e0 < total; e0 += 64) {
+    const int e = e0 + lane;
+    const bool on = e < total;
+    int q, rem, i, j;
+    divmod_small(on ? e : 0, nper, rnper, q, rem);
+    divmod_small(rem, dB, rdB, j, i);
+    const i64 joff = ((i64)__shfl((int)(r_jac >> 32), q) << 32) | (unsigned)__shfl((int)(r_jac & 0xffffffff), q);
+    const int dst = __shfl(r_dst, q);
+    const int rows = __shfl(f_rows, q);
+    const i64 hoff = ((i64)__shfl((int)(f_hoff >> 32), q) << 32) | (unsigned)__shfl((int)(f_hoff & 0xffffffff), q);
+    if (on) {
+      const double* Jf = jac + joff;
+      double acc;
+      if (m == 2 && (joff & 1) == 0) {
+        const double2 x = reinterpret_cast<const double2*>(Jf)[colB + i];
+        const double2 y = reinterpret_cast<const double2*>(Jf)[colA + j];
+        acc = x.x * y.x + x.y * y.y;
+      } else {
+        acc = 0.0;
+        for (int r = 0; r < m; ++r) acc += Jf[(colB + i) * m + r] * Jf[(colA + j) * m + r];
+      }
+      H[hoff + dst + i + j * rows] = acc;
+    }
+  }
+  // own block and rhs row: a lane per (variable, entry), over that variable's factors in list order
+  {
+    int slot, ent;
+    divmod_small(lane, nown, 1.0f / (float)nown, slot, ent);
+    const bool on = slot < nv;
+    const int sl = on ? slot : 0;
+    const int rows = __shfl(s_rows, sl), first = __shfl(s_first, sl), nf = __shfl(s_nf, sl);
+    const i64 hoff = ((i64)__shfl((int)(s_hoff >> 32), sl) << 32) | (unsigned)__shfl((int)(s_hoff & 0xffffffff), sl);
+    int ci, cj, odst;
+    if (ent < d * d) {
+      const int i = ent % d, j = ent / d;
+      ci = colA + i; cj = colA + j; odst = i + j * rows;
+    } else {
+      const int j = ent - d * d;
+      ci = colR; cj = colA + j; odst = (rows - 1) + j * rows;
+    }
+    int nfmax = 0;
+#pragma unroll
+    for (int k = 0; k < kStarVars; ++k) nfmax = max(nfmax, k < nv ? __builtin_amdgcn_readlane(s_nf, k) : 0);
+    double own = 0.0;
+    for (int it = 0; it < nfmax; ++it) {
+      const int q = min(first + it, 63);
+      const i64 joff = ((i64)__shfl((int)(r_jac >> 32), q) << 32) | (unsigned)__shfl((int)(r_jac & 0xffffffff), q);
+      if (on && it < nf) {
+        const double* Jf = jac + joff;
+        if (m == 2 && (joff & 1) == 0) {
+          const double2 x = reinterpret_cast<const double2*>(Jf)[ci];
+          const double2 y = reinterpret_cast<const double2*>(Jf)[cj];
+          own += x.x * y.x + x.y * y.y;
+        } else {
+          for (int r = 0; r < m; ++r) own += Jf[ci * m + r] * Jf[cj * m + r];
+        }
+      }
+    }
+    if (on) H[hoff + odst] = own;
+  }
+}
+void launch_assemble_h_star_bundles(const DevProblem& P, const DevSymbolic& S, const int* vars, const int2* bundles,
+                                    int count, const double* jac, double* H, hipStream_t st) {
+  if (count) assemble_h_star_bundle_kernel<<<(count + 3) / 4, 256, 0, st>>>(P, S, vars, bundles, count, jac, H);
+}
+
 static int g_max_lds = -1;
 int max_dynamic_lds() {
   if (g_max_lds < 0) {

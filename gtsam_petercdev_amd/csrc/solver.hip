@@ -135,6 +135,8 @@ struct gsx_context {
     bool global;
   };
   std::vector<HGroup> hgroups;
+  DevBuf<int2> d_star_bundles;   // bundles of the star group (positions relative to the group's variable list)
+  int n_star_bundles = 0;
   // numeric buffers
   DevBuf<double> d_values, d_trial, d_delta, d_udelta, d_jac, d_H, d_arena, d_hdiag, d_damp, d_partials, d_scalars;
   DevBuf<double> d_dlu, d_dld;  // Dogleg: steepest-descent point, dog-leg point (allocated on first use)
@@ -494,9 +496,36 @@ gsx_status upload_symbolic(gsx_context* c) {
     emit(light, 64, 1, false);
     emit(heavy, 256, 4, false);
     emit(huge, 64, 1, true);
+    c->n_star_bundles = 0;
     if (!star.empty()) {  // threads == -1 marks the group
       c->hgroups.push_back({(int)hv.size(), (int)star.size(), -1, 0, false});
       for (const VI& x : star) hv.push_back(x.v);
+      // bundles for the one-wave-per-bundle kernel: consecutive variables of one shape, <= 5 of them (the own entries of
+      // a bundle fit a wave: 5 x (3*3 + 3) lanes), <= 64 factors; a variable too big or of another shape is alone
+      auto shape = [&](int v) {
+        const int64_t t = S.term_ptr[v];
+        return std::array<int, 6>{P.dims[v], S.t_m[t], S.t_colA[t], S.t_colB[t + 1], S.t_dB[t + 1], S.t_colB[t + 2]};
+      };
+      std::vector<int2> bundles;
+      size_t i = 0;
+      while (i < star.size()) {
+        const auto sh = shape(star[i].v);
+        const int nown = sh[0] * sh[0] + sh[0];
+        int nf = (int)(star[i].terms / 3), nv = 1;
+        if (nf > 64 || nown > 64) {  // (the bundle kernel holds a factor per lane)
+          bundles.clear();
+          break;
+        }
+        while (i + nv < star.size() && nv < 5 && (nv + 1) * nown <= 64 && shape(star[i + nv].v) == sh &&
+               nf + (int)(star[i + nv].terms / 3) <= 64) {
+          nf += (int)(star[i + nv].terms / 3);
+          ++nv;
+        }
+        bundles.push_back(int2{(int)i, nv});
+        i += nv;
+      }
+      c->n_star_bundles = (int)bundles.size();
+      if (c->n_star_bundles) HIPCHK(c, c->d_star_bundles.upload(bundles, st));
     }
     if (!diag.empty()) {  // threads == 0 marks the group for launch_assemble_h_group
       c->hgroups.push_back({(int)hv.size(), (int)diag.size(), 0, 0, false});
@@ -739,9 +768,15 @@ void dev_linearize(gsx_context* c) {
 
 void dev_assemble_h(gsx_context* c) {
   timer_begin(c, PH_ASSEMBLE_H);
-  for (const auto& g : c->hgroups)
+  for (const auto& g : c->hgroups) {
+    if (g.threads == -1 && c->n_star_bundles) {  // the whole star group, a wave per bundle of variables
+      launch_assemble_h_star_bundles(c->DP, c->DS, c->d_hvars.p + g.begin, c->d_star_bundles.p, c->n_star_bundles,
+                                     c->d_jac.p, c->d_H.p, c->stream);
+      continue;
+    }
     launch_assemble_h_group(c->DP, c->DS, c->d_hvars.p + g.begin, g.count, g.threads, g.lds, g.global, c->d_jac.p,
                             c->d_H.p, c->stream);
+  }
   timer_end(c, PH_ASSEMBLE_H);
   c->h_ready = true;
   c->hdiag_ready = false;  // diag(H) is extracted on demand: lambda * I damping never needs it
