@@ -824,7 +824,8 @@ void dev_factorize(gsx_context* c, double lambda) {
     for (const SmallLaunch& sl : c->leaf_launch[l]) max_count = std::max(max_count, sl.count);
     for (const SmallLaunch& sl : c->small_launch[l]) max_count = std::max(max_count, sl.count);
     // (a fork + join costs ~85 us of cross-queue event latency, measured: only worth it for many groups)
-    const bool side = !c->profiling && n_groups >= 4 && max_count < 16384 && side_fork(c);
+    // the long ones are the LDS-front launches (40-150 us each); leaf launches are 10-30 us and do not justify a fork)
+    const bool side = !c->profiling && n_groups >= 4 && c->small_launch[l].size() >= 4 && max_count < 16384 && side_fork(c);
     unsigned used = 0;
     int gi = 0;
     for (const SmallLaunch& sl : c->leaf_launch[l]) {
