@@ -909,9 +909,22 @@ void dev_backsolve(gsx_context* c) {
                          c->d_status.p, side ? side_stream(c, gi++, &used) : c->stream);
         if (c->profiling) timer_end(c, PH_K_BACKSOLVE);
       }
-      for (const SmallLaunch& sl : c->small_launch[l])
-        launch_backsolve(c->DS, c->d_sched.p + sl.begin, sl.count, sl.max_n <= 48 ? 64 : 256, sl.max_n, c->d_arena.p,
-                         c->d_delta.p, c->d_status.p, side ? side_stream(c, gi++, &used) : c->stream);
+      // the size groups of the factorization (split by LDS footprint) mean nothing here — the back-substitution keeps
+      // only n - 1 doubles per clique in LDS: all the level's LDS-class cliques go in ONE launch (a level's
+      // launches are each bound by the latency of one clique, 20-50 us)
+      const std::vector<SmallLaunch>& G = c->small_launch[l];
+      for (size_t k = 0; k < G.size();) {
+        size_t e = k;
+        int total = 0, maxn = 0;
+        while (e < G.size() && G[e].begin == G[k].begin + total) {
+          total += G[e].count;
+          maxn = std::max(maxn, G[e].max_n);
+          ++e;
+        }
+        launch_backsolve(c->DS, c->d_sched.p + G[k].begin, total, maxn <= 48 ? 64 : 256, maxn, c->d_arena.p, c->d_delta.p,
+                         c->d_status.p, side ? side_stream(c, gi++, &used) : c->stream);
+        k = e;
+      }
       if (side) side_join(c, used);
     }
     // all leaf-kernel cliques of the level in one launch (a wave each)
