@@ -355,6 +355,31 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     fsize[f] = (sz + 1) & ~int64_t(1);  // 16-byte aligned fronts
   }
   {
+    // A level's LDS fronts cost one launch bound by the latency of its slowest front (60-100 us for a 100-140 row front:
+    // a barrier per pivot) however few they are.  Where the level has blocked (big) fronts anyway and only a handful of
+    // LDS fronts, those join the blocked path: no launch of their own, and the level's panel-step chain is set by the
+    // big fronts' wider frontal blocks in any case (measured on the 100 000-pose graphs: one launch less on ~9 levels).
+    std::vector<int> n_lds(S.n_levels + 1, 0), n_blk(S.n_levels + 1, 0);
+    int nlev = 0;
+    for (int f = 0; f < nfr; ++f) nlev = std::max(nlev, S.level[f] + 1);
+    n_lds.assign(nlev, 0);
+    n_blk.assign(nlev, 0);
+    for (int f = 0; f < nfr; ++f) {
+      if (S.cls[f] == 1) n_lds[S.level[f]]++;
+      else if (S.cls[f] == 2) n_blk[S.level[f]]++;
+    }
+    for (int f = 0; f < nfr; ++f) {
+      const int l = S.level[f];
+      if (S.cls[f] != 1 || n_blk[l] == 0 || n_lds[l] > 256) continue;
+      S.cls[f] = 2;
+      S.n_big++;
+      S.n_small--;
+      int64_t sz = (int64_t)S.N[f] * S.N[f];
+      sz = ((sz + 1) & ~int64_t(1)) + (int64_t)S.N[f] * S.F[f];
+      fsize[f] = (sz + 1) & ~int64_t(1);
+    }
+  }
+  {
     // arena layout: the subtree fronts, then the cap fronts in one contiguous block (the exchange buffer)
     int64_t cursor = 0;
     for (int f = 0; f < nfr; ++f)
