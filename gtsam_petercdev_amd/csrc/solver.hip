@@ -193,6 +193,7 @@ struct gsx_context {
 namespace {
 
 void timer_begin(gsx_context* c, int ph) {
+  if (c->profiling < 0) return;  // (an event record costs ~5 us of stream time: gsx_set_profiling(h, -1) switches them off)
   Timer& t = c->timers[ph];
   std::pair<hipEvent_t, hipEvent_t> ev;
   if (!t.pool.empty()) {
@@ -205,7 +206,10 @@ void timer_begin(gsx_context* c, int ph) {
   hipEventRecord(ev.first, c->stream);
   t.pending.push_back(ev);
 }
-void timer_end(gsx_context* c, int ph) { hipEventRecord(c->timers[ph].pending.back().second, c->stream); }
+void timer_end(gsx_context* c, int ph) {
+  if (c->profiling < 0) return;
+  hipEventRecord(c->timers[ph].pending.back().second, c->stream);
+}
 void timers_resolve(gsx_context* c) {
   hipStreamSynchronize(c->stream);
   for (int ph = 0; ph < PH_COUNT; ++ph) {
@@ -826,37 +830,37 @@ void dev_factorize(gsx_context* c, double lambda) {
     for (const SmallLaunch& sl : c->small_launch[l]) max_count = std::max(max_count, sl.count);
     // (a fork + join costs ~85 us of cross-queue event latency, measured: only worth it for many groups)
     // the long ones are the LDS-front launches (40-150 us each); leaf launches are 10-30 us and do not justify a fork)
-    const bool side = !c->profiling && n_groups >= 4 && c->small_launch[l].size() >= 4 && max_count < 16384 && side_fork(c);
+    const bool side = c->profiling <= 0 && n_groups >= 4 && c->small_launch[l].size() >= 4 && max_count < 16384 && side_fork(c);
     unsigned used = 0;
     int gi = 0;
     for (const SmallLaunch& sl : c->leaf_launch[l]) {
-      if (c->profiling) timer_begin(c, PH_FACTOR_LEAF);
+      if (c->profiling > 0) timer_begin(c, PH_FACTOR_LEAF);
       launch_front_leaf(c->DP, c->DS, c->d_leaf_recs.p + (sl.begin - c->leaf_base), sl.count, sl.max_panel, sl.threads, c->d_H.p,
                         c->d_damp.p, c->d_scalars.p, c->d_arena.p, c->d_status.p,
                         side ? side_stream(c, gi++, &used) : c->stream);
-      if (c->profiling) timer_end(c, PH_FACTOR_LEAF);
+      if (c->profiling > 0) timer_end(c, PH_FACTOR_LEAF);
     }
     // (largest fronts first: they are the longest launches and land on different hardware queues)
     for (size_t k = c->small_launch[l].size(); k-- > 0;) {
       const SmallLaunch& sl = c->small_launch[l][k];
-      if (c->profiling) timer_begin(c, PH_FACTOR_SMALL);
+      if (c->profiling > 0) timer_begin(c, PH_FACTOR_SMALL);
       launch_front_small(c->DP, c->DS, c->d_sched.p + sl.begin, sl.count, sl.max_n, sl.threads, c->d_H.p, c->d_damp.p,
                          c->d_scalars.p, c->d_arena.p, c->d_status.p, side ? side_stream(c, gi++, &used) : c->stream);
-      if (c->profiling) timer_end(c, PH_FACTOR_SMALL);
+      if (c->profiling > 0) timer_end(c, PH_FACTOR_SMALL);
     }
     if (side) side_join(c, used);
     if (l == 0 && S.gseg_lvl_ptr[1] > S.gseg_lvl_ptr[0]) {
       // gather group 0: the product-form contributions of all lean leaves to all big fronts (symbolic.cpp)
-      if (c->profiling) timer_begin(c, PH_K_GATHER);
+      if (c->profiling > 0) timer_begin(c, PH_K_GATHER);
       launch_big_gather(c->GA, S.gseg_lvl_ptr[0], S.gseg_lvl_ptr[1] - S.gseg_lvl_ptr[0], S.gm_lvl_ptr[0],
                         S.gm_lvl_ptr[1] - S.gm_lvl_ptr[0], c->d_arena.p, c->stream);
-      if (c->profiling) timer_end(c, PH_K_GATHER);
+      if (c->profiling > 0) timer_end(c, PH_K_GATHER);
     }
     const BigLevel& B = c->big_level[l];
     if (B.count) {
-      if (c->profiling) timer_begin(c, PH_FACTOR_BIG);
+      if (c->profiling > 0) timer_begin(c, PH_FACTOR_BIG);
       // children of every earlier level are complete: deterministic extend-add into this level's big fronts
-      const bool prof = c->profiling != 0;
+      const bool prof = c->profiling > 0;
       if (l > 0) {  // (group 0 was launched above)
         if (prof) timer_begin(c, PH_K_GATHER);
         launch_big_gather(c->GA, S.gseg_lvl_ptr[l], S.gseg_lvl_ptr[l + 1] - S.gseg_lvl_ptr[l], S.gm_lvl_ptr[l],
@@ -874,7 +878,7 @@ void dev_factorize(gsx_context* c, double lambda) {
         launch_big_step(c->d_big.p + B.begin, B.count, kb, B.pairs[kb], c->d_arena.p, c->d_status.p, c->stream);
         if (prof) timer_end(c, PH_K_SYRK);
       }
-      if (c->profiling) timer_end(c, PH_FACTOR_BIG);
+      if (c->profiling > 0) timer_end(c, PH_FACTOR_BIG);
     }
   }
   timer_end(c, PH_FACTORIZE);
@@ -891,10 +895,10 @@ void dev_backsolve(gsx_context* c) {
       // few fronts: small and big ones of the level in ONE launch (the level costs one kernel latency, not 2-4)
       int maxn = 0;
       for (int k = le; k < S.lvl_ptr[l + 1]; ++k) maxn = std::max(maxn, S.N[S.sched[k]]);
-      if (c->profiling) timer_begin(c, PH_K_BACKSOLVE);
+      if (c->profiling > 0) timer_begin(c, PH_K_BACKSOLVE);
       launch_backsolve(c->DS, c->d_sched.p + le, n_rest, B.count ? 1024 : (maxn <= 48 ? 64 : 256), maxn, c->d_arena.p,
                        c->d_delta.p, c->d_status.p, c->stream);
-      if (c->profiling) timer_end(c, PH_K_BACKSOLVE);
+      if (c->profiling > 0) timer_end(c, PH_K_BACKSOLVE);
     } else {
       // (the cliques of a level only read their parents' solution: their launches are independent — side by side)
       // — measured: the launches of a back-substitution level are too short (20-50 us each) to pay for the ~85 us of
@@ -905,10 +909,10 @@ void dev_backsolve(gsx_context* c) {
       if (B.count) {
         int maxn = 0;
         for (int k = se; k < S.lvl_ptr[l + 1]; ++k) maxn = std::max(maxn, S.N[S.sched[k]]);
-        if (c->profiling) timer_begin(c, PH_K_BACKSOLVE);
+        if (c->profiling > 0) timer_begin(c, PH_K_BACKSOLVE);
         launch_backsolve(c->DS, c->d_sched.p + se, S.lvl_ptr[l + 1] - se, 1024, maxn, c->d_arena.p, c->d_delta.p,
                          c->d_status.p, side ? side_stream(c, gi++, &used) : c->stream);
-        if (c->profiling) timer_end(c, PH_K_BACKSOLVE);
+        if (c->profiling > 0) timer_end(c, PH_K_BACKSOLVE);
       }
       // the size groups of the factorization (split by LDS footprint) mean nothing here — the back-substitution keeps
       // only n - 1 doubles per clique in LDS: all the level's LDS-class cliques go in ONE launch (a level's
