@@ -154,7 +154,7 @@ struct gsx_context {
   int lm_iterations = 0, lm_inner = 0;
   // stats
   Timer timers[PH_COUNT];
-  int profiling = 0;
+  int profiling = -1;  // -1: no event timers (default), 0: phase timers, 1: + every front launch (gsx_set_profiling)
   int64_t n_cheirality = 0;
   // host copies of the launch tables, for the filtered plans of gsx_relinearize_partial
   std::vector<LeafRec> h_leaf_recs;

@@ -432,9 +432,9 @@ gsx_status gsx_cholesky_partial(double* abc, int32_t n, int32_t nfrontal, int32_
 gsx_status gsx_get_stats(gsx_handle h, gsx_stats* out);
 gsx_status gsx_reset_stats(gsx_handle h);
 gsx_status gsx_synchronize(gsx_handle h);
-/* level 0 (default): HIP-event timers around the phases (the ms_* fields of gsx_stats; an event record costs ~5 us of
- * stream time, ~70 us per LM iteration); level 1: additionally every factor_small / factor_big launch (and one stream
- * only); level -1: no timers at all — what a production loop and the timed region of bench.py use */
+/* level -1 (default): no timers — the ms_* / n_* fields of gsx_stats stay 0; level 0: HIP-event timers around the phases
+ * (an event record costs ~5 us of stream time, ~70 us per LM iteration); level 1: additionally every factor_small /
+ * factor_big launch (and one stream only).  bench.py times with -1 and reads the phase times from a level-0 pass. */
 gsx_status gsx_set_profiling(gsx_handle h, int32_t level);
 /* average duration (ms) of the named kernel class over launches since the last
  * gsx_reset_stats, measured with HIP events on the handle's stream; names:

@@ -52,10 +52,12 @@ def main():
                 be.solve(0.0, False, want_delta=False)
             be.synchronize()
             t_part = (time.perf_counter() - t0) / 10
+            be.set_profiling(0)
             be.reset_stats()
             be.relinearize_partial(keys, states)
             be.synchronize()
             st = be.stats()
+            be.set_profiling(-1)
             dev_ms = st["ms_linearize"] + st["ms_assemble_hessian"] + st["ms_factorize"]
             rows.append(dict(workload=name, moved=f"{pick} {n} poses", full_ms=1e3 * t_full, partial_ms=1e3 * t_part,
                              partial_device_ms_without_backsolve=dev_ms, **stats))
