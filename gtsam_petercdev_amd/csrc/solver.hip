@@ -767,7 +767,7 @@ void dev_linearize(gsx_context* c) {
   c->linearized = true;
   c->fact_valid = false;
   c->h_ready = false;
-  c->damp_ready = false;
+  if (c->damp_kind != 0) c->damp_ready = false;  // (lambda I weights do not depend on the linearization: keep them)
   c->solved = false;
 }
 
@@ -799,7 +799,7 @@ void dev_hessian_diag(gsx_context* c) {
 }
 
 void dev_damping(gsx_context* c, int diagonal, double mind, double maxd) {
-  if (c->damp_ready && c->damp_kind == diagonal && c->damp_min == mind && c->damp_max == maxd) return;
+  if (c->damp_ready && c->damp_kind == diagonal && (diagonal == 0 || (c->damp_min == mind && c->damp_max == maxd))) return;
   if (diagonal) dev_hessian_diag(c);
   launch_make_damping((int)c->P.tan_size, c->d_hdiag.p, diagonal, mind, maxd, c->d_damp.p, c->stream);
   // (a cap variable is damped once: by rank 0's share of the exchange)
