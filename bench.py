@@ -63,7 +63,7 @@ def parse():
 
 
 # relaxed amalgamation per workload (relax, max merged frontal dim), from tools/sweep_amalgamation.sh on MI355X
-AMALGAMATION = {"bal1723": (0.25, 128), "bal49": (0.25, 128), "pose3_100k": (0.5, 64), "pose2_100k": (1.0, 64)}
+AMALGAMATION = {"bal1723": (0.25, 128), "bal49": (0.25, 128), "pose3_100k": (0.5, 80), "pose2_100k": (0.5, 64)}
 
 
 def make_problem(name, seed):
