@@ -360,11 +360,9 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     // LDS fronts, those join the blocked path: no launch of their own, and the level's panel-step chain is set by the
     // big fronts' wider frontal blocks in any case (measured on the 100 000-pose graphs, limit swept 256 / 1024 / 4096:
     // 1024 is best — 7.79 -> 7.13 ms and 4.56 -> 3.69 ms per iteration).
-    std::vector<int> n_lds(S.n_levels + 1, 0), n_blk(S.n_levels + 1, 0);
     int nlev = 0;
     for (int f = 0; f < nfr; ++f) nlev = std::max(nlev, S.level[f] + 1);
-    n_lds.assign(nlev, 0);
-    n_blk.assign(nlev, 0);
+    std::vector<int> n_lds(nlev, 0), n_blk(nlev, 0);
     for (int f = 0; f < nfr; ++f) {
       if (S.cls[f] == 1) n_lds[S.level[f]]++;
       else if (S.cls[f] == 2) n_blk[S.level[f]]++;
