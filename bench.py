@@ -110,14 +110,16 @@ def front_split(be, arrays, small_max_n=140, leaf_max_f=16, tile=32, leaf_max_pa
         out["n_" + k] += 1
         out["n_lean"] += int(lean[i])
         out["lpanel_bytes"] += 8.0 * f * n
-        if k == "big":  # blocked path, 32-column panels: flops of each kernel class
+        if k == "big":  # blocked path (csrc/bigfront.hip), rounds of <= 192 frontal columns: flops of each kernel
+            nch = int(np.ceil(f / 192.0))
+            chunk = min(192.0, np.ceil(np.ceil(f / nch) / tile) * tile)
             c0 = 0.0
             while c0 < f:
-                w = min(tile, f - c0)
+                w = min(chunk, f - c0)
                 m = n - (c0 + w)
-                out["big_potrf_flops"] += w ** 3 / 3 + w ** 3       # tile factorization + explicit tile inverse
-                out["big_trsm_flops"] += w * w * m                    # X <- X L^-T (triangular tile product)
-                out["big_syrk_flops"] += w * m * (m + 1)              # C -= X X' on the lower tile pairs
+                out["big_potrf_flops"] += w ** 3 / 3                  # L11 = chol(A11) of the chunk (big_diag)
+                out["big_trsm_flops"] += w * w * m                    # L21 = A21 L11^-T (big_rows)
+                out["big_syrk_flops"] += w * m * (m + 1)              # A22 -= L21 L21' on the lower tile pairs (big_schur)
                 c0 += w
             out["gather_bytes"] += 2 * 8.0 * n * (n + 1) / 2          # destination lower triangle read + written once
     for i, p in enumerate(parent):
@@ -293,8 +295,9 @@ def main():
     kernels = [
         ("factor_leaf", "front_leaf_kernel", "hbm", split["leaf_bytes"]),
         ("factor_small", "front_small_kernel", "hbm", split["small_bytes"]),
-        ("big_syrk", "big_panel_kernel", "mfma", split["big_syrk_flops"] + split["big_trsm_flops"]),
-        ("big_potrf0", "big_potrf0_kernel", "mfma", split["big_potrf_flops"]),
+        ("big_diag", "big_diag_kernel", "mfma", split["big_potrf_flops"]),
+        ("big_rows", "big_rows_kernel", "mfma", split["big_trsm_flops"]),
+        ("big_schur", "big_schur_kernel", "mfma", split["big_syrk_flops"]),
         ("big_gather", "big_gather_seg_kernel(+combine)", "hbm", split["gather_bytes"]),
         ("assemble_hessian", "assemble_h_kernel(+hessian_diag)", "hbm", st["jacobian_bytes"] + st["hessian_bytes"]),
         ("backsolve", "backsolve_kernel (all levels)", "hbm", split["lpanel_bytes"]),

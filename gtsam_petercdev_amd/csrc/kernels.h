@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <vector>
 
 namespace gsx {
 
@@ -117,9 +118,18 @@ void launch_front_small(const DevProblem& P, const DevSymbolic& S, const int* id
 void launch_big_init(const DevProblem& P, const DevSymbolic& S, const BigDesc* descs, int count, int max_n,
                      int max_nfv, const double* H, const double* damp, const double* scalars, double* arena,
                      hipStream_t st);
-void launch_big_potrf0(const BigDesc* descs, int count, double* arena, DevStatus* status, hipStream_t st);
-void launch_big_step(const BigDesc* descs, int count, int kb, int max_pairs, double* arena, DevStatus* status,
+// Partial Cholesky of a group of big fronts (bigfront.hip): rounds of `chunk` frontal columns, three launches each —
+// diag (L11 of the chunk, one workgroup per front), rows (L21 = A21 L11^-T, one per 32 rows), schur (A22 -= L21 L21').
+struct BigPlan {
+  int chunk = 0;
+  std::vector<int> fw, rb, pairs;  // per round: widest chunk, most 32-row blocks below it, most lower tile pairs
+  int rounds() const { return (int)fw.size(); }
+};
+void plan_big_group(const BigDesc* host_descs, int count, BigPlan& plan);
+void launch_big_diag(const BigDesc* descs, int count, const BigPlan& plan, int round, double* arena, DevStatus* status,
                      hipStream_t st);
+void launch_big_rows(const BigDesc* descs, int count, const BigPlan& plan, int round, double* arena, hipStream_t st);
+void launch_big_schur(const BigDesc* descs, int count, const BigPlan& plan, int round, double* arena, hipStream_t st);
 void launch_front_leaf(const DevProblem& P, const DevSymbolic& S, const LeafRec* recs, int count, int max_panel, int threads,
                        const double* H, const double* damp, const double* scalars, double* arena, DevStatus* status,
                        hipStream_t st);

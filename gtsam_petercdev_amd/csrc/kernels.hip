@@ -2470,12 +2470,12 @@ void launch_dense_partial(double* a, int n, int nf, DevStatus* status, hipStream
   BigDesc* d = nullptr;
   hipMalloc(&d, sizeof(BigDesc));
   hipMemcpyAsync(d, &h, sizeof(BigDesc), hipMemcpyHostToDevice, st);
-  const int steps = (nf + T - 1) / T;
-  launch_big_potrf0(d, 1, a, status, st);
-  for (int kb = 0; kb < steps; ++kb) {
-    const int c0 = kb * T, w = (nf - c0 < T) ? nf - c0 : T, base = c0 + w;
-    const int nt = (n - base + T - 1) / T;
-    launch_big_step(d, 1, kb, nt * (nt + 1) / 2, a, status, st);
+  BigPlan plan;
+  plan_big_group(&h, 1, plan);
+  for (int r = 0; r < plan.rounds(); ++r) {
+    launch_big_diag(d, 1, plan, r, a, status, st);
+    launch_big_rows(d, 1, plan, r, a, st);
+    launch_big_schur(d, 1, plan, r, a, st);
   }
   big_copy_panel_kernel<<<64, 256, 0, st>>>(d, a);
   hipMemcpyAsync(user, work, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, st);

@@ -68,8 +68,8 @@ struct SmallLaunch {
   int max_panel = 0;  // leaf launches: largest n*F of the group (LDS doubles)
 };
 struct BigLevel {
-  int begin = 0, count = 0, steps = 0, max_s1 = 0;
-  std::vector<int> pairs;  // per panel step kb: the most lower tile pairs of any front of the level
+  int begin = 0, count = 0;
+  BigPlan plan;  // rounds of the level's blocked fronts (bigfront.hip)
 };
 
 enum Phase { PH_LINEARIZE, PH_ASSEMBLE_H, PH_FACTORIZE, PH_BACKSOLVE, PH_LINERR, PH_RETRACT, PH_ERROR,
@@ -77,7 +77,7 @@ enum Phase { PH_LINEARIZE, PH_ASSEMBLE_H, PH_FACTORIZE, PH_BACKSOLVE, PH_LINERR,
              PH_K_BACKSOLVE, PH_COUNT };
 const char* kPhaseNames[PH_COUNT] = {"linearize", "assemble_hessian", "factorize", "backsolve", "linear_error",
                                      "retract", "error", "factor_small", "factor_big", "factor_leaf",
-                                     "big_syrk", "big_trsm", "big_potrf0", "big_gather", "backsolve_launch"};
+                                     "big_schur", "big_rows", "big_diag", "big_gather", "backsolve_launch"};
 
 struct Timer {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, pool;
@@ -145,8 +145,9 @@ struct gsx_context {
   DevStatus* h_status = nullptr;
   static constexpr int kPartials = 4096;
   bool values_set = false, linearized = false, h_ready = false, hdiag_ready = false, solved = false, damp_ready = false;
-  bool fact_valid = false;   // the arena holds the factorization of the current linearization ...
+  bool fact_valid = false;   // the arena holds a SUCCESSFUL factorization of the current linearization and tree ...
   double fact_lambda = 0.0;  // ... for this lambda
+  bool fact_pending = false; // a factorization is queued whose status the host has not read yet (readback decides)
   int damp_kind = -1;
   double damp_min = 0, damp_max = 0;
   // LM state
@@ -623,21 +624,11 @@ gsx_status upload_symbolic(gsx_context* c) {
       const int f = S.sched[k];
       c->big_descs.push_back(BigDesc{(i64)S.off[f], (i64)S.off[f] + big_panel_offset(S.N[f]), S.N[f], S.F[f], f,
                                      S.parent[f]});
-      B.steps = std::max(B.steps, (S.F[f] + kTile - 1) / kTile);
-      B.max_s1 = std::max(B.max_s1, S.N[f] - S.F[f]);
       c->big_max_n = std::max(c->big_max_n, S.N[f]);
       c->big_max_nfv = std::max(c->big_max_nfv, S.nfrontal_vars[f]);
     }
     B.count = (int)c->big_descs.size() - B.begin;
-    B.pairs.assign(B.steps, 0);
-    for (int k = B.begin; k < B.begin + B.count; ++k) {
-      const BigDesc& d = c->big_descs[k];
-      for (int kb = 0; kb * kTile < d.F; ++kb) {
-        const int c0 = kb * kTile, w = std::min(kTile, d.F - c0), base = c0 + w;
-        const int nt = (d.N - base + kTile - 1) / kTile;
-        B.pairs[kb] = std::max(B.pairs[kb], nt * (nt + 1) / 2);
-      }
-    }
+    plan_big_group(c->big_descs.data() + B.begin, B.count, B.plan);
   }
   // front -> where it sits in the launch plan (for the filtered plans of gsx_relinearize_partial)
   c->fr_sched_pos.assign(S.n_fronts, -1);
@@ -714,8 +705,12 @@ gsx_status upload_symbolic(gsx_context* c) {
   D.term_ptr = c->d_term_ptr.p; D.terms = c->d_terms.p;
   D.var_recs = c->d_var_recs.p; D.child_recs = c->d_child_recs.p;
   HIPCHK(c, hipStreamSynchronize(st));
+  // a new tree: the arena and H were re-allocated for it — nothing computed for the old one may be reused
   c->h_ready = false;
   c->solved = false;
+  c->fact_valid = c->fact_pending = false;
+  c->damp_ready = c->hdiag_ready = false;   // (sharded: the damping weights carry the ownership mask)
+  if (c->sharded()) c->linearized = false;  // the owned factor set changed with the partition
   return GSX_OK;
 }
 
@@ -810,9 +805,26 @@ void dev_damping(gsx_context* c, int diagonal, double mind, double maxd) {
   c->damp_max = maxd;
 }
 
+// the blocked fronts of one launch group: per round of frontal columns L11 (one workgroup per front), the rows of
+// L21 (one per 32 rows), the Schur complement (one per lower tile pair) — bigfront.hip
+void dev_big_factor(gsx_context* c, const BigDesc* descs, int count, const BigPlan& plan, hipStream_t st, bool prof) {
+  for (int r = 0; r < plan.rounds(); ++r) {
+    if (prof) timer_begin(c, PH_K_POTRF0);  // (one HIP-event pair per kernel launch)
+    launch_big_diag(descs, count, plan, r, c->d_arena.p, c->d_status.p, st);
+    if (prof) timer_end(c, PH_K_POTRF0);
+    if (prof) timer_begin(c, PH_K_TRSM);
+    launch_big_rows(descs, count, plan, r, c->d_arena.p, st);
+    if (prof) timer_end(c, PH_K_TRSM);
+    if (prof) timer_begin(c, PH_K_SYRK);
+    launch_big_schur(descs, count, plan, r, c->d_arena.p, st);
+    if (prof) timer_end(c, PH_K_SYRK);
+  }
+}
+
 void dev_factorize(gsx_context* c, double lambda) {
   const Symbolic& S = c->S;
-  c->fact_valid = true;
+  c->fact_valid = false;   // becomes true when the read-back shows no failed front (readback)
+  c->fact_pending = true;
   c->fact_lambda = lambda;
   c->sc_dirty |= kXFact;
   timer_begin(c, PH_FACTORIZE);
@@ -870,14 +882,7 @@ void dev_factorize(gsx_context* c, double lambda) {
       // sharded: every rank's share of the cap (H terms, damping, its subtrees' Schur complements) is in; their sum
       // is the assembled cap, which all ranks now factor alike
       if (l == S.cap_level0) shard_allreduce(c, c->d_arena.p + S.cap_begin, S.cap_end - S.cap_begin);
-      if (prof) timer_begin(c, PH_K_POTRF0);
-      launch_big_potrf0(c->d_big.p + B.begin, B.count, c->d_arena.p, c->d_status.p, c->stream);
-      if (prof) timer_end(c, PH_K_POTRF0);
-      for (int kb = 0; kb < B.steps; ++kb) {
-        if (prof) timer_begin(c, PH_K_SYRK);  // one HIP-event pair per kernel launch
-        launch_big_step(c->d_big.p + B.begin, B.count, kb, B.pairs[kb], c->d_arena.p, c->d_status.p, c->stream);
-        if (prof) timer_end(c, PH_K_SYRK);
-      }
+      dev_big_factor(c, c->d_big.p + B.begin, B.count, B.plan, c->stream, prof);
       if (c->profiling > 0) timer_end(c, PH_FACTOR_BIG);
     }
   }
@@ -976,8 +981,16 @@ gsx_status readback(gsx_context* c) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());
   c->n_cheirality = c->h_status->n_cheirality;
+  // the factorization in the arena is only trusted (solve at the same lambda, marginals, partial re-elimination) once its
+  // status has been seen clean
+  const bool bad = c->h_status->n_fail > 0 || c->h_status->n_nonfinite > 0;
+  if (c->fact_pending) c->fact_valid = !bad;
+  else if (bad) c->fact_valid = false;
+  c->fact_pending = false;
   return GSX_OK;
 }
+
+bool factorization_ok(const gsx_context* c) { return c->h_status->n_fail == 0 && c->h_status->n_nonfinite == 0; }
 
 uint64_t failing_key(gsx_context* c) {
   const DevStatus& s = *c->h_status;
@@ -1008,6 +1021,7 @@ struct Trace {
   }
 };
 
+// One damped trial on the device + the controller's verdict on it (csrc/lm_policy.cpp: gsx_lm_decide).
 gsx_status lm_try_lambda(gsx_context* c, const gsx_lm_params& p, Trace& tr, gsx_lm_result* res, bool* done) {
   dev_damping(c, p.diagonal_damping, p.min_diagonal, p.max_diagonal);
   dev_factorize(c, c->lm_lambda);
@@ -1017,62 +1031,28 @@ gsx_status lm_try_lambda(gsx_context* c, const gsx_lm_params& p, Trace& tr, gsx_
   dev_error(c, c->d_trial.p, SC_TRIAL_ERR);
   gsx_status st = readback(c);
   if (st != GSX_OK) return st;
-  const bool systemSolvedSuccessfully = (c->h_status->n_fail == 0 && c->h_status->n_nonfinite == 0);
-  if (!systemSolvedSuccessfully && res) res->n_solve_failures++;
-  double modelFidelity = 0.0;
-  bool step_is_successful = false, stopSearchingLambda = false;
-  double newError = std::numeric_limits<double>::infinity();
-  double costChange = 0.0;
-  const double lambda_tried = c->lm_lambda;
-  if (systemSolvedSuccessfully) {
-    const double oldLinearizedError = c->h_scalars[SC_LIN0];
-    const double newlinearizedError = c->h_scalars[SC_LIND];
-    const double linearizedCostChange = oldLinearizedError - newlinearizedError;
-    if (linearizedCostChange >= 0) {
-      newError = c->h_scalars[SC_TRIAL_ERR];
-      costChange = c->lm_error - newError;
-      if (linearizedCostChange > std::numeric_limits<double>::epsilon() * oldLinearizedError) {
-        modelFidelity = costChange / linearizedCostChange;
-        step_is_successful = modelFidelity > p.min_model_fidelity;
-      }
-      const double minAbsoluteTolerance = p.relative_error_tol * c->lm_error;
-      if (std::abs(costChange) < minAbsoluteTolerance) stopSearchingLambda = true;
-    }
-  }
+  const bool solved = factorization_ok(c);
+  if (!solved && res) res->n_solve_failures++;
+  gsx_lm_state ctl{c->lm_lambda, c->lm_factor, c->lm_error, c->lm_iterations, c->lm_inner};
+  gsx_lm_decision d;
+  gsx_lm_decide(&p, &ctl, solved, c->h_scalars[SC_LIN0], c->h_scalars[SC_LIND], c->h_scalars[SC_TRIAL_ERR], &d);
   if (p.verbosity >= 1)
-    std::printf("%4d %12.6g %12.2e %10.2e %6d\n", c->lm_iterations, newError, costChange, c->lm_lambda,
-                (int)systemSolvedSuccessfully);
-  if (step_is_successful) {
-    double newLambda = c->lm_lambda, newFactor = c->lm_factor;
-    if (p.use_fixed_lambda_factor) {
-      newLambda /= c->lm_factor;
-    } else {
-      newLambda *= std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * modelFidelity - 1.0, 3));
-      newFactor = 2.0 * c->lm_factor;
-    }
-    newLambda = std::max(p.lambda_lower_bound, newLambda);
-    std::swap(c->d_values.p, c->d_trial.p);  // accept the trial values
+    std::printf("%4d %12.6g %12.2e %10.2e %6d\n", c->lm_iterations, d.trial_cost, d.cost_change, d.lambda_tried, d.solved);
+  if (d.verdict == GSX_LM_TAKE) {
+    std::swap(c->d_values.p, c->d_trial.p);  // the trial values become the current ones
     c->values_synced = false;
     c->linearized = false;
     c->h_ready = false;
     c->solved = false;
-    c->lm_error = newError;
-    c->lm_lambda = newLambda;
-    c->lm_factor = newFactor;
-    c->lm_iterations += 1;
-    c->lm_inner += 1;
-    tr.push(newError, lambda_tried, 1);
-    *done = true;
-  } else if (!stopSearchingLambda) {
-    c->lm_lambda *= c->lm_factor;
-    c->lm_inner += 1;
-    if (!p.use_fixed_lambda_factor) c->lm_factor *= 2.0;
-    tr.push(newError, lambda_tried, systemSolvedSuccessfully ? 0 : -1);
-    *done = (c->lm_lambda >= p.lambda_upper_bound);
-  } else {
-    tr.push(newError, lambda_tried, 0);
-    *done = true;
+    c->fact_valid = false;
   }
+  c->lm_lambda = ctl.lambda;
+  c->lm_factor = ctl.factor;
+  c->lm_error = ctl.cost;
+  c->lm_iterations = ctl.outer_iterations;
+  c->lm_inner = ctl.inner_iterations;
+  tr.push(d.trial_cost, d.lambda_tried, d.verdict == GSX_LM_TAKE ? 1 : (solved ? 0 : -1));
+  *done = d.verdict != GSX_LM_RETRY;
   return GSX_OK;
 }
 
@@ -1938,8 +1918,8 @@ gsx_status gsx_relinearize_partial(gsx_handle h, const uint64_t* keys, int32_t n
     struct LevelPlan {
       std::vector<std::array<int, 4>> leaf;   // begin, count, max_panel, threads
       std::vector<std::array<int, 4>> small;  // begin, count, max_n, threads
-      int big_begin = 0, big_count = 0, steps = 0;
-      std::vector<int> pairs;
+      int big_begin = 0, big_count = 0;
+      BigPlan big_plan;
       std::vector<int> seg_idx, gm_idx;
       int seg0 = 0, nseg = 0, m0 = 0, nm = 0;
     };
@@ -1966,7 +1946,6 @@ gsx_status gsx_relinearize_partial(gsx_handle h, const uint64_t* keys, int32_t n
           const BigDesc& d = h->big_descs[g];
           big.push_back(d);
           L.big_count++;
-          L.steps = std::max(L.steps, (d.F + kTile - 1) / kTile);
           big_max_n = std::max(big_max_n, d.N);
           big_max_nfv = std::max(big_max_nfv, S.nfrontal_vars[f]);
           // its gather segments (sources: ALL its children, clean or not), at the level the full schedule runs them
@@ -1982,12 +1961,7 @@ gsx_status gsx_relinearize_partial(gsx_handle h, const uint64_t* keys, int32_t n
     }
     for (int l = 0; l < S.n_levels; ++l) {
       LevelPlan& L = plan[l];
-      L.pairs.assign(L.steps, 0);
-      for (int k = L.big_begin; k < L.big_begin + L.big_count; ++k)
-        for (int kb = 0; kb * kTile < big[k].F; ++kb) {
-          const int c0 = kb * kTile, w = std::min(kTile, big[k].F - c0), nt = (big[k].N - (c0 + w) + kTile - 1) / kTile;
-          L.pairs[kb] = std::max(L.pairs[kb], nt * (nt + 1) / 2);
-        }
+      plan_big_group(big.data() + L.big_begin, L.big_count, L.big_plan);
       // (no particular order is needed: every segment adds into its own destination block or its own scratch slot)
       L.seg0 = (int)segs.size();
       for (int i : L.seg_idx) segs.push_back(h->h_gsegs[i]);
@@ -2030,9 +2004,7 @@ gsx_status gsx_relinearize_partial(gsx_handle h, const uint64_t* keys, int32_t n
       if (l == 0 && L.nseg) launch_big_gather(GA, L.seg0, L.nseg, L.m0, L.nm, h->d_arena.p, sm);  // gather group 0
       if (L.big_count) {
         if (l > 0 && L.nseg) launch_big_gather(GA, L.seg0, L.nseg, L.m0, L.nm, h->d_arena.p, sm);
-        launch_big_potrf0(ps.big.p + L.big_begin, L.big_count, h->d_arena.p, h->d_status.p, sm);
-        for (int kb = 0; kb < L.steps; ++kb)
-          launch_big_step(ps.big.p + L.big_begin, L.big_count, kb, L.pairs[kb], h->d_arena.p, h->d_status.p, sm);
+        dev_big_factor(h, ps.big.p + L.big_begin, L.big_count, L.big_plan, sm, false);
       }
     }
     timer_end(h, PH_FACTORIZE);

@@ -370,6 +370,33 @@ gsx_status gsx_lm_optimize(gsx_handle h, const gsx_lm_params* p, gsx_lm_result* 
 gsx_status gsx_lm_reset(gsx_handle h, const gsx_lm_params* p);
 gsx_status gsx_lm_iterate(gsx_handle h, const gsx_lm_params* p, double* error,
                           double* lambda);
+/* The trust policy alone, as a pure host function (csrc/lm_policy.cpp; usable without a GPU): what one damped trial means
+ * for the controller.  Inputs: whether the damped system could be factored, the quadratic model's cost at zero and at the
+ * step (undamped linearized graph), the true cost at the retracted point.  `state` is updated in place.  Decision-equivalent
+ * to LevenbergMarquardtOptimizer::tryLambda (gtsam/nonlinear/LevenbergMarquardtOptimizer.cpp:121-270) +
+ * LevenbergMarquardtState::increaseLambda / decreaseLambda (gtsam/nonlinear/internal/LevenbergMarquardtState.h:70-94);
+ * gsx_lm_optimize / gsx_lm_iterate call exactly this function. */
+typedef struct gsx_lm_state {
+  double lambda;                 /* damping weight of the next trial            */
+  double factor;                 /* its growth multiplier                       */
+  double cost;                   /* nonlinear cost at the current values        */
+  int32_t outer_iterations;      /* accepted steps                              */
+  int32_t inner_iterations;      /* trials that changed the controller          */
+} gsx_lm_state;
+enum { GSX_LM_TAKE = 1,          /* step accepted: commit the trial values, relinearize           */
+       GSX_LM_RETRY = 0,         /* step rejected: same linearization, larger damping             */
+       GSX_LM_SETTLE = 2,        /* change below the relative tolerance: stop searching lambda    */
+       GSX_LM_GIVE_UP = 3 };     /* damping passed lambda_upper_bound                             */
+typedef struct gsx_lm_decision {
+  int32_t verdict;               /* GSX_LM_*                                    */
+  int32_t solved;                /* the damped system was factored              */
+  double gain_ratio;             /* actual / predicted decrease (0 when not formed) */
+  double cost_change;            /* cost(now) - cost(trial)                     */
+  double trial_cost;             /* +inf when the trial cost was not consulted  */
+  double lambda_tried;
+} gsx_lm_decision;
+gsx_status gsx_lm_decide(const gsx_lm_params* p, gsx_lm_state* state, int32_t solved, double model_at_zero,
+                         double model_at_step, double trial_cost, gsx_lm_decision* out);
 /* One LM trial without the accept/reject policy — the numeric body of LevenbergMarquardtOptimizer::tryLambda
  * (gtsam/nonlinear/LevenbergMarquardtOptimizer.cpp:121-230), preceded when relinearize != 0 by the linearization
  * iterate() does (:252-262): damped solve, linearized error at 0 and at delta, retract into the trial values (the
