@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 
 #include "gsx_internal.h"
 #include "kernels.h"
@@ -37,6 +38,20 @@ namespace {
 typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int T = kTile;          // 32: edge of the diagonal tiles of the stored layout
 constexpr int kMaxChunk = 192;    // frontal columns one round factors (12 tile rows of 16: 78 tiles over 8 waves)
+
+#ifdef GSX_STAMP
+__device__ unsigned long long g_bstamp[16];
+#define BST_BEGIN unsigned long long bst0__ = __builtin_amdgcn_s_memtime();
+#define BST_ADD(slot)                                                          \
+  {                                                                            \
+    unsigned long long t__ = __builtin_amdgcn_s_memtime();                     \
+    if (threadIdx.x == 0 && blockIdx.x == 0) g_bstamp[slot] += t__ - bst0__;   \
+    bst0__ = t__;                                                              \
+  }
+#else
+#define BST_BEGIN
+#define BST_ADD(slot)
+#endif
 
 __device__ __forceinline__ void lds_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -83,6 +98,7 @@ __global__ void __launch_bounds__(NW * 64) big_diag_kernel(const BigDesc* descs,
   __shared__ double ldiag[kMaxChunk];   // L_cc
   __shared__ int sfail;
   extern __shared__ double dyn[];       // the factored 32 x 32 diagonal tiles [kb][r][33], then the 16 x 16 inverses [b][i][17]
+  BST_BEGIN
   const BigDesc d = descs[blockIdx.x];
   const int n = d.N, F = d.F;
   if (c0 >= F) return;
@@ -119,6 +135,7 @@ __global__ void __launch_bounds__(NW * 64) big_diag_kernel(const BigDesc* descs,
 
   int fail = 0;
   int s0 = 0;  // first slot whose tile column has not been finished
+  BST_ADD(0)
   for (int tc = 0; tc < nt16; ++tc) {
     const int jb = 16 * tc;
     // this wave's tiles of column tc (a column has at most 2 NW tiles: at most two, its first unfinished slots)
@@ -141,6 +158,7 @@ __global__ void __launch_bounds__(NW * 64) big_diag_kernel(const BigDesc* descs,
         }
       }
     }
+    BST_ADD(1)
     // 2. of a stage: factor the 4 x 4 pivot block (every owner lane alike), scale the tile's rows, publish L
 #define GSX_PHASE2(PT, R, M)                                                                                          \
   {                                                                                                                   \
@@ -196,9 +214,12 @@ __global__ void __launch_bounds__(NW * 64) big_diag_kernel(const BigDesc* descs,
         if (own0) P[r0][lk] = pt0[m];
         if (own1) P[r1][lk] = pt1[m];
         lds_bar();
+        BST_ADD(2)
         if (own0) GSX_PHASE2(pt0, r0, m)
         if (own1) GSX_PHASE2(pt1, r1, m)
+        BST_ADD(3)
         lds_bar();
+        BST_ADD(4)
         // rank-4 updates: D[col][row] -= sum_k L[col][j+k] L[row][j+k]
         if (m < 3) {
           if (own0) GSX_OWN_UPD(pt0, r0)
@@ -210,6 +231,7 @@ __global__ void __launch_bounds__(NW * 64) big_diag_kernel(const BigDesc* descs,
           if (s0 <= k)
             acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lc[16 * tj[k] + li][lk], Lc[16 * ti[k] + li][lk], acc[k], 0, 0,
                                                           0);
+        BST_ADD(5)
       }
     }
 #undef GSX_PHASE2
@@ -230,6 +252,7 @@ __global__ void __launch_bounds__(NW * 64) big_diag_kernel(const BigDesc* descs,
         if (same) tiles[((r >> 5) * T + (r & 31)) * (T + 1) + (cc & 31)] = v;
       }
     }
+    BST_ADD(6)
   }
   if (fail) sfail = 1;
   lds_bar();
@@ -280,6 +303,7 @@ __global__ void __launch_bounds__(NW * 64) big_diag_kernel(const BigDesc* descs,
       if (i < w1) A[(c0 + kb * T + li) + (i64)(c0 + kb * T + 16 + i) * n] = t2[q];
     }
   }
+  BST_ADD(7)
   if (tid == 0) {
     int bad = sfail;
     if (c0 + fw == F) {  // conditioning test on the last two pivots (cholesky.cpp:145-158)
@@ -429,6 +453,18 @@ __global__ void __launch_bounds__(256) big_schur_kernel(const BigDesc* descs, in
 }
 
 }  // namespace
+
+#ifdef GSX_STAMP
+void big_stamp_dump(const char* what) {
+  unsigned long long h[16];
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bstamp), sizeof(h));
+  printf("[bstamp] %s: diag prologue %llu | column setup %llu | publish+bar1 %llu | phase2 %llu | bar2 %llu | updates %llu | "
+         "column store %llu | inverse %llu  (cycles, wave 0 of block 0)\n", what, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+  unsigned long long z[16] = {0};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_bstamp), z, sizeof(z));
+}
+#endif
 
 // ---- host side -----------------------------------------------------------------------------------------------------
 // Rounds of one launch group: every front of the group advances by `chunk` frontal columns per round.

@@ -128,6 +128,9 @@ struct BigPlan {
 void plan_big_group(const BigDesc* host_descs, int count, BigPlan& plan);
 void launch_big_diag(const BigDesc* descs, int count, const BigPlan& plan, int round, double* arena, DevStatus* status,
                      hipStream_t st);
+#ifdef GSX_STAMP
+void big_stamp_dump(const char* what);
+#endif
 void launch_big_rows(const BigDesc* descs, int count, const BigPlan& plan, int round, double* arena, hipStream_t st);
 void launch_big_schur(const BigDesc* descs, int count, const BigPlan& plan, int round, double* arena, hipStream_t st);
 void launch_front_leaf(const DevProblem& P, const DevSymbolic& S, const LeafRec* recs, int count, int max_panel, int threads,

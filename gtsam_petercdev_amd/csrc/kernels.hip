@@ -2482,12 +2482,9 @@ void launch_dense_partial(double* a, int n, int nf, DevStatus* status, hipStream
   hipStreamSynchronize(st);
 #ifdef GSX_STAMP
   {
-    unsigned long long h[8];
-    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamp), sizeof(h));
-    printf("[stamp] big n=%d F=%d tiles=%d: factor %llu inv8 %llu doubling %llu writeback %llu | panel-before-lookahead %llu\n",
-           n, nf, steps, h[2], h[3], h[4], h[5], h[6]);
-    unsigned long long z[8] = {0};
-    hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z));
+    char what[64];
+    snprintf(what, sizeof(what), "n=%d F=%d", n, nf);
+    big_stamp_dump(what);
   }
 #endif
   hipFree(d);
