@@ -68,36 +68,37 @@ __device__ inline void report_failure(DevStatus* status, int front) {
 }
 
 // ---- A. L11 = chol(A11[c0 .. c0 + fw)) ------------------------------------------------------------------------------
-// Lower 16 x 16 tiles (ti >= tj), column-major over the triangle, tile t -> wave t % NW, slot t / NW (so a wave's slots
-// are sorted by tile column, and a wave owns at most one tile of any column).  A lane (li = lane & 15, lk = lane >> 4)
-// holds of a tile the entries (row 16 ti + li, column 16 tj + 4 q + lk), q = 0..3 — the accumulator layout of
-// v_mfma_f64_16x16x4 with the tile computed transposed, so that the rank-4 update of a tile by four finished columns
-// is ONE instruction whose operands are the tile row's and the tile column's L values.
-// Per tile column: the wave that owns a tile of it moves that tile to `pt`, the four stages (4 pivots each) run
-//   1. owners publish their rows of the 4 current columns            -> LDS barrier
-//   2. owners factor the 4 x 4 pivot block (each lane alike), scale their rows, publish L -> LDS barrier
-//   3. every tile to the right takes its rank-4 update (one matrix-core instruction per tile)
-// and the finished tile goes out to the front.  The slots still to the right are a suffix s >= s0 of the wave's slots:
-// the update chain is entered through a switch, so every slot's code exists once and there is no per-slot branch.
-__device__ __forceinline__ void tile_coords(int t, int nt16, int& ti, int& tj) {
-  int c = 0;
-  while (t >= nt16 - c) {
-    t -= nt16 - c;
-    ++c;
-  }
-  tj = c;
-  ti = c + t;
+// Lower 16 x 16 tiles (ti >= tj), column-major over the triangle, tile t -> wave t % NW, slot t / NW: a wave's slots are
+// sorted by tile column and (NW >= tile rows) it owns at most one tile of any column.  A lane (li = lane & 15,
+// lk = lane >> 4) holds of a tile the entries (row 16 ti + li, column 16 tj + 4 q + lk), q = 0..3 — the accumulator
+// layout of v_mfma_f64_16x16x4 with the tile computed transposed: a rank-4 update of a tile is ONE instruction whose
+// operands are the tile column's and the tile row's L values, and a tile's own four columns ARE the row-side operand.
+// Per tile column tc (16 pivots), two workgroup barriers:
+//   D. the wave that owns the diagonal tile factors it alone, pivot by pivot, with NO cross-lane data movement but one
+//      v_readlane of the pivot: the lanes that hold column j scale it and ARE the (one non-zero k of the) operands of
+//      the rank-1 update of the tile, one matrix-core instruction.  An identity tile carried through the same column
+//      operations comes out as L_dd^-T: the inverse of the diagonal tile (published; it is also what the stored
+//      32 x 32 tile inverses are assembled from).  Chain per pivot: readlane -> rsq + correction -> mul -> mfma.
+//   O. the waves that own the other tiles of the column: L_tile = A_tile L_dd^-T, four matrix-core instructions whose
+//      row-side operand is the tile as it stands in its registers; they publish their rows of L (a 16-column strip)
+//   U. every tile to the right takes its rank-16 update, four matrix-core instructions with operands from the strip.
+//      The next diagonal tile is the first slot of its owner's chain, and that wave goes straight on to its D: the
+//      sequential part of column tc+1 runs beside the updates of column tc.
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {  // src_lane wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
 }
 
 template <int NW, int MAXS>
 __global__ void __launch_bounds__(NW * 64) big_diag_kernel(const BigDesc* descs, int c0, int chunk, double* arena,
                                                            DevStatus* status) {
-  __shared__ double P[kMaxChunk][4];    // the four current columns, raw (updated through the previous stage)
-  __shared__ double Lc[kMaxChunk][4];   // the same columns of L
-  __shared__ double dinv[kMaxChunk];    // 1 / L_cc
-  __shared__ double ldiag[kMaxChunk];   // L_cc
+  constexpr int LS = 18;                 // row stride (doubles) of the L strips: operand reads hit 32 distinct bank pairs
+  __shared__ double Lc[kMaxChunk][LS];   // rows of L of the current tile column (16 columns), the tile rows below the diagonal tile
+  __shared__ double dinv[kMaxChunk];     // 1 / L_cc
+  __shared__ double ldiag[kMaxChunk];    // L_cc
   __shared__ int sfail;
-  extern __shared__ double dyn[];       // the factored 32 x 32 diagonal tiles [kb][r][33], then the 16 x 16 inverses [b][i][17]
+  extern __shared__ double dyn[];        // the factored 32 x 32 diagonal tiles [kb][r][33], then the 16 x 16 inverses [b][i][17]
   BST_BEGIN
   const BigDesc d = descs[blockIdx.x];
   const int n = d.N, F = d.F;
@@ -119,7 +120,15 @@ __global__ void __launch_bounds__(NW * 64) big_diag_kernel(const BigDesc* descs,
   for (int s = 0; s < MAXS; ++s) {
     const int t = wv + s * NW;
     ti[s] = tj[s] = 0;  // an empty slot updates a tile of zeros with valid operands: harmless
-    if (t < ntile) tile_coords(t, nt16, ti[s], tj[s]);
+    if (t < ntile) {
+      int c = 0, rem = t;
+      while (rem >= nt16 - c) {
+        rem -= nt16 - c;
+        ++c;
+      }
+      tj[s] = c;
+      ti[s] = c + rem;
+    }
     const int r = 16 * ti[s] + li;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -134,153 +143,121 @@ __global__ void __launch_bounds__(NW * 64) big_diag_kernel(const BigDesc* descs,
   }
 
   int fail = 0;
-  int s0 = 0;  // first slot whose tile column has not been finished
   BST_ADD(0)
   for (int tc = 0; tc < nt16; ++tc) {
     const int jb = 16 * tc;
-    // this wave's tiles of column tc (a column has at most 2 NW tiles: at most two, its first unfinished slots)
-    bool own0 = false, own1 = false;
-    int r0 = 0, r1 = 0;
-    v4d pt0 = {0.0, 0.0, 0.0, 0.0}, pt1 = {0.0, 0.0, 0.0, 0.0};
+    // this wave's tile of column tc: the column's tiles are t = start .. start + (nt16 - tc) - 1, tile row tc + (t - start)
+    const int start = tc * nt16 - tc * (tc - 1) / 2;
+    int off = (wv - start) % NW;
+    off += off < 0 ? NW : 0;
+    const bool own = off < nt16 - tc;
+    const bool diag = own && off == 0;
+    const int slot = (start + off - wv) / NW;
+    const int r = 16 * (tc + off) + li;  // this lane's row of the owned tile
+    v4d pt = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int o = 0; o < 2; ++o) {
-      const int t = wv + s0 * NW;
-      if (s0 < MAXS && t < ntile) {
-        int cti, ctj;
-        tile_coords(t, nt16, cti, ctj);
-        if (ctj == tc) {
-#pragma unroll
-          for (int s = 0; s < MAXS; ++s)
-            if (s == s0) (o == 0 ? pt0 : pt1) = acc[s];
-          (o == 0 ? own0 : own1) = true;
-          (o == 0 ? r0 : r1) = 16 * cti + li;
-          ++s0;
-        }
-      }
-    }
+    for (int s = 0; s < MAXS; ++s)
+      if (own && s == slot) pt = acc[s];
+    const int s0 = max(0, (start + (nt16 - tc) - wv + NW - 1) / NW);  // slots of tile columns <= tc: finished after this column
     BST_ADD(1)
-    // 2. of a stage: factor the 4 x 4 pivot block (every owner lane alike), scale the tile's rows, publish L
-#define GSX_PHASE2(PT, R, M)                                                                                          \
-  {                                                                                                                   \
-    const double p00 = P[j][0];                                                                                       \
-    const double p10 = P[j + 1][0], p11 = P[j + 1][1];                                                                \
-    const double p20 = P[j + 2][0], p21 = P[j + 2][1], p22 = P[j + 2][2];                                             \
-    const double p30 = P[j + 3][0], p31 = P[j + 3][1], p32 = P[j + 3][2], p33 = P[j + 3][3];                          \
-    const double a0 = P[R][0], a1 = P[R][1], a2 = P[R][2], a3 = P[R][3];                                              \
-    /* pivot block: l_kk = sqrt(d_k), i_k = 1 / l_kk; a non-positive pivot fails the front (Eigen::LLT NumericalIssue) */ \
-    const double d0 = p00;                                                                                            \
-    const double i0 = d0 > 0 ? rsqrt_refined(d0) : 1.0;                                                               \
-    const double l10 = p10 * i0, l20 = p20 * i0, l30 = p30 * i0;                                                      \
-    const double d1 = fma(-l10, l10, p11);                                                                            \
-    const double i1 = d1 > 0 ? rsqrt_refined(d1) : 1.0;                                                               \
-    const double l21 = fma(-l20, l10, p21) * i1, l31 = fma(-l30, l10, p31) * i1;                                      \
-    const double d2 = fma(-l21, l21, fma(-l20, l20, p22));                                                            \
-    const double i2 = d2 > 0 ? rsqrt_refined(d2) : 1.0;                                                               \
-    const double l32 = fma(-l31, l21, fma(-l30, l20, p32)) * i2;                                                      \
-    const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, p33)));                                            \
-    const double i3 = d3 > 0 ? rsqrt_refined(d3) : 1.0;                                                               \
-    if (!(d0 > 0) || !(d1 > 0) || !(d2 > 0) || !(d3 > 0)) fail = 1;                                                   \
-    /* this lane's row against the block */                                                                           \
-    const double x0 = a0 * i0;                                                                                        \
-    const double x1 = fma(-x0, l10, a1) * i1;                                                                         \
-    const double x2 = fma(-x1, l21, fma(-x0, l20, a2)) * i2;                                                          \
-    const double x3 = fma(-x2, l32, fma(-x1, l31, fma(-x0, l30, a3))) * i3;                                           \
-    double out = (lk == 0) ? x0 : ((lk == 1) ? x1 : ((lk == 2) ? x2 : x3));                                           \
-    const int cpos = j + lk;                                                                                          \
-    if (R == cpos) {                                                                                                  \
-      const double dd = (lk == 0) ? d0 : ((lk == 1) ? d1 : ((lk == 2) ? d2 : d3));                                    \
-      const double ii = (lk == 0) ? i0 : ((lk == 1) ? i1 : ((lk == 2) ? i2 : i3));                                    \
-      out = dd * ii; /* sqrt(d) */                                                                                    \
-      dinv[R] = ii;                                                                                                   \
-      ldiag[R] = out;                                                                                                 \
-    }                                                                                                                 \
-    if (R < cpos) out = 0.0; /* above the diagonal */                                                                 \
-    Lc[R][lk] = out;                                                                                                  \
-    PT[M] = out;                                                                                                      \
-  }
-    // 3. for an owned tile itself: rows / columns up to j+3 are final -> zero operands
-#define GSX_OWN_UPD(PT, R)                                                                                            \
-  {                                                                                                                   \
-    const int rc = jb + li;                                                                                           \
-    double a = Lc[rc][lk], b = Lc[R][lk];                                                                             \
-    a = (rc >= j + 4) ? -a : 0.0;                                                                                     \
-    b = (R >= j + 4) ? b : 0.0;                                                                                       \
-    PT = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, PT, 0, 0, 0);                                                     \
-  }
+
+    if (diag) {
+      // ---- D: the diagonal tile, alone.  Other waves may still be in U of the previous column on this SIMD's matrix
+      //      core: this wave is the critical path of the whole front and issues first ----
+      __builtin_amdgcn_s_setprio(3);
+      v4d E;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int j = jb + 4 * m;
-      if (j < fw) {
-        if (own0) P[r0][lk] = pt0[m];
-        if (own1) P[r1][lk] = pt1[m];
-        lds_bar();
-        BST_ADD(2)
-        if (own0) GSX_PHASE2(pt0, r0, m)
-        if (own1) GSX_PHASE2(pt1, r1, m)
-        BST_ADD(3)
-        lds_bar();
-        BST_ADD(4)
-        // rank-4 updates: D[col][row] -= sum_k L[col][j+k] L[row][j+k]
-        if (m < 3) {
-          if (own0) GSX_OWN_UPD(pt0, r0)
-          if (own1) GSX_OWN_UPD(pt1, r1)
+      for (int q = 0; q < 4; ++q) E[q] = (li == 4 * q + lk) ? 1.0 : 0.0;
+      double my_s = 0.0, my_l = 1.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int q = j >> 2, lkj = j & 3;
+        __builtin_amdgcn_sched_barrier(0);  // keep the pivots apart: the chain is the schedule
+        const double dj = readlane_f64(pt[q], lkj * 16 + j);
+        if (!(dj > 0)) fail = 1;  // a non-positive pivot fails the front (Eigen::LLT NumericalIssue)
+        const double sj = rsqrt_refined(dj);
+        const bool colj = lk == lkj;  // the lanes that hold column j
+        const double xm = (colj && li >= j) ? pt[q] * sj : 0.0;  // L[li][j] (zero above the diagonal)
+        const double ej = colj ? E[q] * sj : 0.0;
+        pt[q] = colj ? xm : pt[q];
+        E[q] = colj ? ej : E[q];
+        if (lane == j) {
+          my_s = sj;
+          my_l = dj * sj;
         }
-        // tiles right of the column (tile column > tc: nothing of them is final yet, no masks): the slots from s0 on
-#pragma unroll
-        for (int k = 0; k < MAXS; ++k)
-          if (s0 <= k)
-            acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lc[16 * tj[k] + li][lk], Lc[16 * ti[k] + li][lk], acc[k], 0, 0,
-                                                          0);
-        BST_ADD(5)
+        if (j < 15) {  // rank-1 update of the columns right of j: the column's lanes are the k = lkj operands, all others zero
+          const double xu = (li > j) ? xm : 0.0;
+          pt = __builtin_amdgcn_mfma_f64_16x16x4f64(-xu, xu, pt, 0, 0, 0);
+          E = __builtin_amdgcn_mfma_f64_16x16x4f64(-xu, ej, E, 0, 0, 0);
+        }
       }
-    }
-#undef GSX_PHASE2
-#undef GSX_OWN_UPD
-    // the finished tiles: L inside a diagonal 32-tile goes to the square (and to LDS for the inverse), the rest to
-    // the L-panel area
+      if (lane < 16) {
+        dinv[jb + lane] = my_s;
+        ldiag[jb + lane] = my_l;
+      }
+      // E[row][col] = (L_dd^-1)[col][row]: published as Xd[tc][i][c] = (L_dd^-1)[i][c]; its strictly lower part inside the
+      // same 32-tile also goes to the front (transposed: the strictly upper triangle of the diagonal tile)
+      double* xd = Xd + (size_t)tc * 16 * 17;
 #pragma unroll
-    for (int o = 0; o < 2; ++o) {
-      if (!(o == 0 ? own0 : own1)) continue;
-      const int r = (o == 0) ? r0 : r1;
+      for (int q = 0; q < 4; ++q) {
+        const int i = 4 * q + lk, c = li;
+        xd[i * 17 + c] = E[q];
+        if (i > c && jb + i < fw) A[(c0 + jb + c) + (i64)(c0 + jb + i) * n] = E[q];
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+    BST_ADD(2)
+    lds_bar();
+    BST_ADD(3)
+    if (own && !diag) {
+      // ---- O: a tile below the diagonal tile: L_tile[row][col] = sum_k A[row][k] (L_dd^-1)[col][k] ----
+      const double* xd = Xd + (size_t)tc * 16 * 17 + li * 17 + lk;
+      v4d nt = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) nt = __builtin_amdgcn_mfma_f64_16x16x4f64(xd[4 * s], pt[s], nt, 0, 0, 0);
+      pt = nt;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Lc[r][4 * q + lk] = pt[q];
+    }
+    BST_ADD(4)
+    // the finished tile: L inside a diagonal 32-tile goes to the square (and to LDS for the inverse), the rest to the
+    // L-panel area
+    if (own) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int cc = jb + 4 * q + lk;
         if (r >= fw || cc >= fw || r < cc) continue;
         const bool same = (r >> 5) == (cc >> 5);
-        const double v = (o == 0) ? pt0[q] : pt1[q];
-        (same ? A : X)[(c0 + r) + (i64)(c0 + cc) * n] = v;
-        if (same) tiles[((r >> 5) * T + (r & 31)) * (T + 1) + (cc & 31)] = v;
+        (same ? A : X)[(c0 + r) + (i64)(c0 + cc) * n] = pt[q];
+        if (same) tiles[((r >> 5) * T + (r & 31)) * (T + 1) + (cc & 31)] = pt[q];
       }
     }
+    BST_ADD(5)
+    lds_bar();
     BST_ADD(6)
+    // ---- U: rank-16 update of every tile right of the column: D[col][row] -= sum_k L[col][k] L[row][k] ----
+#pragma unroll
+    for (int k = 0; k < MAXS; ++k) {
+      const double* pa = &Lc[16 * tj[k] + li][lk];
+      const double* pb = &Lc[16 * ti[k] + li][lk];
+      const double a0 = pa[0], a1 = pa[4], a2 = pa[8], a3 = pa[12];
+      const double b0 = pb[0], b1 = pb[4], b2 = pb[8], b3 = pb[12];
+      if (k >= s0) {
+        acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0, b0, acc[k], 0, 0, 0);
+        acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, b1, acc[k], 0, 0, 0);
+        acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a2, b2, acc[k], 0, 0, 0);
+        acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a3, b3, acc[k], 0, 0, 0);
+      }
+    }
+    BST_ADD(7)
   }
   if (fail) sfail = 1;
   lds_bar();
 
-  // ---- (L^-1)' of every diagonal 32-tile into its strictly upper triangle, 1 / L_cc into the L-panel area --------------
+  // ---- (L^-1)' of every diagonal 32-tile into its strictly upper triangle (its two 16 x 16 diagonal blocks are in place:
+  //      D), 1 / L_cc into the L-panel area ----
   for (int c = tid; c < fw; c += NW * 64) X[(c0 + c) + (i64)(c0 + c) * n] = dinv[c];
-  // 1. the 16 x 16 diagonal blocks: thread (b, c) solves L_bb x = e_c right-looking (the partial sums of all later rows
-  //    advance together: independent FMAs)
-  if (tid < 16 * nt16) {
-    const int b = tid >> 4, c = tid & 15;
-    const int w16 = min(16, fw - 16 * b);
-    const double* Lt = tiles + ((size_t)(b >> 1) * T + (b & 1) * 16) * (T + 1) + (b & 1) * 16;
-    double* xd = Xd + (size_t)b * 16 * 17;
-    double sum[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) sum[i] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const double di = (k < w16) ? dinv[16 * b + k] : 0.0;
-      const double xk = (k == c) ? di : ((k > c) ? -sum[k] * di : 0.0);
-      xd[k * 17 + c] = xk;
-      if (k > c && k < w16) A[(c0 + 16 * b + c) + (i64)(c0 + 16 * b + k) * n] = xk;
-#pragma unroll
-      for (int i = k + 1; i < 16; ++i) sum[i] = fma((i < w16) ? Lt[i * (T + 1) + k] : 0.0, xk, sum[i]);
-    }
-  }
-  lds_bar();
-  // 2. the off-diagonal block of a 32-tile: X10 = -X11 (L10 X00), one wave per tile, two products of four matrix-core
+  // the off-diagonal block of a 32-tile: X10 = -X11 (L10 X00), one wave per tile, two products of four matrix-core
   //    instructions; the first product's accumulator IS the second one's operand (same lane layout)
   for (int kb = wv; kb < nt32; kb += NW) {
     if (fw - kb * T <= 16) continue;  // a single 16-block
@@ -303,7 +280,7 @@ __global__ void __launch_bounds__(NW * 64) big_diag_kernel(const BigDesc* descs,
       if (i < w1) A[(c0 + kb * T + li) + (i64)(c0 + kb * T + 16 + i) * n] = t2[q];
     }
   }
-  BST_ADD(7)
+  BST_ADD(8)
   if (tid == 0) {
     int bad = sfail;
     if (c0 + fw == F) {  // conditioning test on the last two pivots (cholesky.cpp:145-158)
@@ -335,67 +312,120 @@ struct Quad {
 };
 
 // ---- B. rows of L21 (and the rhs row): X_i = A_i L11^-T, 32 rows per workgroup --------------------------------------
-//   for k = 0 .. : T = A_ik - sum_{p<k} X_ip L_kp';  X_ik = T (L_kk^-1)'      (tile inverse left by big_diag)
+// Right-looking along the row block:  X_ik = T_k (L_kk^-1)'  then  T_k' -= X_ik L_k'k'  for every k' > k.
+// The 32 x 32 tiles T_k of the row block stay in matrix-core accumulators; the tiles of L11's column block k (the
+// diagonal tile's inverse left by big_diag and the L tiles below it) are staged through LDS, double-buffered: the
+// loads of column block k+1 are in flight during step k.  The dependent chain of a step is LDS -> 8 products -> LDS ->
+// 8 products; nothing on it touches global memory.
+static_assert(kMaxChunk / T == 6, "launch_big_rows dispatches on 1..6 column steps");
+constexpr int TS = T * (T + 2);       // an LDS tile: row stride 34 doubles (operand reads conflict-free)
+
+// NK = 32-column steps of the widest chunk of the launch group (a narrower chunk runs its missing steps on tiles of
+// zeros: no run-time guards, the whole kernel is straight-line code over register arrays)
+template <int NK>
 __global__ void __launch_bounds__(256) big_rows_kernel(const BigDesc* descs, int c0, int chunk, double* arena) {
   extern __shared__ double dyn[];
   const BigDesc d = descs[blockIdx.y];
   const int n = d.N, F = d.F;
   if (c0 >= F) return;
   const int fw = min(chunk, F - c0), base = c0 + fw;
-  const int ri = base + T * blockIdx.x;
-  if (ri >= n) return;
-  const int hi = min(T, n - ri);
-  const int nk = (fw + T - 1) / T;
-  const int ldx = T * nk + 2;           // row stride = 2 mod 32 doubles: the operand reads below are conflict-free
-  double* Xrow = dyn;                   // [32][ldx]: the solved row block so far
-  double(*Tt)[T + 2] = (double(*)[T + 2])(dyn + (size_t)T * ldx);
+  const int nrb = (n - base + T - 1) / T;
+  if ((int)blockIdx.x >= nrb) return;
+  constexpr int nk = NK;
+  double* Lb = dyn;                                   // [2][nk] tiles: column block k = inverse of L_kk, then L_k'k, k' > k
+  double(*Tt)[T + 2] = (double(*)[T + 2])(dyn + (size_t)2 * nk * TS);
+  double(*Xt)[T + 2] = (double(*)[T + 2])(dyn + (size_t)(2 * nk + 1) * TS);
   double* A = arena + d.off;
   double* X = arena + d.xoff;
   const Quad L;
-  const int row = L.r0 + L.li;
-  for (int k = 0; k < nk; ++k) {
-    const int wk = min(T, fw - k * T), ck = c0 + k * T;
-    v4d acc;
+  const int tid = threadIdx.x, row = L.r0 + L.li;
+  // element e = tid + 256 q of a tile as (lo = e & 31, hi = e >> 5): the fast index of the global read
+  const int elo = tid & 31, ehi = tid >> 5;
+
+  // column block kc of L11 into registers (4 doubles a thread per tile) / from registers into LDS buffer kc & 1
+  double stg[NK][4];
+  auto fetch = [&](int kc) {
+    const int ck = c0 + kc * T, wk = min(T, fw - kc * T);  // (wk <= 0 beyond a narrower chunk: tiles of zeros)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = L.cq0 + 4 * q + L.lk;
-      acc[q] = (row < hi && c < wk) ? A[(ri + row) + (i64)(ck + c) * n] : 0.0;
+    for (int q = 0; q < 4; ++q) {  // tile 0: (L_kk^-1)[c][kk], kk <= c — strictly upper triangle of the diagonal tile
+      const int kk = elo, c = ehi + 8 * q;  //   (transposed), 1 / L_cc on the L-panel area's diagonal
+      double v = 0.0;
+      if (c < wk && kk < c) v = A[(ck + kk) + (i64)(ck + c) * n];
+      else if (c < wk && kk == c) v = X[(ck + c) + (i64)(ck + c) * n];
+      stg[0][q] = v;
     }
-    const int lrow = k * T + L.cq0 + L.li;  // row of L11 this lane feeds (inside the chunk)
-    for (int p = 0; p < k; ++p) {
-      const double* Lkp = X + (c0 + lrow) + (i64)(c0 + p * T) * n;
-      const double* xr = Xrow + (size_t)row * ldx + p * T;
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const double a = (lrow < fw) ? Lkp[(i64)(4 * s + L.lk) * n] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a, xr[4 * s + L.lk], acc, 0, 0, 0);
+    for (int t = 1; t < NK; ++t) {  // tile t: L[rows of 32-block kc + t][columns of block kc]
+      if (kc + t < nk) {
+        const int rr = (kc + t) * T;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = elo, kk = ehi + 8 * q;
+          stg[t][q] = (rr + c < fw && kk < wk) ? X[(c0 + rr + c) + (i64)(ck + kk) * n] : 0.0;
+        }
       }
     }
+  };
+  auto stash = [&](int kc) {
+    double* buf = Lb + (size_t)(kc & 1) * nk * TS;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) Tt[row][L.cq0 + 4 * q + L.lk] = acc[q];
-    // (L_kk^-1)[c][kk], kk <= c: strictly upper triangle of the diagonal tile (transposed), 1 / L_cc in the L-panel area
-    const int c = L.cq0 + L.li;
-    double av[8];
+    for (int q = 0; q < 4; ++q) buf[(ehi + 8 * q) * (T + 2) + elo] = stg[0][q];  // [c][kk]
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int kk = 4 * s + L.lk;
-      av[s] = 0.0;
-      if (c < wk && kk < c) av[s] = A[(ck + kk) + (i64)(ck + c) * n];
-      else if (c < wk && kk == c) av[s] = X[(ck + c) + (i64)(ck + c) * n];
+    for (int t = 1; t < NK; ++t) {
+      if (kc + t < nk) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) buf[(size_t)t * TS + elo * (T + 2) + ehi + 8 * q] = stg[t][q];  // [c][kk]
+      }
     }
-    lds_bar();
-    v4d x = {0.0, 0.0, 0.0, 0.0};
+  };
+
+  for (int rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+    const int ri = base + T * rb, hi = min(T, n - ri);
+    fetch(0);
+    v4d tk[NK];
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
-      if (s < 4 || L.cq0 != 0)  // columns of the first half only need kk < 16 (wave-uniform)
-        x = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], Tt[row][4 * s + L.lk], x, 0, 0, 0);
+    for (int k = 0; k < NK; ++k) {
+      const int wk = min(T, fw - k * T);  // (<= 0 beyond the chunk: a tile of zeros)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int cc = L.cq0 + 4 * q + L.lk;
-      Xrow[(size_t)row * ldx + k * T + cc] = x[q];
-      if (row < hi && cc < wk) X[(ri + row) + (i64)(ck + cc) * n] = x[q];
+      for (int q = 0; q < 4; ++q) {
+        const int c = L.cq0 + 4 * q + L.lk;
+        tk[k][q] = (row < hi && c < wk) ? A[(ri + row) + (i64)(c0 + k * T + c) * n] : 0.0;
+      }
     }
-    lds_bar();
+    lds_bar();  // (a previous row block's reads of the buffers are done)
+    stash(0);
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int wk = min(T, fw - k * T);
+      const double* buf = Lb + (size_t)(k & 1) * nk * TS;
+      if (k + 1 < nk) fetch(k + 1);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Tt[row][L.cq0 + 4 * q + L.lk] = tk[k][q];
+      lds_bar();
+      // X[r][c] = sum_{kk <= c} T[r][kk] Linv[c][kk]: columns of the first half only need kk < 16 (wave-uniform)
+      v4d x = {0.0, 0.0, 0.0, 0.0};
+      {
+        const double* pa = buf + (L.cq0 + L.li) * (T + 2) + L.lk;
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+          if (s < 4 || L.cq0 != 0) x = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * s], Tt[row][4 * s + L.lk], x, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int cc = L.cq0 + 4 * q + L.lk;
+        Xt[row][cc] = x[q];
+        if (row < hi && cc < wk) X[(ri + row) + (i64)(c0 + k * T + cc) * n] = x[q];
+      }
+      lds_bar();
+#pragma unroll
+      for (int k2 = k + 1; k2 < NK; ++k2) {  // T_k2[r][c] -= sum_kk X[r][kk] L[32 k2 + c][32 k + kk]
+        const double* pa = buf + (size_t)(k2 - k) * TS + (L.cq0 + L.li) * (T + 2) + L.lk;
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+          tk[k2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * s], Xt[row][4 * s + L.lk], tk[k2], 0, 0, 0);
+      }
+      if (k + 1 < nk) stash(k + 1);
+    }
   }
 }
 
@@ -430,22 +460,18 @@ __global__ void __launch_bounds__(256) big_schur_kernel(const BigDesc* descs, in
   const double* pa = X + (rj + L.cq0 + L.li) + (i64)(c0 + L.lk) * n;
   const double* pb = X + (ri + row) + (i64)(c0 + L.lk) * n;
   v4d acc = {0.0, 0.0, 0.0, 0.0};
-  int kk = 0;
-  for (; kk + 32 <= fw; kk += 32) {  // eight k-steps with all sixteen loads in flight
-    double a[8], b[8];
+  // the operands of up to 64 columns (16 k-steps) are requested together: the kernel is one or two memory round trips
+  for (int kk = 0; kk < fw; kk += 64) {
+    double a[16], b[16];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      a[s] = ain ? pa[(i64)(kk + 4 * s) * n] : 0.0;
-      b[s] = bin ? pb[(i64)(kk + 4 * s) * n] : 0.0;
+    for (int s = 0; s < 16; ++s) {
+      const bool in = kk + 4 * s + L.lk < fw;
+      a[s] = (ain && in) ? pa[(i64)(kk + 4 * s) * n] : 0.0;
+      b[s] = (bin && in) ? pb[(i64)(kk + 4 * s) * n] : 0.0;
     }
 #pragma unroll
-    for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
-  }
-  for (; kk < fw; kk += 4) {
-    const bool in = kk + L.lk < fw;
-    const double a = (ain && in) ? pa[(i64)kk * n] : 0.0;
-    const double b = (bin && in) ? pb[(i64)kk * n] : 0.0;
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    for (int s = 0; s < 16; ++s)
+      if (kk + 4 * s < fw) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q)
@@ -459,8 +485,9 @@ void big_stamp_dump(const char* what) {
   unsigned long long h[16];
   hipDeviceSynchronize();
   hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bstamp), sizeof(h));
-  printf("[bstamp] %s: diag prologue %llu | column setup %llu | publish+bar1 %llu | phase2 %llu | bar2 %llu | updates %llu | "
-         "column store %llu | inverse %llu  (cycles, wave 0 of block 0)\n", what, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+  printf("[bstamp] %s: diag prologue %llu | column setup %llu | D %llu | bar1 %llu | O %llu | store %llu | bar2 %llu | U %llu | "
+         "inverse %llu  (cycles, wave 0 of block 0)\n", what, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8]);
+
   unsigned long long z[16] = {0};
   hipMemcpyToSymbol(HIP_SYMBOL(g_bstamp), z, sizeof(z));
 }
@@ -500,30 +527,47 @@ void launch_big_diag(const BigDesc* descs, int count, const BigPlan& plan, int r
   };
   const int kTilesLds = (int)lds_for(kMaxChunk);
   if (!attr) {
-    hipFuncSetAttribute((const void*)big_diag_kernel<8, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, kTilesLds);
-    hipFuncSetAttribute((const void*)big_diag_kernel<8, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kTilesLds);
+    hipFuncSetAttribute((const void*)big_diag_kernel<12, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kTilesLds);
+    hipFuncSetAttribute((const void*)big_diag_kernel<12, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, kTilesLds);
     attr = true;
   }
   const int c0 = round * plan.chunk, fw = plan.fw[round];
   const size_t lds = lds_for(fw);
   const int nt16 = (fw + 15) / 16;
-  // tiles: nt16 (nt16 + 1) / 2 over the waves; a column's tiles (<= nt16) over at most two slots of a wave
+  // tiles: nt16 (nt16 + 1) / 2 over the waves, at least as many waves as tile rows
   if (nt16 <= 4) big_diag_kernel<4, 3><<<count, 256, lds, st>>>(descs, c0, plan.chunk, arena, status);
   else if (nt16 <= 6) big_diag_kernel<8, 3><<<count, 512, lds, st>>>(descs, c0, plan.chunk, arena, status);
-  else if (nt16 <= 10) big_diag_kernel<8, 7><<<count, 512, lds, st>>>(descs, c0, plan.chunk, arena, status);
-  else big_diag_kernel<8, 10><<<count, 512, lds, st>>>(descs, c0, plan.chunk, arena, status);
+  else if (nt16 <= 8) big_diag_kernel<8, 5><<<count, 512, lds, st>>>(descs, c0, plan.chunk, arena, status);
+  else if (nt16 <= 10) big_diag_kernel<12, 5><<<count, 768, lds, st>>>(descs, c0, plan.chunk, arena, status);
+  else big_diag_kernel<12, 7><<<count, 768, lds, st>>>(descs, c0, plan.chunk, arena, status);
+}
+
+template <int NK>
+static void launch_rows_nk(const BigDesc* descs, int count, int gx, int c0, int chunk, double* arena, hipStream_t st) {
+  static bool attr = false;
+  constexpr size_t lds = (size_t)(2 * NK + 2) * TS * sizeof(double);
+  if (!attr) {
+    hipFuncSetAttribute((const void*)big_rows_kernel<NK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  big_rows_kernel<NK><<<dim3(gx, count), 256, lds, st>>>(descs, c0, chunk, arena);
 }
 
 void launch_big_rows(const BigDesc* descs, int count, const BigPlan& plan, int round, double* arena, hipStream_t st) {
   if (!count || plan.rb[round] <= 0) return;
-  static bool attr = false;
-  const auto lds_for = [](int fw) { return (size_t)(T * (T * ((fw + T - 1) / T) + 2) + T * (T + 2)) * sizeof(double); };
-  if (!attr) {
-    hipFuncSetAttribute((const void*)big_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_for(kMaxChunk));
-    attr = true;
+  // one workgroup per 32-row block; with many fronts in the group a workgroup takes several row blocks of its front in
+  // turn (the column blocks of L11 fill most of the LDS: about one workgroup per CU)
+  int gx = plan.rb[round];
+  if ((long)gx * count > 1024) gx = std::max(1, std::min(gx, 1024 / count));
+  const int c0 = round * plan.chunk;
+  switch ((plan.fw[round] + T - 1) / T) {
+    case 1: launch_rows_nk<1>(descs, count, gx, c0, plan.chunk, arena, st); break;
+    case 2: launch_rows_nk<2>(descs, count, gx, c0, plan.chunk, arena, st); break;
+    case 3: launch_rows_nk<3>(descs, count, gx, c0, plan.chunk, arena, st); break;
+    case 4: launch_rows_nk<4>(descs, count, gx, c0, plan.chunk, arena, st); break;
+    case 5: launch_rows_nk<5>(descs, count, gx, c0, plan.chunk, arena, st); break;
+    default: launch_rows_nk<6>(descs, count, gx, c0, plan.chunk, arena, st); break;
   }
-  big_rows_kernel<<<dim3(plan.rb[round], count), 256, lds_for(plan.fw[round]), st>>>(descs, round * plan.chunk, plan.chunk,
-                                                                                   arena);
 }
 
 void launch_big_schur(const BigDesc* descs, int count, const BigPlan& plan, int round, double* arena, hipStream_t st) {
