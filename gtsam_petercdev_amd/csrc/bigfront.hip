@@ -94,7 +94,7 @@ template <int NW, int MAXS>
 __global__ void __launch_bounds__(NW * 64) big_diag_kernel(const BigDesc* descs, int c0, int chunk, double* arena,
                                                            DevStatus* status) {
   constexpr int LS = 18;                 // row stride (doubles) of the L strips: operand reads hit 32 distinct bank pairs
-  __shared__ double Lc[kMaxChunk][LS];   // rows of L of the current tile column (16 columns), the tile rows below the diagonal tile
+  __shared__ double Lc[2][kMaxChunk][LS];  // rows of L of a tile column (16 columns, tile rows below the diagonal tile), columns alternate
   __shared__ double dinv[kMaxChunk];     // 1 / L_cc
   __shared__ double ldiag[kMaxChunk];    // L_cc
   __shared__ int sfail;
@@ -142,7 +142,20 @@ __global__ void __launch_bounds__(NW * 64) big_diag_kernel(const BigDesc* descs,
     }
   }
 
+  // rank-16 update of slot k from the strip of L
+#define GSX_UPD16(k, c)                                                           \
+  {                                                                               \
+    const double* pa = &Lc[(c)&1][16 * tj[k] + li][lk];                           \
+    const double* pb = &Lc[(c)&1][16 * ti[k] + li][lk];                           \
+    const double a0 = pa[0], a1 = pa[4], a2 = pa[8], a3 = pa[12];                 \
+    const double b0 = pb[0], b1 = pb[4], b2 = pb[8], b3 = pb[12];                 \
+    acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0, b0, acc[k], 0, 0, 0);      \
+    acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, b1, acc[k], 0, 0, 0);      \
+    acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a2, b2, acc[k], 0, 0, 0);      \
+    acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a3, b3, acc[k], 0, 0, 0);      \
+  }
   int fail = 0;
+  int defer_k = MAXS;  // first slot whose update by the PREVIOUS column is still to do (MAXS: none)
   BST_ADD(0)
   for (int tc = 0; tc < nt16; ++tc) {
     const int jb = 16 * tc;
@@ -154,6 +167,8 @@ __global__ void __launch_bounds__(NW * 64) big_diag_kernel(const BigDesc* descs,
     const bool diag = own && off == 0;
     const int slot = (start + off - wv) / NW;
     const int r = 16 * (tc + off) + li;  // this lane's row of the owned tile
+    // (the loop's back edge sits between the matrix-core updates and this read of their result: explicit wait states)
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
     v4d pt = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < MAXS; ++s)
@@ -163,37 +178,41 @@ __global__ void __launch_bounds__(NW * 64) big_diag_kernel(const BigDesc* descs,
 
     if (diag) {
       // ---- D: the diagonal tile, alone.  Other waves may still be in U of the previous column on this SIMD's matrix
-      //      core: this wave is the critical path of the whole front and issues first ----
+      //      core: this wave is the critical path of the whole front and issues first.  The loop is straight-line code:
+      //      a branch between a matrix-core instruction and the v_readlane of its result hides the dependency from the
+      //      compiler's hazard padding (measured: stale pivots) ----
       __builtin_amdgcn_s_setprio(3);
       v4d E;
 #pragma unroll
       for (int q = 0; q < 4; ++q) E[q] = (li == 4 * q + lk) ? 1.0 : 0.0;
-      double my_s = 0.0, my_l = 1.0;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int q = j >> 2, lkj = j & 3;
         __builtin_amdgcn_sched_barrier(0);  // keep the pivots apart: the chain is the schedule
+        int lj = li;
+        asm volatile("" : "+v"(lj));  // (the lane masks are two compares a pivot; hoisted out of the column loop they spill)
         const double dj = readlane_f64(pt[q], lkj * 16 + j);
-        if (!(dj > 0)) fail = 1;  // a non-positive pivot fails the front (Eigen::LLT NumericalIssue)
-        const double sj = rsqrt_refined(dj);
-        const bool colj = lk == lkj;  // the lanes that hold column j
-        const double xm = (colj && li >= j) ? pt[q] * sj : 0.0;  // L[li][j] (zero above the diagonal)
+        const double sj = rsqrt_refined(dj);  // (a non-positive pivot makes L_jj a NaN: caught when the column is stored)
+        const bool colj = lk == lkj;          // the lanes that hold column j
+        const double xj = pt[q] * sj;
+        const double xm = (colj && lj >= j) ? xj : 0.0;  // L[li][j] (zero above the diagonal)
         const double ej = colj ? E[q] * sj : 0.0;
         pt[q] = colj ? xm : pt[q];
         E[q] = colj ? ej : E[q];
-        if (lane == j) {
-          my_s = sj;
-          my_l = dj * sj;
-        }
         if (j < 15) {  // rank-1 update of the columns right of j: the column's lanes are the k = lkj operands, all others zero
-          const double xu = (li > j) ? xm : 0.0;
+          const double xu = (lj > j) ? xm : 0.0;
           pt = __builtin_amdgcn_mfma_f64_16x16x4f64(-xu, xu, pt, 0, 0, 0);
           E = __builtin_amdgcn_mfma_f64_16x16x4f64(-xu, ej, E, 0, 0, 0);
         }
       }
-      if (lane < 16) {
-        dinv[jb + lane] = my_s;
-        ldiag[jb + lane] = my_l;
+      __builtin_amdgcn_s_setprio(0);
+      // the diagonal of the tile: entry (li, li) sits in the lane with lk = li & 3, register li >> 2
+      if (lk == (li & 3)) {
+        const int qd = li >> 2;
+        const double l = (qd == 0) ? pt[0] : ((qd == 1) ? pt[1] : ((qd == 2) ? pt[2] : pt[3]));
+        ldiag[jb + li] = l;
+        dinv[jb + li] = 1.0 / l;
+        if (jb + li < fw && !(l > 0)) fail = 1;  // non-positive or non-finite pivot (Eigen::LLT NumericalIssue)
       }
       // E[row][col] = (L_dd^-1)[col][row]: published as Xd[tc][i][c] = (L_dd^-1)[i][c]; its strictly lower part inside the
       // same 32-tile also goes to the front (transposed: the strictly upper triangle of the diagonal tile)
@@ -204,11 +223,15 @@ __global__ void __launch_bounds__(NW * 64) big_diag_kernel(const BigDesc* descs,
         xd[i * 17 + c] = E[q];
         if (i > c && jb + i < fw) A[(c0 + jb + c) + (i64)(c0 + jb + i) * n] = E[q];
       }
-      __builtin_amdgcn_s_setprio(0);
     }
     BST_ADD(2)
     lds_bar();
     BST_ADD(3)
+    // the updates by the previous column that this wave put off to start its D early, beside the other waves' O
+#pragma unroll
+    for (int k = 0; k < MAXS; ++k)
+      if (k >= defer_k) GSX_UPD16(k, tc + 1)
+    defer_k = MAXS;
     if (own && !diag) {
       // ---- O: a tile below the diagonal tile: L_tile[row][col] = sum_k A[row][k] (L_dd^-1)[col][k] ----
       const double* xd = Xd + (size_t)tc * 16 * 17 + li * 17 + lk;
@@ -217,7 +240,7 @@ __global__ void __launch_bounds__(NW * 64) big_diag_kernel(const BigDesc* descs,
       for (int s = 0; s < 4; ++s) nt = __builtin_amdgcn_mfma_f64_16x16x4f64(xd[4 * s], pt[s], nt, 0, 0, 0);
       pt = nt;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) Lc[r][4 * q + lk] = pt[q];
+      for (int q = 0; q < 4; ++q) Lc[tc & 1][r][4 * q + lk] = pt[q];
     }
     BST_ADD(4)
     // the finished tile: L inside a diagonal 32-tile goes to the square (and to LDS for the inverse), the rest to the
@@ -235,22 +258,20 @@ __global__ void __launch_bounds__(NW * 64) big_diag_kernel(const BigDesc* descs,
     BST_ADD(5)
     lds_bar();
     BST_ADD(6)
-    // ---- U: rank-16 update of every tile right of the column: D[col][row] -= sum_k L[col][k] L[row][k] ----
+    // ---- U: rank-16 update of every tile right of the column: D[col][row] -= sum_k L[col][k] L[row][k].  The wave
+    //      that owns the next diagonal tile (its first unfinished slot) updates only that one now and the rest after its D ----
+    {
+      int offn = (wv - (start + nt16 - tc)) % NW;
+      offn += offn < 0 ? NW : 0;
+      const bool next_diag = tc + 1 < nt16 && offn == 0;
 #pragma unroll
-    for (int k = 0; k < MAXS; ++k) {
-      const double* pa = &Lc[16 * tj[k] + li][lk];
-      const double* pb = &Lc[16 * ti[k] + li][lk];
-      const double a0 = pa[0], a1 = pa[4], a2 = pa[8], a3 = pa[12];
-      const double b0 = pb[0], b1 = pb[4], b2 = pb[8], b3 = pb[12];
-      if (k >= s0) {
-        acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0, b0, acc[k], 0, 0, 0);
-        acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, b1, acc[k], 0, 0, 0);
-        acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a2, b2, acc[k], 0, 0, 0);
-        acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a3, b3, acc[k], 0, 0, 0);
-      }
+      for (int k = 0; k < MAXS; ++k)
+        if (k >= s0 && (!next_diag || k == s0)) GSX_UPD16(k, tc)
+      if (next_diag) defer_k = s0 + 1;
     }
     BST_ADD(7)
   }
+#undef GSX_UPD16
   if (fail) sfail = 1;
   lds_bar();
 
@@ -526,9 +547,12 @@ void launch_big_diag(const BigDesc* descs, int count, const BigPlan& plan, int r
     return (size_t)(((fw + T - 1) / T) * T * (T + 1) + ((fw + 15) / 16) * 16 * 17) * sizeof(double);
   };
   const int kTilesLds = (int)lds_for(kMaxChunk);
-  if (!attr) {
+  if (!attr) {  // (static + dynamic LDS exceeds the 64 KB default)
     hipFuncSetAttribute((const void*)big_diag_kernel<12, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kTilesLds);
     hipFuncSetAttribute((const void*)big_diag_kernel<12, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, kTilesLds);
+    hipFuncSetAttribute((const void*)big_diag_kernel<8, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, kTilesLds);
+    hipFuncSetAttribute((const void*)big_diag_kernel<8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kTilesLds);
+    hipFuncSetAttribute((const void*)big_diag_kernel<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kTilesLds);
     attr = true;
   }
   const int c0 = round * plan.chunk, fw = plan.fw[round];
