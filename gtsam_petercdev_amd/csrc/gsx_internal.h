@@ -103,6 +103,12 @@ struct Symbolic {
 // host algorithms
 gsx_status lower_problem(const gsx_problem_desc* d, HostProblem& P, std::string& err);
 void compute_ordering(const HostProblem& P, int kind, std::vector<int>& order);
+// multilevel nested dissection of the vertices `verts` of the graph `adj` (nd.cpp); sets of at most `leaf` vertices and
+// the separators are ordered by `leaf_order` (appends to `out`)
+typedef void (*NdLeafOrder)(const std::vector<std::vector<int>>& adj, const std::vector<int>& w,
+                            const std::vector<int>& verts, std::vector<int>& out);
+void multilevel_nested_dissection(const std::vector<std::vector<int>>& adj, const std::vector<int>& w,
+                                  const std::vector<int>& verts, int leaf, NdLeafOrder leaf_order, std::vector<int>& out);
 gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order, double relax, int relax_max_f,
                              int shard_rank, int shard_world, Symbolic& S, std::string& err);
 

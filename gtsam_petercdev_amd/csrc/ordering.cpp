@@ -5,7 +5,8 @@
 // gtsam/inference/Ordering.h:217-236, via CCOLAMD / METIS).  Neither CCOLAMD nor METIS is part
 // of this library; these are independent implementations of the same ideas:
 //   MINDEGREE  quotient-graph minimum degree with element absorption (approximate external degree)
-//   ND         nested dissection by BFS level-set separators, min-degree at the leaves
+//   ND         multilevel nested dissection (nd.cpp: heavy-edge coarsening, FM-refined bisection, minimum-vertex-cover
+//              separators), min-degree at the leaves and inside the separators
 //   SCHUR      3-D landmarks first, the rest (cameras) by MINDEGREE on the co-visibility graph
 //   SCHUR_ND   same, cameras by ND (the analogue of the reference's METIS choice for BAL)
 #include <algorithm>
@@ -109,114 +110,10 @@ static void min_degree(const Adj& adj, const std::vector<int>& w, const std::vec
   }
 }
 
-// Nested dissection on the vertex set `verts`.
-static void nested_dissection(const Adj& adj, const std::vector<int>& w, std::vector<int> verts,
-                              std::vector<int>& label, int& next_label, int leaf, std::vector<int>& out) {
-  if ((int)verts.size() <= leaf) {
-    min_degree(adj, w, verts, out);
-    return;
-  }
-  const int my = next_label++;
-  for (int v : verts) label[v] = my;
-  // connected components first
-  std::vector<int> comp_of;  // reuse label with negative marks: do BFS using a visited stamp
-  std::vector<int> bfs, lvl_start;
-  auto run_bfs = [&](int start, int want_label, std::vector<int>& order, std::vector<int>& lstart, int mark) {
-    order.clear();
-    lstart.clear();
-    order.push_back(start);
-    label[start] = mark;
-    size_t head = 0;
-    lstart.push_back(0);
-    while (head < order.size()) {
-      const size_t end = order.size();
-      for (; head < end; ++head)
-        for (int u : adj[order[head]])
-          if (label[u] == want_label) {
-            label[u] = mark;
-            order.push_back(u);
-          }
-      if (order.size() > end) lstart.push_back((int)end);
-    }
-    lstart.push_back((int)order.size());
-  };
-  // split into components
-  std::vector<std::vector<int>> comps;
-  {
-    const int mark = next_label++;
-    for (int v : verts) {
-      if (label[v] != my) continue;
-      std::vector<int> order, ls;
-      run_bfs(v, my, order, ls, mark);
-      comps.push_back(order);
-    }
-  }
-  if (comps.size() > 1) {
-    for (auto& c : comps) nested_dissection(adj, w, c, label, next_label, leaf, out);
-    return;
-  }
-  // single component: pseudo-peripheral start by two sweeps
-  const int l1 = next_label++;
-  for (int v : verts) label[v] = l1;
-  std::vector<int> order, ls;
-  const int m1 = next_label++;
-  run_bfs(verts[0], l1, order, ls, m1);
-  int far = order.back();
-  const int m2 = next_label++;
-  run_bfs(far, m1, order, ls, m2);
-  far = order.back();
-  const int m3 = next_label++;
-  run_bfs(far, m2, order, ls, m3);
-  const int nl = (int)ls.size() - 1;
-  if (nl < 3) {  // no usable level structure (dense blob)
-    min_degree(adj, w, verts, out);
-    return;
-  }
-  // choose the separator level: smallest level in the middle third (by cumulative count)
-  const int total = (int)order.size();
-  int best = -1;
-  int64_t best_size = INT64_MAX;
-  for (int l = 1; l < nl - 1; ++l) {
-    const int before = ls[l];
-    if (before < total / 3 || before > 2 * total / 3) continue;
-    int64_t sz = 0;
-    for (int k = ls[l]; k < ls[l + 1]; ++k) sz += w[order[k]];
-    if (sz < best_size) {
-      best_size = sz;
-      best = l;
-    }
-  }
-  if (best < 0) {
-    // fall back to the level containing the median
-    for (int l = 1; l < nl - 1; ++l)
-      if (ls[l + 1] > total / 2) {
-        best = l;
-        break;
-      }
-    if (best < 0) best = nl / 2;
-  }
-  std::vector<int> part1(order.begin(), order.begin() + ls[best]);
-  std::vector<int> sep, part2(order.begin() + ls[best + 1], order.end());
-  {
-    // thin the level-set separator: a vertex of the level without a neighbour in the next level does not
-    // separate anything and goes to part 1 (labels: every vertex of this component carries m3 now)
-    const int far_mark = next_label++;
-    for (int v : part2) label[v] = far_mark;
-    for (int k = ls[best]; k < ls[best + 1]; ++k) {
-      const int v = order[k];
-      bool touches = false;
-      for (int u : adj[v])
-        if (label[u] == far_mark) {
-          touches = true;
-          break;
-        }
-      (touches ? sep : part1).push_back(v);
-    }
-  }
-  nested_dissection(adj, w, part1, label, next_label, leaf, out);
-  nested_dissection(adj, w, part2, label, next_label, leaf, out);
-  // order the separator itself by minimum degree restricted to the separator
-  min_degree(adj, w, sep, out);
+// (GSX_ND_LEAF overrides the leaf size of the dissection: a tuning knob of the stand-alone harness)
+static int nd_leaf(int dflt) {
+  const char* e = std::getenv("GSX_ND_LEAF");
+  return e ? std::max(1, std::atoi(e)) : dflt;
 }
 
 void compute_ordering(const HostProblem& P, int kind, std::vector<int>& order) {
@@ -235,9 +132,7 @@ void compute_ordering(const HostProblem& P, int kind, std::vector<int>& order) {
     return;
   }
   if (kind == GSX_ORDER_ND) {
-    std::vector<int> label(P.n_vars, -1);
-    int next_label = 0;
-    nested_dissection(adj, P.dims, all, label, next_label, 48, order);
+    multilevel_nested_dissection(adj, P.dims, all, nd_leaf(24), min_degree, order);
     return;
   }
   // SCHUR: landmarks = VECTOR(3) variables all of whose neighbours are cameras
@@ -276,9 +171,7 @@ void compute_ordering(const HostProblem& P, int kind, std::vector<int>& order) {
     l.erase(std::unique(l.begin(), l.end()), l.end());
   }
   if (kind == GSX_ORDER_SCHUR_ND) {  // nested dissection of the reduced (camera) graph: shallower tree
-    std::vector<int> label(P.n_vars, -1);
-    int next_label = 0;
-    nested_dissection(red, P.dims, rest, label, next_label, 16, order);
+    multilevel_nested_dissection(red, P.dims, rest, nd_leaf(16), min_degree, order);
   } else {
     min_degree(red, P.dims, rest, order);
   }

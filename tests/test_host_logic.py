@@ -407,10 +407,209 @@ def test_host_code_under_address_sanitizer(golden_dir, tmp_path):
     exe = tmp_path / "host_sanitize"
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
            os.path.join(ROOT, "tests", "native", "host_sanitize.cpp")] + \
-          [os.path.join(src, f) for f in ("problem.cpp", "ordering.cpp", "symbolic.cpp", "io.cpp")] + ["-o", str(exe)]
+          [os.path.join(src, f) for f in ("problem.cpp", "ordering.cpp", "nd.cpp", "lm_policy.cpp", "symbolic.cpp", "io.cpp")] + ["-o", str(exe)]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     run = subprocess.run([str(exe), golden_dir, str(tmp_path)], capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0"))
     assert run.returncode == 0, (run.stdout[-1500:], run.stderr[-3000:])
     assert run.stdout.count(" ok") == 7
+
+
+# ---- the library's own nested dissection against the reference's CCOLAMD ------------------------------------
+def _tree_cost(be, dims):
+    """(factor flops sum f^3/3 + f^2 (s+1) + f (s+1)^2, height of the Bayes tree in cliques) of the handle's tree."""
+    parent, fronts = be.get_tree()
+    F = np.array([float(dims[fv].sum()) for fv, _ in fronts])
+    S1 = np.array([float(dims[sv].sum()) + 1.0 for _, sv in fronts])
+    children = [[] for _ in fronts]
+    roots = []
+    for i, p in enumerate(parent):
+        (children[p] if p >= 0 else roots).append(i)
+    depth, stack = 0, [(r, 1) for r in roots]
+    while stack:
+        i, d = stack.pop()
+        depth = max(depth, d)
+        stack.extend((c, d + 1) for c in children[i])
+    return float((F ** 3 / 3 + F * F * S1 + F * S1 * S1).sum()), depth
+
+
+ND_BOUNDS = {  # workload -> (max flops of ORDER_ND, max ratio to the reference's CCOLAMD flops, max tree height)
+    "pose3_100k": (1.5e9, 1.5, 40),
+    "pose2_100k": (3.0e8, 1.5, 40),
+    "bal1723": (2.6e9, 1.3, 24),
+}
+
+
+@pytest.mark.parametrize("workload", list(ND_BOUNDS))
+def test_nested_dissection_against_reference_colamd(lib, oracle, workload):
+    """ORDER_ND / ORDER_SCHUR_ND (csrc/nd.cpp: multilevel nested dissection) on the seeded full-size bench problems:
+    factor flops of the reference's cliques (no amalgamation) within a small factor of the reference's own CCOLAMD
+    ordering (compiled from its C sources, oracle/_ref), at a tree height an order of magnitude lower — the height is
+    what a level-scheduled GPU factorization pays for."""
+    import bench
+    arr, kind = bench.make_problem(workload, 42)
+    okind = {"schur_nd": A.ORDER_SCHUR_ND, "nd": A.ORDER_ND}[kind]
+    be = _lib.ProductBackend(arr, host_only=True)
+    be.set_amalgamation(0.0, 128)
+    be.set_ordering(be.compute_ordering(okind))
+    flops, depth = _tree_cost(be, arr.var_dims)
+    be.close()
+    max_flops, max_ratio, max_depth = ND_BOUNDS[workload]
+    line = f"{workload}: ORDER_{kind.upper()} flops {flops:.4g} height {depth}"
+    if oracle.have_ref_colamd():
+        ref = _lib.ProductBackend(arr, host_only=True)
+        ref.set_amalgamation(0.0, 128)
+        ref.set_ordering(oracle.colamd_ordering(arr))
+        rflops, rdepth = _tree_cost(ref, arr.var_dims)
+        ref.close()
+        line += f" | reference CCOLAMD flops {rflops:.4g} height {rdepth} | ratio {flops / rflops:.2f}"
+        assert flops <= max_ratio * rflops, line
+        assert depth * 4 <= rdepth, line
+    print(line)
+    assert flops <= max_flops and depth <= max_depth, line
+
+
+def test_nested_dissection_is_a_permutation_on_awkward_graphs(lib):
+    """Disconnected graphs, stars (matching stalls), a clique (no separator), a path, single vertices."""
+    rng = np.random.default_rng(5)
+    cases = []
+    # 3 disconnected Pose2 chains + isolated prior-only variables; a star; a clique; a long path
+    def graph(n, edges):
+        keys = np.arange(n, dtype=np.uint64)
+        arr = A.ProblemArrays(var_keys=keys, var_types=np.full(n, A.VAR_VECTOR, np.int32), var_dims=np.full(n, 2, np.int32),
+                              f_type=np.zeros(0, np.int32), f_rows=np.zeros(0, np.int32), f_key_ptr=np.zeros(1, np.int32),
+                              f_vars=np.zeros(0, np.int32), f_meas_ptr=np.zeros(1, np.int64), meas=np.zeros(0),
+                              f_noise_kind=np.zeros(0, np.int32), f_noise_ptr=np.zeros(1, np.int64), noise=np.zeros(0),
+                              values=np.zeros(2 * n), meta={})
+        for v in range(n):
+            arr = arr.with_factor(A.F_PRIOR, [v], 2, np.zeros(2), A.NOISE_UNIT)
+        for a, b in edges:
+            arr = arr.with_factor(A.F_BETWEEN, [a, b], 2, np.zeros(2), A.NOISE_UNIT)
+        return arr
+    cases.append(graph(400, [(i, i + 1) for i in range(399) if i % 100 != 99]))
+    cases.append(graph(300, [(0, i) for i in range(1, 300)]))
+    cases.append(graph(60, [(i, j) for i in range(60) for j in range(i + 1, 60)]))
+    cases.append(graph(1, []))
+    cases.append(graph(500, [(i, i + 1) for i in range(499)] + [(int(a), int(b)) for a, b in rng.integers(0, 500, (200, 2)) if a != b]))
+    for arr in cases:
+        be = _lib.ProductBackend(arr, host_only=True)
+        order = be.compute_ordering(A.ORDER_ND)
+        assert sorted(order.tolist()) == sorted(arr.var_keys.tolist())
+        be.set_ordering(order)
+        be.close()
+
+
+# ---- the Levenberg-Marquardt trust policy as a pure function (csrc/lm_policy.cpp) --------------------------------------------
+class _LmState(C.Structure):
+    _fields_ = [("lam", C.c_double), ("factor", C.c_double), ("cost", C.c_double), ("outer", C.c_int32), ("inner", C.c_int32)]
+
+
+class _LmDecision(C.Structure):
+    _fields_ = [("verdict", C.c_int32), ("solved", C.c_int32), ("gain_ratio", C.c_double), ("cost_change", C.c_double),
+                ("trial_cost", C.c_double), ("lambda_tried", C.c_double)]
+
+
+def _reference_try_lambda(p, lam, factor, error, solved, lin0, lind, trial):
+    """LevenbergMarquardtOptimizer::tryLambda + increaseLambda / decreaseLambda restated literally
+    (gtsam/nonlinear/LevenbergMarquardtOptimizer.cpp:141-270, internal/LevenbergMarquardtState.h:70-94): returns
+    (verdict, lambda, factor, error) with verdict 1 accepted / 0 retry / 2 stop searching / 3 lambda over its bound."""
+    step_ok, stop = False, False
+    fidelity, new_error, cost_change = 0.0, float("inf"), 0.0
+    if solved:
+        lin_change = lin0 - lind
+        if lin_change >= 0:
+            new_error = trial
+            cost_change = error - new_error
+            if lin_change > np.finfo(float).eps * lin0:
+                fidelity = cost_change / lin_change
+                step_ok = fidelity > p.min_model_fidelity
+            if abs(cost_change) < p.relative_error_tol * error:
+                stop = True
+    if step_ok:
+        if p.use_fixed_lambda_factor:
+            lam /= factor
+        else:
+            lam *= max(1.0 / 3.0, 1.0 - (2.0 * fidelity - 1.0) ** 3)
+            factor *= 2.0
+        return 1, max(p.lambda_lower_bound, lam), factor, new_error
+    if not stop:
+        lam *= factor
+        if not p.use_fixed_lambda_factor:
+            factor *= 2.0
+        return (3 if lam >= p.lambda_upper_bound else 0), lam, factor, error
+    return 2, lam, factor, error
+
+
+@pytest.mark.parametrize("preset", ["legacy", "ceres"])
+def test_lm_decide_equals_the_reference_policy(lib, preset):
+    lib.gsx_lm_decide.restype = C.c_int32
+    p = A.lm_params_legacy() if preset == "legacy" else A.lm_params_ceres()
+    rng = np.random.default_rng(11)
+    n_verdicts = [0, 0, 0, 0]
+    for _ in range(4000):
+        lam = 10.0 ** rng.uniform(-8, 6)
+        factor = float(rng.choice([2.0, 4.0, 10.0, 64.0]))
+        error = 10.0 ** rng.uniform(-3, 6)
+        solved = int(rng.random() > 0.1)
+        lin0 = error * (1 + 0.1 * rng.normal())
+        kind = rng.integers(0, 5)
+        lind = lin0 * {0: rng.uniform(0, 1), 1: 1 + 1e-3 * rng.random(), 2: 1.0, 3: 1 - 1e-17, 4: rng.uniform(0.9, 1)}[int(kind)]
+        trial = error * {0: rng.uniform(0, 1.5), 1: 1 - 1e-7 * rng.random(), 2: 1.0, 3: rng.uniform(0.5, 1), 4: 1 + 1e-9}[int(rng.integers(0, 5))]
+        st = _LmState(lam, factor, error, 3, 7)
+        d = _LmDecision()
+        assert lib.gsx_lm_decide(C.byref(p), C.byref(st), C.c_int32(solved), C.c_double(lin0), C.c_double(lind), C.c_double(trial),
+                                 C.byref(d)) == 0
+        v, l2, f2, e2 = _reference_try_lambda(p, lam, factor, error, solved, lin0, lind, trial)
+        assert d.verdict == v
+        assert st.lam == pytest.approx(l2, rel=1e-15) and st.factor == f2 and st.cost == e2
+        assert st.outer == 3 + (v == 1) and st.inner == 7 + (v in (0, 1, 3))
+        n_verdicts[v] += 1
+    assert min(n_verdicts[:3]) > 20, n_verdicts   # every branch was exercised
+
+
+def test_lm_decide_reproduces_the_oracle_trace(lib, oracle):
+    """Drive an LM run with the ORACLE's numerics and the PRODUCT's decision function: the accept / reject trace and the
+    lambdas must be the ones the oracle's own optimizer (a restatement of the reference's) produces."""
+    lib.gsx_lm_decide.restype = C.c_int32
+    arr = datasets.synth_manhattan_pose2(120, seed=9)
+    ordering = _lib.ProductBackend(arr, host_only=True).compute_ordering(A.ORDER_MINDEGREE)
+    for p in (A.lm_params_legacy(), A.lm_params_ceres()):
+        p.max_iterations = 12
+        ref = oracle.oracle_backend(arr)
+        ref.set_ordering(ordering)
+        expect = ref.lm_optimize(p)
+        ob = oracle.oracle_backend(arr)
+        ob.set_ordering(ordering)
+        st = _LmState(p.lambda_initial, p.lambda_factor, ob.error(), 0, 0)
+        trace = []
+        while st.outer < p.max_iterations:
+            before = st.cost
+            ob.linearize()
+            while True:
+                lam = st.lam
+                solved = True
+                try:
+                    ob.solve(lam, bool(p.diagonal_damping), p.min_diagonal, p.max_diagonal, want_delta=False)
+                    lin0, lind = ob.linear_error()
+                    trial = ob.retract(None, commit=False)
+                except A.IndeterminantLinearSystemException:
+                    solved, lin0, lind, trial = False, 0.0, 0.0, 0.0
+                d = _LmDecision()
+                lib.gsx_lm_decide(C.byref(p), C.byref(st), C.c_int32(int(solved)), C.c_double(lin0), C.c_double(lind),
+                                  C.c_double(trial), C.byref(d))
+                trace.append((d.trial_cost, lam, 1 if d.verdict == 1 else (0 if solved else -1)))
+                if d.verdict == 1:
+                    ob.retract(None, commit=True, want_error=False)
+                if d.verdict != 0:
+                    break
+            if d.verdict == 3 or st.cost <= p.error_tol:
+                break
+            dec = before - st.cost
+            if (p.relative_error_tol and dec / before <= p.relative_error_tol) or dec <= p.absolute_error_tol:
+                break
+        n = len(expect["trace_accepted"])
+        assert n >= 3 and len(trace) == n, (len(trace), n)
+        assert [t[2] for t in trace] == list(expect["trace_accepted"][:n])
+        assert np.allclose([t[1] for t in trace], expect["trace_lambda"][:n], rtol=1e-12)
+        assert np.allclose([t[0] for t in trace], expect["trace_error"][:n], rtol=1e-9)
