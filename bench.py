@@ -40,8 +40,8 @@ def parse():
     ap.add_argument("--ordering", default=None, choices=[None, "schur", "schur_nd", "mindegree", "nd"])
     ap.add_argument("--lam", type=float, default=1e-5)
     ap.add_argument("--amalgamation", default=None, metavar="RELAX,MAXF",
-                    help="relaxed clique amalgamation (gsx_set_amalgamation); default: tuned per workload, 0 = the "
-                         "reference's cliques")
+                    help="relaxed clique amalgamation (gsx_set_amalgamation); default: the library's own choice "
+                         "(GSX_AMALGAMATION_AUTO, what a drop-in caller gets), 0,128 = the reference's cliques")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -60,10 +60,6 @@ def parse():
                          "\"shard_run\" — the strong-scaling number next to the weak-scaling headline; 'none' to skip")
     ap.add_argument("--shard-extra-timeout", type=float, default=240.0)
     return ap.parse_args()
-
-
-# relaxed amalgamation per workload (relax, max merged frontal dim), from tools/sweep_amalgamation.sh on MI355X
-AMALGAMATION = {"bal1723": (0.25, 128), "bal49": (0.25, 128), "pose3_100k": (0.5, 80), "pose2_100k": (0.5, 64)}
 
 
 def make_problem(name, seed):
@@ -217,14 +213,14 @@ def main():
     t0 = time.time()
     ordering = be.compute_ordering(okind)
     t_order = time.time() - t0
-    relax, relax_maxf = AMALGAMATION[args.workload]
-    if args.amalgamation is not None:
+    if args.amalgamation is not None:   # (a new handle's default is the library's own choice)
         a, b = args.amalgamation.split(",")
-        relax, relax_maxf = float(a), int(b)
-    be.set_amalgamation(relax, relax_maxf)
+        be.set_amalgamation(float(a), int(b))
     t0 = time.time()
     be.set_ordering(ordering)
     t_symbolic = time.time() - t0
+    st0 = be.stats()
+    relax, relax_maxf = st0["amalgamation_relax"], int(st0["amalgamation_max_frontal_dim"])
     lam = args.lam
 
     def step():
@@ -333,7 +329,8 @@ def main():
         "scaling": "strong" if (sharded and world > 1) else "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": args.workload, "shape": arrays.meta, "ordering": args.ordering or default_order,
-                   "amalgamation": {"relax": relax, "max_frontal_dim": relax_maxf}, "lambda": lam,
+                   "amalgamation": {"relax": relax, "max_frontal_dim": relax_maxf,
+                                    "chosen_by": "caller" if args.amalgamation is not None else "library"}, "lambda": lam,
                    "replicas": 1 if sharded else world,
                    "parallelism": (f"shard{world}" if world > 1 else f"rank 0 of shard{args.shard_share}, exchange "
                                    "stubbed") if sharded else f"replicas{world}"},

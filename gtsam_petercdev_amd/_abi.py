@@ -33,6 +33,9 @@ _STATUS_NAMES = {
 }
 
 
+AMALGAMATION_AUTO = -1.0   # gsx_set_amalgamation: the library's own choice (the default of a new handle)
+
+
 class GsxError(RuntimeError):
     def __init__(self, status: int, what: str, detail: str = ""):
         self.status = status
@@ -92,6 +95,7 @@ class Stats(C.Structure):
                                      "ms_linearize", "ms_assemble_hessian", "ms_factorize", "ms_backsolve",
                                      "ms_linear_error", "ms_retract", "ms_error")]
         + [(n, C.c_int64) for n in ("n_linearize", "n_factorize", "n_backsolve", "n_error", "n_cheirality")]
+        + [("amalgamation_relax", C.c_double), ("amalgamation_max_frontal_dim", C.c_int64)]
     )
 
     def as_dict(self):

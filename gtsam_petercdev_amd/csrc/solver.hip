@@ -95,7 +95,7 @@ struct gsx_context {
   HostProblem P;
   Symbolic S;
   bool has_symbolic = false;
-  double relax = 0.0;      // relaxed amalgamation (gsx_set_amalgamation); 0 = the reference's cliques
+  double relax = GSX_AMALGAMATION_AUTO;  // relaxed amalgamation (gsx_set_amalgamation); 0 = the reference's cliques, < 0 = the library's choice
   int relax_max_f = 128;
   std::vector<int> order;
 
@@ -1207,7 +1207,7 @@ gsx_status gsx_compute_ordering(gsx_handle h, int32_t kind, uint64_t* keys_out) 
 }
 
 gsx_status gsx_set_amalgamation(gsx_handle h, double relax, int32_t max_frontal_dim) {
-  if (!h || !(relax >= 0.0) || max_frontal_dim < 1) return GSX_E_INVALID;
+  if (!h || relax != relax || (relax >= 0.0 && max_frontal_dim < 1)) return GSX_E_INVALID;
   h->relax = relax;
   h->relax_max_f = max_frontal_dim;
   return GSX_OK;
@@ -2237,6 +2237,8 @@ gsx_status gsx_get_stats(gsx_handle h, gsx_stats* out) {
   out->n_backsolve = h->timers[PH_BACKSOLVE].count;
   out->n_error = h->timers[PH_ERROR].count;
   out->n_cheirality = h->n_cheirality;
+  out->amalgamation_relax = h->S.relax;
+  out->amalgamation_max_frontal_dim = h->S.relax_max_f;
   return GSX_OK;
 }
 

@@ -118,39 +118,106 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
   // merged[j] = true when node j was merged into its etree parent's cluster.
   std::vector<char> merged(n, 0);
   std::vector<int> nfront_of(n, 1);  // frontal variable count of the cluster topped by node j
-  // relaxed amalgamation (S.relax > 0; off = the reference's Bayes tree exactly): a child cluster is also merged
-  // when the explicit zeros this adds to its columns are at most S.relax x its own L panel and the merged
+  // relaxed amalgamation (relax > 0; off = the reference's Bayes tree exactly): a child cluster is also merged
+  // when the explicit zeros this adds to its columns are at most relax x its own L panel and the merged
   // frontal dimension stays moderate.  Fewer, larger cliques => fewer levels / kernel launches on the
   // latency-bound chains; the solution is unchanged (zeros are factored as zeros).
   std::vector<int64_t> fdim_of(n, 0), sdim_of(n, 0);  // scalar frontal / separator dims of the cluster topped by j
   std::vector<int> ref_nfront_of(n, 1);
-  for (int j = 0; j < n; ++j) {
-    const size_t myNrParents = st[j].size();
-    size_t myNrFrontals = 1;     // all frontal variables gathered so far
-    size_t refNrFrontals = 1;    // ... counting only the reference's merges (its rule is evaluated on its own count,
-                                 //     so that every reference clique survives whole inside a relaxed one)
-    int64_t sp = 0;
-    for (int pj : st[j]) sp += P.dims[order[pj]];
-    int64_t fp = P.dims[order[j]];
-    for (int c = ech_ptr[j]; c < ech_ptr[j + 1]; ++c) {
-      const int ch = ech[c];
-      bool take = myNrParents + refNrFrontals == st[ch].size();
-      if (take) refNrFrontals += ref_nfront_of[ch];
-      if (!take && S.relax > 0) {
-        const int64_t fc = fdim_of[ch], sc = sdim_of[ch];
-        const int64_t extra = fc * (fp + sp - sc);
-        take = (double)extra <= S.relax * (double)(fc * (fc + sc + 1)) && fc + fp <= S.relax_max_f;
+  std::vector<int64_t> sdim_node(n, 0);
+  for (int j = 0; j < n; ++j)
+    for (int pj : st[j]) sdim_node[j] += P.dims[order[pj]];
+  auto merge_pass = [&](double rx, int max_f) {
+    for (int j = 0; j < n; ++j) {
+      const size_t myNrParents = st[j].size();
+      size_t myNrFrontals = 1;     // all frontal variables gathered so far
+      size_t refNrFrontals = 1;    // ... counting only the reference's merges (its rule is evaluated on its own count,
+                                   //     so that every reference clique survives whole inside a relaxed one)
+      const int64_t sp = sdim_node[j];
+      int64_t fp = P.dims[order[j]];
+      for (int c = ech_ptr[j]; c < ech_ptr[j + 1]; ++c) {
+        const int ch = ech[c];
+        bool take = myNrParents + refNrFrontals == st[ch].size();
+        if (take) refNrFrontals += ref_nfront_of[ch];
+        if (!take && rx > 0) {
+          const int64_t fc = fdim_of[ch], sc = sdim_of[ch];
+          const int64_t extra = fc * (fp + sp - sc);
+          take = (double)extra <= rx * (double)(fc * (fc + sc + 1)) && fc + fp <= max_f;
+        }
+        merged[ch] = take;
+        if (take) {
+          myNrFrontals += nfront_of[ch];
+          fp += fdim_of[ch];
+        }
       }
-      if (take) {
-        myNrFrontals += nfront_of[ch];
-        fp += fdim_of[ch];
-        merged[ch] = 1;
-      }
+      nfront_of[j] = (int)myNrFrontals;
+      ref_nfront_of[j] = (int)refNrFrontals;
+      fdim_of[j] = fp;
+      sdim_of[j] = sp;
     }
-    nfront_of[j] = (int)myNrFrontals;
-    ref_nfront_of[j] = (int)refNrFrontals;
-    fdim_of[j] = fp;
-    sdim_of[j] = sp;
+  };
+  if (relax >= 0) {
+    merge_pass(relax, relax_max_f);
+  } else {
+    // ---- the library's own choice (gsx_set_amalgamation(h, GSX_AMALGAMATION_AUTO, .)) ------------------------------
+    // The factorization is a level schedule: every level of the clique tree costs its kernel launches and the
+    // sequential pivot chain of its largest front, while the arithmetic itself runs far below the matrix cores' rate —
+    // so a tree is priced by its levels and chains first and by its (padded) flops last.  Constants in microseconds,
+    // measured on MI355X (profiles/r02_*, tools/bigfront_bench.hip): a level with blocked fronts = gather + three
+    // launches (~35) + 0.33 per pivot of its widest chunk chain + its flops at ~10 TFLOP/s; a level with LDS fronts
+    // ~25 + 1.0 per pivot of its largest front + flops at ~2 TFLOP/s; the back-substitution ~25 per level.
+    double best_cost = 0;
+    double best_rx = 0;
+    int best_mf = 128;
+    bool first = true;
+    std::vector<int> lvl(n), bigF, smallF;
+    std::vector<double> bigFl, smallFl;
+    const double cand_rx[] = {0.0, 0.125, 0.25, 0.5, 1.0, 2.0};
+    const int cand_mf[] = {32, 64, 96, 128, 160};
+    for (double rx : cand_rx)
+      for (int mf : cand_mf) {
+        if (rx == 0.0 && mf != cand_mf[0]) continue;
+        merge_pass(rx, mf);
+        bigF.clear(), smallF.clear(), bigFl.clear(), smallFl.clear();
+        std::fill(lvl.begin(), lvl.end(), 0);
+        int nl = 0;
+        for (int j = 0; j < n; ++j) {  // children before parents: lvl[j] of a cluster top is final when j is reached
+          if (merged[j]) {             // a merged node hands its children's levels to the cluster's top
+            if (eparent[j] >= 0) lvl[eparent[j]] = std::max(lvl[eparent[j]], lvl[j]);
+            continue;
+          }
+          const int l = lvl[j];
+          if (l >= nl) {
+            nl = l + 1;
+            bigF.resize(nl, 0), smallF.resize(nl, 0), bigFl.resize(nl, 0.0), smallFl.resize(nl, 0.0);
+          }
+          const double F = (double)fdim_of[j], s1 = (double)sdim_of[j] + 1.0;
+          const double fl = F * F * F / 3.0 + F * F * s1 + F * s1 * s1;
+          if (fdim_of[j] + sdim_of[j] + 1 > kSmallMaxN) {
+            bigF[l] = std::max(bigF[l], (int)fdim_of[j]);
+            bigFl[l] += fl;
+          } else if (ech_ptr[j + 1] > ech_ptr[j] || fdim_of[j] > kLeafMaxF) {  // (childless small cliques: the leaf kernel, one launch)
+            smallF[l] = std::max(smallF[l], (int)fdim_of[j]);
+            smallFl[l] += fl;
+          }
+          if (eparent[j] >= 0) lvl[eparent[j]] = std::max(lvl[eparent[j]], l + 1);
+        }
+        double cost = 0;
+        for (int l = 0; l < nl; ++l) {
+          cost += 25.0;
+          if (bigF[l]) cost += 35.0 + 0.33 * bigF[l] + bigFl[l] / 1e7;
+          if (smallF[l]) cost += 25.0 + 1.0 * smallF[l] + smallFl[l] / 2e6;
+        }
+        if (first || cost < best_cost) {
+          first = false;
+          best_cost = cost;
+          best_rx = rx;
+          best_mf = mf;
+        }
+      }
+    merge_pass(best_rx, best_mf);
+    S.relax = best_rx;
+    S.relax_max_f = best_mf;
   }
   // top node of the cluster containing each node
   std::vector<int> top(n);

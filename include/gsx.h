@@ -223,6 +223,8 @@ typedef struct gsx_stats {
       ms_linear_error, ms_retract, ms_error;
   int64_t n_linearize, n_factorize, n_backsolve, n_error;
   int64_t n_cheirality;          /* SFM factors zeroed by cheirality in the last linearize */
+  double amalgamation_relax;     /* the amalgamation in effect (the library's choice under GSX_AMALGAMATION_AUTO) */
+  int64_t amalgamation_max_frontal_dim;
 } gsx_stats;
 
 /* ---- on-disk formats (host only) -------------------------
@@ -281,12 +283,16 @@ int32_t gsx_device_count(void);                    /* 0 when no GPU is visible  
 /* ---- ordering / symbolic analysis (host only; works without a GPU) -------- */
 gsx_status gsx_set_ordering(gsx_handle h, const uint64_t* keys, int32_t n);
 gsx_status gsx_compute_ordering(gsx_handle h, int32_t kind, uint64_t* keys_out);
-/* Relaxed clique amalgamation, applied by the NEXT gsx_set_ordering.  relax = 0 (the default) builds exactly the
+/* Relaxed clique amalgamation, applied by the NEXT gsx_set_ordering.  relax = 0 builds exactly the
  * reference's Bayes tree: a child cluster is merged into its parent only when that adds no structural zero
  * (gtsam/inference/JunctionTree-inst.h:120-149).  relax > 0 also merges a child when the explicit zeros padded
  * into its columns are at most relax x its own conditional's size and the merged frontal dimension stays
  * <= max_frontal_dim: fewer, larger cliques, i.e. fewer levels and kernel launches on the latency-bound chains of
- * the elimination tree.  The solution is unchanged (zeros are factored as zeros); only gsx_get_tree differs. */
+ * the elimination tree.  The solution is unchanged (zeros are factored as zeros); only gsx_get_tree differs.
+ * relax = GSX_AMALGAMATION_AUTO (the default of a new handle; max_frontal_dim ignored): the symbolic analysis picks
+ * (relax, max_frontal_dim) itself from a cost model of the level schedule — levels, pivot chains, padded flops —
+ * and reports its choice in gsx_stats.  Every reference clique still survives whole inside one of the library's. */
+#define GSX_AMALGAMATION_AUTO (-1.0)
 gsx_status gsx_set_amalgamation(gsx_handle h, double relax, int32_t max_frontal_dim);
 /* ---- one problem over the GPUs of a node -------------------------------------------------------
  * The reference has no distributed solver; the seam is the same as everywhere else in this header — the handle

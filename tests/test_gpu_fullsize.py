@@ -41,6 +41,7 @@ def test_full_size_step_matches_oracle(gpu, oracle, name):
     build, kind = CASES[name]
     arr = build()
     gb = gpu.product_backend(arr)
+    gb.set_amalgamation(0.0, 128)   # the reference's cliques: the tree statistics are compared below
     ob = oracle.oracle_backend(arr)
     ordering = gb.compute_ordering(kind)
     gb.set_ordering(ordering)
@@ -67,25 +68,23 @@ def test_full_size_step_matches_oracle(gpu, oracle, name):
     assert abs(st["factor_flops"] - tree["flops"]) <= 1e-9 * tree["flops"]
 
 
-BENCH_CONFIGS = {
-    # the configurations bench.py measures: ordering + relaxed amalgamation (bench.py AMALGAMATION)
-    "bal1723": (CASES["bal1723"][0], A.ORDER_SCHUR_ND, 0.25, 128),
-    "pose3_100k": (CASES["pose3_100k"][0], A.ORDER_ND, 0.5, 64),
-    "pose2_100k": (lambda: datasets.synth_manhattan_pose2(100000, seed=42), A.ORDER_ND, 1.0, 64),
-}
+BENCH_WORKLOADS = ["bal1723", "pose3_100k", "pose2_100k"]
 
 
-@pytest.mark.parametrize("name", list(BENCH_CONFIGS))
+@pytest.mark.parametrize("name", BENCH_WORKLOADS)
 def test_bench_configuration_matches_oracle(gpu, oracle, name):
-    """The exact configuration bench.py times — own ordering AND relaxed clique amalgamation — against the oracle,
+    """The exact configuration bench.py times — the problem, seed and ordering kind come from bench.make_problem itself,
+    the clique amalgamation is the library's own choice (a new handle's default, as in bench.py) — against the oracle,
     which eliminates the reference's (un-amalgamated) Bayes tree for the same ordering."""
-    build, kind, relax, maxf = BENCH_CONFIGS[name]
-    arr = build()
+    import bench
+    arr, okind = bench.make_problem(name, 42)
+    kind = {"schur_nd": A.ORDER_SCHUR_ND, "nd": A.ORDER_ND}[okind]
     gb = gpu.product_backend(arr)
     ob = oracle.oracle_backend(arr)
     ordering = gb.compute_ordering(kind)
-    gb.set_amalgamation(relax, maxf)
     gb.set_ordering(ordering)
+    st = gb.stats()
+    assert st["amalgamation_relax"] > 0 and st["n_fronts"] > 0   # the library merged cliques on its own
     ob.set_ordering(ordering)
     gb.linearize()
     ob.linearize()
@@ -141,14 +140,14 @@ def test_full_size_properties(gpu, name):
 @pytest.mark.parametrize("name", ["bal1723", "pose3_100k"])
 def test_full_size_lm_run_matches_oracle(gpu, oracle, name):
     """north star: the LM run itself — same accept/reject decisions, same lambda schedule, final chi^2 within 1e-6 of the
-    reference algorithm — at BASELINE's full sizes, in the configuration bench.py times (relaxed amalgamation on the
-    device, the reference's cliques in the oracle)."""
-    build, kind, relax, maxf = BENCH_CONFIGS[name]
-    arr = build()
+    reference algorithm — at BASELINE's full sizes, in the configuration bench.py times (bench.make_problem, the library's
+    own amalgamation on the device, the reference's cliques in the oracle)."""
+    import bench
+    arr, okind = bench.make_problem(name, 42)
+    kind = {"schur_nd": A.ORDER_SCHUR_ND, "nd": A.ORDER_ND}[okind]
     gb = gpu.product_backend(arr)
     ob = oracle.oracle_backend(arr)
     ordering = gb.compute_ordering(kind)
-    gb.set_amalgamation(relax, maxf)
     gb.set_ordering(ordering)
     ob.set_ordering(ordering)
     p = A.lm_params_legacy()

@@ -127,6 +127,7 @@ PROBLEMS = dict(_problems())
 def test_step_parity(gpu, oracle, name):
     arr = PROBLEMS[name]
     gb = gpu.product_backend(arr)
+    gb.set_amalgamation(0.0, 128)   # the reference's cliques: the tree itself is compared below
     ob = oracle.oracle_backend(arr)
     # nonlinear error
     assert abs(gb.error() - ob.error()) <= 1e-11 * abs(ob.error())
@@ -252,6 +253,7 @@ def test_GaussianBayesTree_chain(gpu):
     arrays = chain_graph().to_arrays(None)
     arrays.values = np.zeros(4)
     be = gpu.product_backend(arrays)
+    be.set_amalgamation(0.0, 128)   # the reference's cliques
     be.set_ordering([2, 1, 3, 4])
     parent, fronts = be.get_tree()
     keys = arrays.var_keys.tolist()

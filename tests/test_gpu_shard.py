@@ -27,7 +27,7 @@ def test_partition_properties(kind, world):
         arr, okind = datasets.synth_bal_arrays(40, 2500, 11000, seed=2, long_range=0.3), A.ORDER_SCHUR_ND
     plain = _lib.ProductBackend(arr, host_only=True)
     ordering = plain.compute_ordering(okind)
-    plain.set_ordering(ordering)
+    plain.set_ordering(ordering)   # (every handle: the library's own amalgamation, the same choice on every rank)
     parent, fronts = plain.get_tree()
     owners, owned = [], []
     for rank in range(world):

@@ -69,6 +69,7 @@ def test_bayes_tree_identical_to_reference_construction(lib, oracle, name):
     for its own orderings and for the reference's CCOLAMD ordering."""
     arr = PROBLEMS[name]()
     pb = _lib.ProductBackend(arr, host_only=True)
+    pb.set_amalgamation(0.0, 128)   # the reference's cliques (a new handle's default is the library's own amalgamation)
     ob = oracle.oracle_backend(arr)
     orderings = [pb.compute_ordering(k) for k in (A.ORDER_NATURAL, A.ORDER_MINDEGREE, A.ORDER_ND, A.ORDER_SCHUR, A.ORDER_SCHUR_ND)]
     if oracle.have_ref_colamd():
@@ -89,7 +90,7 @@ def test_bayes_tree_identical_to_reference_construction(lib, oracle, name):
 
 
 @pytest.mark.parametrize("name", list(PROBLEMS))
-@pytest.mark.parametrize("relax,maxf", [(0.25, 128), (1.0, 64), (50.0, 4096)])
+@pytest.mark.parametrize("relax,maxf", [(0.25, 128), (1.0, 64), (50.0, 4096), (A.AMALGAMATION_AUTO, 0)])
 def test_relaxed_amalgamation_is_a_coarsening_of_the_reference_tree(lib, name, relax, maxf):
     """gsx_set_amalgamation(relax > 0): every clique is a union of CONNECTED reference cliques, its separator is the
     separator of its topmost member, the parent relation is the quotient of the reference tree; relax = 0 restores
@@ -97,6 +98,7 @@ def test_relaxed_amalgamation_is_a_coarsening_of_the_reference_tree(lib, name, r
     arr = PROBLEMS[name]()
     pb = _lib.ProductBackend(arr, host_only=True)
     ordering = pb.compute_ordering(A.ORDER_ND)
+    pb.set_amalgamation(0.0, 128)
     pb.set_ordering(ordering)
     ref_parent, ref_fronts = pb.get_tree()
     ref_flops = pb.stats()["factor_flops"]

@@ -1,11 +1,16 @@
 #!/bin/bash
-# Sweep of the relaxed-amalgamation settings (gsx_set_amalgamation) per workload on the GPU box:
-#   gpurun -- 'bash tools/sweep_amalgamation.sh > gpurun_out/sweep.log 2>&1'
-# Prints: relax max_frontal_dim workload ms/LM-iteration levels big-fronts GFLOP.  bench.py's AMALGAMATION table holds
-# the winners.
-run() {
-  timeout -k 10 200 python bench.py --workload $3 --amalgamation $1,$2 --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1 $2 $3', round(d['ms_per_step'],3), d['symbolic']['n_levels'], d['symbolic']['n_big_fronts'], round(d['symbolic']['factor_flops']/1e9,1))"
-}
-for cfg in "0 128" "0.5 64" "0.5 256" "0.75 128" "1.0 128" "1.0 64" "2.0 64"; do set -- $cfg; for w in pose3_100k pose2_100k; do run $1 $2 $w; done; done
-for cfg in "0 128" "0.15 128" "0.25 64" "0.25 96" "0.25 128" "0.2 128" "0.3 128"; do set -- $cfg; run $1 $2 bal1723; done
+# usage (on the GPU box, via gpurun): tools/sweep_amalgamation.sh <outfile> [workloads...]
+# ms per LM iteration for explicit (relax, max_frontal_dim) settings next to the library's own choice (no flag)
+out=$1; shift
+wl=${@:-"bal1723 pose3_100k pose2_100k"}
+: > $out
+for w in $wl; do
+  for a in auto 0,128 0.125,64 0.25,64 0.25,128 0.5,32 0.5,64 0.5,96 1.0,32 1.0,64 2.0,64; do
+    if [ $a = auto ]; then flag=""; else flag="--amalgamation $a"; fi
+    python3 bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline $flag 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.readline())
+print('%-11s %-9s -> relax %-6s maxf %-4s  %.3f ms/iter  levels %d  flops %.3g' % ('$w', '$a', d['config']['amalgamation']['relax'], d['config']['amalgamation']['max_frontal_dim'], d['ms_per_step'], d['symbolic']['n_levels'], d['symbolic']['factor_flops']))" >> $out
+  done
+done
+cat $out
