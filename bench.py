@@ -8,10 +8,15 @@ committed, so every step does identical work on data already resident in HBM.
 
   N = 1   workload = BAL Ladybug-1723 shape (1 723 cameras / 156 502 points / 678 718 observations,
           seeded synthetic: 70 % ring-local + 30 % half-lap revisit co-visibility), Schur ordering with
-          nested dissection of the camera graph (BASELINE config 3: "LM + METIS ordering").
-  N > 1   one process per GPU (torch.distributed, backend nccl = RCCL), every rank an independent
-          seeded replica of the same shape (weak scaling; see DESIGN.md "multi-GPU": the clique-partitioned
-          single-problem path is not built yet, so no data-path collective is invented here).
+          multilevel nested dissection of the camera graph (BASELINE config 3: "LM + METIS ordering").
+  N > 1   one process per GPU (torch.distributed, backend nccl = RCCL over xGMI): the ranks solve ONE
+          100 000-pose Pose3 graph together ("100k-pose g2o @1/2/4/8", BASELINE's metric) — gsx_set_shard:
+          subtrees of the Bayes tree dealt to the ranks, one all-reduce of the top ("cap") fronts per
+          factorization; "scaling": "strong".  `--replicas` runs N independent seeded replicas of the N=1
+          workload instead (weak scaling, no data-path collective).
+          The sharded path has been rehearsed on ONE GPU only (several ranks sharing it, exchange over gloo):
+          strong scaling on real xGMI and the RCCL branch of the exchange are unmeasured until the driver's
+          multi-GPU run.
 
 Prints ONE JSON line on rank 0.
 """
@@ -36,7 +41,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="bal1723", choices=["bal1723", "bal49", "pose3_100k", "pose2_100k"])
+    ap.add_argument("--workload", default=None, choices=["bal1723", "bal49", "pose3_100k", "pose2_100k"],
+                    help="default: bal1723 on one GPU (and for --replicas), pose3_100k for the sharded N > 1 run")
     ap.add_argument("--ordering", default=None, choices=[None, "schur", "schur_nd", "mindegree", "nd"])
     ap.add_argument("--lam", type=float, default=1e-5)
     ap.add_argument("--amalgamation", default=None, metavar="RELAX,MAXF",
@@ -48,16 +54,17 @@ def parse():
                     help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the N>1 path on a box "
                          "with fewer GPUs than ranks)")
     ap.add_argument("--shard", action="store_true",
-                    help="N>1: the ranks solve ONE problem together (gsx_set_shard: cap + subtrees, one all-reduce of the "
-                         "cap per factorization) instead of one replica each; strong scaling")
+                    help="(the default for N>1) the ranks solve ONE problem together (gsx_set_shard: cap + subtrees, one "
+                         "all-reduce of the cap per factorization); strong scaling")
+    ap.add_argument("--replicas", action="store_true",
+                    help="N>1: one independent seeded replica per rank instead (weak scaling, no data-path collective)")
     ap.add_argument("--shard-share", type=int, default=0, metavar="W",
                     help="N=1 only: time rank 0's share of a W-way sharded problem with the exchange stubbed out (rank 0 "
                          "carries the cap's damping, so its system stays positive definite): the compute on the critical "
                          "path of a W-GPU run, without the all-reduce")
-    ap.add_argument("--shard-extra", default="pose3_100k", metavar="WORKLOAD|none",
-                    help="N>1 in the default replica mode: after the timed replicas, rank 0 also starts a separate N-rank "
-                         "`--shard` run of this workload (own processes, hard time limit) and attaches its result under "
-                         "\"shard_run\" — the strong-scaling number next to the weak-scaling headline; 'none' to skip")
+    ap.add_argument("--shard-extra", default="none", metavar="WORKLOAD|none",
+                    help="N>1 with --replicas: after the timed replicas, rank 0 also starts a separate N-rank sharded run "
+                         "of this workload (own processes, hard time limit) and attaches its result under \"shard_run\"")
     ap.add_argument("--shard-extra-timeout", type=float, default=240.0)
     return ap.parse_args()
 
@@ -143,7 +150,7 @@ def run_shard_child(world, workload, backend, timeout_s):
     port = int(os.environ.get("MASTER_PORT", "29500")) + 23
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-           "--gpus", str(world), "--shard", "--workload", workload, "--steps", "20", "--warmup", "3",
+           "--gpus", str(world), "--workload", workload, "--steps", "20", "--warmup", "3",
            "--no-cpu-baseline", "--backend", backend]
     env = {k: v for k, v in os.environ.items()
            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "GROUP_RANK", "ROLE_RANK",
@@ -189,7 +196,9 @@ def main():
         dist = D.init(args.backend, torch.device("cuda", device) if args.backend == "nccl" else None)
     red_dev = "cuda" if (dist is not None and args.backend == "nccl") else "cpu"
 
-    sharded = (args.shard and world > 1) or args.shard_share > 1
+    sharded = (world > 1 and not args.replicas) or args.shard_share > 1
+    if args.workload is None:
+        args.workload = "pose3_100k" if (sharded and world > 1) else "bal1723"
     arrays, default_order = make_problem(args.workload, seed=42 if sharded else D.replica_seed(42))
     be = _lib.product_backend(arrays, device=device)
     exchange = {"calls": 0, "doubles": 0, "seconds": 0.0}
@@ -241,7 +250,8 @@ def main():
         e_sh = be.lm_trial(True, lam, False)
         if rank == 0:
             ref = _lib.product_backend(arrays, device=device)
-            ref.set_amalgamation(relax, relax_maxf)
+            if args.amalgamation is not None:
+                ref.set_amalgamation(relax, relax_maxf)
             ref.set_ordering(ordering)
             e_ref = ref.lm_trial(True, lam, False)
             ref.synchronize()

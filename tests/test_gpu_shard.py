@@ -109,3 +109,34 @@ def test_sharded_solve_matches_single_gpu(world):
             assert r["lm"] == per_rank[0]["lm"] and r["steps"] == per_rank[0]["steps"], name
         # a real split: a cap plus subtrees on every rank
         assert per_rank[0]["info"]["n_cap_fronts"] >= 1 and len(per_rank[0]["owners"]) == world + 1, name
+
+
+@pytest.mark.gpu
+def test_rccl_allreduce_aliases_device_memory_in_place():
+    """The `nccl` (= RCCL) branch of distributed.torch_allreduce — the exchange callback of a sharded handle on real
+    multi-GPU nodes — run for real with a one-rank group: the callback receives a plain device pointer + count, aliases
+    it as a tensor (__cuda_array_interface__, no copy) and RCCL reduces in place.  (More than one rank on this pool's
+    one GPU is refused by RCCL: the multi-rank tests above go over gloo.)"""
+    code = r"""
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from gtsam_petercdev_amd import distributed as D
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%r, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+allreduce = D.torch_allreduce(dist, dev)
+buf = torch.arange(1000, dtype=torch.float64, device=dev) * 0.5
+allreduce(buf.data_ptr() + 8 * 10, 900)            # a sub-range of library-style memory, by raw pointer
+assert torch.equal(buf.cpu(), torch.arange(1000, dtype=torch.float64) * 0.5)
+t = torch.as_tensor(D._DeviceDoubles(buf.data_ptr(), 1000), device=dev)
+assert t.data_ptr() == buf.data_ptr()              # an alias, not a copy
+t.mul_(2.0)
+assert float(buf[999]) == 999.0
+dist.destroy_process_group()
+print("rccl-ok")
+""" % (ROOT, str(29700 + (os.getpid() % 2000)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0 and "rccl-ok" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
