@@ -31,6 +31,9 @@
 #include <memory>
 #include <set>
 #include <string>
+#include <atomic>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../include/gsx.h"
@@ -117,6 +120,10 @@ struct Problem {
   double tree_flops = 0, tree_bytes = 0;
   int64_t tree_cliques = 0, tree_depth = 0, tree_maxf = 0, tree_maxs = 0;
   std::string err;
+  // host threads for the two loops the reference runs on TBB: factors in linearize
+  // (gtsam/nonlinear/NonlinearFactorGraph.cpp:214-261) and independent subtrees in elimination / back-substitution
+  // (gtsam/base/treeTraversal/parallelTraversalTasks.h:35-156); 1 = the serial reference build (TBB off)
+  int n_threads = 1;
 };
 
 // ---------------------------------------------------------------------------
@@ -351,30 +358,47 @@ static double graph_error(const Problem& P, const double* values) {
 
 // NoiseModelFactor::linearize — gtsam/nonlinear/NonlinearFactor.cpp:152-184;
 // GeneralSFMFactor::linearize — gtsam/slam/GeneralSFMFactor.h:141-177.
+// run body(begin, end, thread) over [0, n) on up to P.n_threads threads (contiguous chunks)
+template <class Body>
+static void parallel_chunks(const Problem& P, size_t n, Body body) {
+  const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)P.n_threads, n / 256 + 1));
+  if (nt == 1) {
+    body((size_t)0, n, 0);
+    return;
+  }
+  vector<std::thread> th;
+  for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { body(n * t / nt, n * (t + 1) / nt, t); });
+  for (auto& x : th) x.join();
+}
+
 static void linearize(Problem& P) {
   const double t0 = now_s();
   P.linear.clear();
   P.linear.resize(P.factors.size());
-  P.n_cheirality = 0;
-  for (size_t i = 0; i < P.factors.size(); ++i) {
-    const Factor& f = P.factors[i];
-    LinFactor& L = P.linear[i];
-    L.vars = f.vars;
-    for (int v : f.vars) L.dims.push_back(P.dims[v]);
-    L.rows = f.rows;
-    const int m = f.rows, nc = L.cols();
-    L.M.assign((size_t)m * nc, 0.0);
-    if (f.type == GSX_F_LINEAR) {
-      L.M = f.meas;  // already [A b]
+  vector<int64_t> cheir((size_t)std::max(P.n_threads, 1), 0);
+  parallel_chunks(P, P.factors.size(), [&](size_t begin, size_t end, int t) {
+    for (size_t i = begin; i < end; ++i) {
+      const Factor& f = P.factors[i];
+      LinFactor& L = P.linear[i];
+      L.vars = f.vars;
+      for (int v : f.vars) L.dims.push_back(P.dims[v]);
+      L.rows = f.rows;
+      const int m = f.rows, nc = L.cols();
+      L.M.assign((size_t)m * nc, 0.0);
+      if (f.type == GSX_F_LINEAR) {
+        L.M = f.meas;  // already [A b]
+        whiten_rows(f, L.M.data(), m, nc);
+        continue;
+      }
+      double e[16];
+      const bool ok = eval_factor(P, f, P.values.data(), e, L.M.data());
+      if (!ok) ++cheir[t];
+      for (int r = 0; r < m; ++r) L.M[(size_t)(nc - 1) * m + r] = -e[r];  // b = -e (SFM: z - pi)
       whiten_rows(f, L.M.data(), m, nc);
-      continue;
     }
-    double e[16];
-    const bool ok = eval_factor(P, f, P.values.data(), e, L.M.data());
-    if (!ok) ++P.n_cheirality;
-    for (int r = 0; r < m; ++r) L.M[(size_t)(nc - 1) * m + r] = -e[r];  // b = -e (SFM: z - pi)
-    whiten_rows(f, L.M.data(), m, nc);
-  }
+  });
+  P.n_cheirality = 0;
+  for (int64_t c : cheir) P.n_cheirality += c;
   P.linearized = true;
   P.t[0] += now_s() - t0;
 }
@@ -728,85 +752,170 @@ static void solve_gfg(Problem& P, const vector<LinFactor>& gfg, Vec& delta) {
   P.t[7] += now_s() - t0;
   t0 = now_s();
 
-  // post-order numeric elimination
+  // post-order numbering of the clusters (roots in order, children in order): clique c of the Bayes tree is the c-th
+  // cluster eliminated by the serial traversal (ClusterTree-inst.h:286-318), whatever the number of threads
+  const int ncl = (int)jt.clusters.size();
+  vector<int> post, idx(ncl, -1), parentCluster(ncl, -1), depth(ncl, 1), size(ncl, 1);
+  post.reserve(ncl);
+  {
+    struct Frame {
+      int cluster;
+      size_t next_child;
+    };
+    vector<Frame> stack;
+    for (int rc : rootClusters) {
+      stack.push_back(Frame{rc, 0});
+      while (!stack.empty()) {
+        Frame& fr = stack.back();
+        const Cluster& cl = jt.clusters[fr.cluster];
+        if (fr.next_child < cl.children.size()) {
+          const int ch = cl.children[fr.next_child++];
+          parentCluster[ch] = fr.cluster;
+          depth[ch] = depth[fr.cluster] + 1;
+          stack.push_back(Frame{ch, 0});
+          continue;
+        }
+        idx[fr.cluster] = (int)post.size();
+        post.push_back(fr.cluster);
+        if (parentCluster[fr.cluster] >= 0) size[parentCluster[fr.cluster]] += size[fr.cluster];
+        stack.pop_back();
+      }
+    }
+  }
   vector<Conditional>& bt = P.bayes_tree;
   bt.clear();
-  vector<int> cliqueOfCluster(jt.clusters.size(), -1);
+  bt.resize(post.size());
+  vector<std::unique_ptr<LinFactor>> remaining(ncl);
   P.tree_flops = P.tree_bytes = 0;
   P.tree_cliques = P.tree_depth = P.tree_maxf = P.tree_maxs = 0;
-  struct Frame {
-    int cluster;
-    size_t next_child;
-    vector<std::unique_ptr<LinFactor>> childFactors;
-    int depth;
-  };
-  vector<std::unique_ptr<LinFactor>> rootRemaining;
-  for (int rc : rootClusters) {
-    vector<Frame> stack;
-    stack.push_back(Frame{rc, 0, {}, 1});
-    while (!stack.empty()) {
-      Frame& fr = stack.back();
-      const Cluster& cl = jt.clusters[fr.cluster];
-      if (fr.next_child < cl.children.size()) {
-        const int ch = cl.children[fr.next_child++];
-        const int d = fr.depth + 1;
-        stack.push_back(Frame{ch, 0, {}, d});
-        continue;
-      }
+  std::mutex stat_mutex;
+  constexpr int kNoFail = 0x7fffffff;
+  std::atomic<int> first_fail{kNoFail};
+  vector<uint64_t> fail_key(post.size(), 0);
+  // eliminate the cliques post[begin .. end) in order (a whole subtree is a contiguous range of the post-order)
+  auto eliminate_range = [&](int begin, int end) {
+    double fl = 0, by = 0;
+    int64_t maxf = 0, maxs = 0, dep = 0;
+    for (int c = begin; c < end; ++c) {
+      const int cluster = post[c];
+      const Cluster& cl = jt.clusters[cluster];
       // gather factors: own then children's remaining
       vector<const LinFactor*> gathered;
       for (int f : cl.factors) gathered.push_back(&gfg[f]);
-      for (auto& cf : fr.childFactors) gathered.push_back(cf.get());
+      for (int ch : cl.children) gathered.push_back(remaining[ch].get());
       Conditional cond;
-      auto remaining = std::make_unique<LinFactor>();
-      eliminate_clique(P, gathered, cl.orderedFrontalVars, cond, *remaining);
+      auto rem = std::make_unique<LinFactor>();
+      try {
+        eliminate_clique(P, gathered, cl.orderedFrontalVars, cond, *rem);
+      } catch (const IndeterminantLinearSystem& e) {
+        fail_key[c] = e.key;
+        int cur = first_fail.load();
+        while (c < cur && !first_fail.compare_exchange_weak(cur, c)) {}
+        break;  // (the serial traversal stops at its first failure; nothing above this clique can be eliminated)
+      }
+      for (int ch : cl.children) remaining[ch].reset();
       const double f = cond.nf, s1 = cond.ncols - cond.nf;  // s + 1
-      P.tree_flops += f * f * f / 3 + f * f * s1 + f * s1 * s1;
-      P.tree_bytes += 8.0 * cond.ncols * cond.ncols;
-      P.tree_cliques++;
-      P.tree_maxf = std::max<int64_t>(P.tree_maxf, cond.nf);
-      P.tree_maxs = std::max<int64_t>(P.tree_maxs, cond.ncols - cond.nf - 1);
-      P.tree_depth = std::max<int64_t>(P.tree_depth, fr.depth);
-      const int my = (int)bt.size();
-      cliqueOfCluster[fr.cluster] = my;
-      bt.push_back(std::move(cond));
-      for (int ch : cl.children) bt[cliqueOfCluster[ch]].parent_clique = my;
-      stack.pop_back();
-      if (!stack.empty())
-        stack.back().childFactors.push_back(std::move(remaining));
-      else
-        rootRemaining.push_back(std::move(remaining));
+      fl += f * f * f / 3 + f * f * s1 + f * s1 * s1;
+      by += 8.0 * cond.ncols * cond.ncols;
+      maxf = std::max<int64_t>(maxf, cond.nf);
+      maxs = std::max<int64_t>(maxs, cond.ncols - cond.nf - 1);
+      dep = std::max<int64_t>(dep, depth[cluster]);
+      cond.parent_clique = parentCluster[cluster] >= 0 ? idx[parentCluster[cluster]] : -1;
+      bt[c] = std::move(cond);
+      remaining[cluster] = std::move(rem);
     }
+    std::lock_guard<std::mutex> lk(stat_mutex);
+    P.tree_flops += fl;
+    P.tree_bytes += by;
+    P.tree_cliques += end - begin;
+    P.tree_maxf = std::max(P.tree_maxf, maxf);
+    P.tree_maxs = std::max(P.tree_maxs, maxs);
+    P.tree_depth = std::max(P.tree_depth, dep);
+  };
+  // the split the reference's parallel traversal makes (parallelTraversalTasks.h:35-156: a task per child subtree above a
+  // size threshold): clusters whose subtree holds more than a share of the tree form the top, handled in order by this
+  // thread; every subtree hanging below it is one task
+  vector<std::pair<int, int>> tasks;  // post-order ranges of whole subtrees
+  vector<char> is_top(ncl, 0);
+  const int nthreads = std::max(1, P.n_threads);
+  if (nthreads > 1) {
+    const int share = std::max(1, (int)post.size() / (16 * nthreads));
+    for (int c = (int)post.size() - 1; c >= 0; --c) {
+      const int cluster = post[c];
+      const int pc = parentCluster[cluster];
+      if (size[cluster] > share && (pc < 0 || is_top[pc])) is_top[cluster] = 1;
+      else if (pc < 0 || is_top[pc]) tasks.push_back({idx[cluster] - size[cluster] + 1, idx[cluster] + 1});
+    }
+    std::sort(tasks.begin(), tasks.end(), [](auto& a, auto& b) { return a.second - a.first > b.second - b.first; });
+    std::atomic<size_t> next{0};
+    auto worker = [&] {
+      for (size_t k = next++; k < tasks.size(); k = next++) eliminate_range(tasks[k].first, tasks[k].second);
+    };
+    vector<std::thread> th;
+    for (int t = 1; t < nthreads; ++t) th.emplace_back(worker);
+    worker();
+    for (auto& x : th) x.join();
+    for (int c = 0; c < (int)post.size() && first_fail.load() == kNoFail; ++c)
+      if (is_top[post[c]]) eliminate_range(c, c + 1);
+  } else {
+    eliminate_range(0, (int)post.size());
   }
+  if (first_fail.load() != kNoFail) throw IndeterminantLinearSystem{fail_key[first_fail.load()]};
   P.t[2] += now_s() - t0;
   t0 = now_s();
 
-  // back-substitution, parents before children (cliques were pushed in post-order)
+  // back-substitution, parents before children (reverse post-order); subtrees below the top in parallel
   delta.assign(P.tan_size, 0.0);
-  Vec rhs;
-  for (int c = (int)bt.size() - 1; c >= 0; --c) {
-    const Conditional& cd = bt[c];
-    const int nf = cd.nf, N = cd.ncols;
-    rhs.assign(nf, 0.0);
-    for (int r = 0; r < nf; ++r) rhs[r] = cd.RSd[(size_t)(N - 1) * nf + r];
-    int col = nf;
-    for (int pv : cd.parents)
-      for (int k = 0; k < P.dims[pv]; ++k, ++col) {
-        const double x = delta[P.tan_off[pv] + k];
-        for (int r = 0; r < nf; ++r) rhs[r] -= cd.RSd[(size_t)col * nf + r] * x;
+  std::atomic<int> last_nan{-1};
+  vector<uint64_t> nan_key(post.size(), 0);
+  auto backsub_range = [&](int begin, int end) {  // cliques end-1 down to begin
+    Vec rhs;
+    for (int c = end - 1; c >= begin; --c) {
+      const Conditional& cd = bt[c];
+      const int nf = cd.nf, N = cd.ncols;
+      rhs.assign(nf, 0.0);
+      for (int r = 0; r < nf; ++r) rhs[r] = cd.RSd[(size_t)(N - 1) * nf + r];
+      int col = nf;
+      for (int pv : cd.parents)
+        for (int k = 0; k < P.dims[pv]; ++k, ++col) {
+          const double x = delta[P.tan_off[pv] + k];
+          for (int r = 0; r < nf; ++r) rhs[r] -= cd.RSd[(size_t)col * nf + r] * x;
+        }
+      for (int r = nf - 1; r >= 0; --r) {  // R x = rhs (upper)
+        double sacc = rhs[r];
+        for (int k = r + 1; k < nf; ++k) sacc -= cd.RSd[(size_t)k * nf + r] * rhs[k];
+        rhs[r] = sacc / cd.RSd[(size_t)r * nf + r];
       }
-    for (int r = nf - 1; r >= 0; --r) {  // R x = rhs (upper)
-      double s = rhs[r];
-      for (int k = r + 1; k < nf; ++k) s -= cd.RSd[(size_t)k * nf + r] * rhs[k];
-      rhs[r] = s / cd.RSd[(size_t)r * nf + r];
+      int row = 0;
+      for (int fv : cd.frontals)
+        for (int k = 0; k < P.dims[fv]; ++k, ++row) {
+          if (std::isnan(rhs[row])) {  // linearAlgorithms-inst.h:100-104
+            nan_key[c] = P.keys[fv];
+            int cur = last_nan.load();
+            while (c > cur && !last_nan.compare_exchange_weak(cur, c)) {}
+            return;
+          }
+          delta[P.tan_off[fv] + k] = rhs[row];
+        }
     }
-    int row = 0;
-    for (int fv : cd.frontals)
-      for (int k = 0; k < P.dims[fv]; ++k, ++row) {
-        if (std::isnan(rhs[row])) throw IndeterminantLinearSystem{P.keys[fv]};  // linearAlgorithms-inst.h:100-104
-        delta[P.tan_off[fv] + k] = rhs[row];
-      }
+  };
+  if (nthreads > 1) {
+    for (int c = (int)post.size() - 1; c >= 0 && last_nan.load() < 0; --c)
+      if (is_top[post[c]]) backsub_range(c, c + 1);
+    if (last_nan.load() < 0) {
+      std::atomic<size_t> next{0};
+      auto worker = [&] {
+        for (size_t k = next++; k < tasks.size(); k = next++) backsub_range(tasks[k].first, tasks[k].second);
+      };
+      vector<std::thread> th;
+      for (int t = 1; t < nthreads; ++t) th.emplace_back(worker);
+      worker();
+      for (auto& x : th) x.join();
+    }
+  } else {
+    backsub_range(0, (int)post.size());
   }
+  if (last_nan.load() >= 0) throw IndeterminantLinearSystem{nan_key[last_nan.load()]};
   P.t[3] += now_s() - t0;
 }
 
@@ -1546,5 +1655,11 @@ int orc_reset_timing(void* h) {
   return GSX_OK;
 }
 int64_t orc_n_cheirality(void* h) { return ((Problem*)h)->n_cheirality; }
+// host threads of linearize / elimination / back-substitution (1 = serial, the reference without TBB)
+int orc_set_threads(void* h, int32_t n) {
+  if (!h || n < 1) return GSX_E_INVALID;
+  ((Problem*)h)->n_threads = n;
+  return GSX_OK;
+}
 
 }  // extern "C"

@@ -49,6 +49,11 @@ class OracleBackend(A.Backend):
     def reset_timing(self):
         self._fn("reset_timing")(self._h)
 
+    def set_threads(self, n: int):
+        """Host threads for the two loops the reference runs on TBB (factors in linearize, independent subtrees in
+        elimination / back-substitution); 1 = serial."""
+        self._check(self._fn("set_threads")(self._h, C.c_int32(n)), "set_threads")
+
     def conditional(self, c):
         nf, nc = C.c_int32(), C.c_int32()
         self._check(self._fn("get_conditional")(self._h, C.c_int32(c), C.byref(nf), C.byref(nc), None), "get_conditional")

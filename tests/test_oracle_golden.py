@@ -863,3 +863,34 @@ def test_toro_examples_converge(orc, golden_dir):
         r = ob.lm_optimize(A.lm_params_legacy())
         assert r["final_error"] < 0.25 * r["initial_error"], name   # (the floor is the measurement noise)
         assert r["iterations"] < 100, name
+
+
+# ---- the oracle's threaded loops (the reference's TBB loops) change nothing but the wall time -------------------------------
+@pytest.mark.parametrize("kind", ["bal", "pose3"])
+def test_oracle_threads_are_bitwise_identical_to_serial(oracle, kind):
+    """orc_set_threads: factors in linearize (NonlinearFactorGraph.cpp:214-261) and independent subtrees in elimination /
+    back-substitution (parallelTraversalTasks.h:35-156) on std::thread — same Jacobians, same Bayes tree in the same
+    clique order, same conditionals, same solution, bit for bit, as the serial traversal."""
+    from gtsam_petercdev_amd import datasets, _lib
+    if kind == "bal":
+        arr, okind = datasets.synth_bal_arrays(30, 3000, 12000, seed=3, long_range=0.3), A.ORDER_SCHUR_ND
+    else:
+        arr, okind = datasets.synth_manhattan_pose3(6000, seed=5), A.ORDER_ND
+    ordering = _lib.ProductBackend(arr, host_only=True).compute_ordering(okind)
+    runs = []
+    for threads in (1, 4):
+        ob = oracle.oracle_backend(arr)
+        ob.set_threads(threads)
+        ob.set_ordering(ordering)
+        ob.linearize()
+        jac = ob.jacobians()
+        delta = ob.solve(1e-4, False)
+        parent, fronts = ob.get_tree()
+        conds = [ob.conditional(c) for c in (0, len(fronts) // 2, len(fronts) - 1)]
+        _, tree = ob.timing()
+        runs.append((jac, delta, list(parent), fronts, conds, tree))
+    a, b = runs
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert a[2] == b[2] and all(np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) for x, y in zip(a[3], b[3]))
+    assert all(np.array_equal(x, y) for x, y in zip(a[4], b[4]))
+    assert a[5] == b[5]
