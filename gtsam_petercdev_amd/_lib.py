@@ -106,6 +106,43 @@ class ProductBackend(A.Backend):
                                                     sp, C.c_int64(ns), C.byref(st)), "relinearize_partial")
         return {k: getattr(st, k) for k, _ in PartialStats._fields_}
 
+    def set_block_jacobians(self, first_factor: int, blocks):
+        """gsx_set_block_jacobians: refresh the [A b] blocks of the GSX_F_LINEAR factors first_factor.. in place (blocks =
+        the factors' m x (sum d + 1) column-major blocks one after the other, unwhitened: the slot's noise model is folded
+        in by the library) — the S5 fallback for factor types the backend does not know."""
+        bl = [np.asfortranarray(b, dtype=np.float64).ravel(order="F") for b in blocks]
+        flat = np.concatenate(bl) if bl else np.zeros(0)
+        self._check(self._fn("set_block_jacobians")(self._h, C.c_int32(first_factor), C.c_int32(len(bl)),
+                                                    flat.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(flat.size)),
+                    "set_block_jacobians")
+
+    def solve_gfg_h(self, blocks=None):
+        """gsx_solve_gfg_h: the linear seam on a kept handle (GSX_F_LINEAR factors only): new numbers, same structure."""
+        out = np.zeros(int(self.arrays.var_dims.sum()))
+        bad = C.c_uint64()
+        if blocks is None:
+            bp, nb = None, 0
+        else:
+            flat = np.concatenate([np.asfortranarray(b, dtype=np.float64).ravel(order="F") for b in blocks])
+            bp, nb = flat.ctypes.data_as(C.POINTER(C.c_double)), flat.size
+        st = self._fn("solve_gfg_h")(self._h, bp, C.c_int64(nb), out.ctypes.data_as(C.POINTER(C.c_double)),
+                                     C.c_int64(out.size), C.byref(bad))
+        if st == A.GSX_E_INDETERMINATE:
+            raise A.IndeterminantLinearSystemException(bad.value, "solve_gfg_h")
+        self._check(st, "solve_gfg_h")
+        return out
+
+    def conditional(self, front: int) -> np.ndarray:
+        """gsx_get_conditional: [R S d] of clique `front` (gsx_get_tree numbering), n_frontal x n_cols."""
+        nf, nc = C.c_int32(), C.c_int32()
+        self._check(self._fn("get_conditional")(self._h, C.c_int32(front), C.byref(nf), C.byref(nc), None, C.c_int64(0)),
+                    "get_conditional")
+        out = np.zeros(nf.value * nc.value)
+        self._check(self._fn("get_conditional")(self._h, C.c_int32(front), C.byref(nf), C.byref(nc),
+                                                out.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(out.size)),
+                    "get_conditional")
+        return out.reshape(nc.value, nf.value).T
+
     def lm_trial(self, relinearize=True, lam=0.0, diagonal_damping=False, min_diagonal=1e-6, max_diagonal=1e32):
         """One LM trial without the policy (gsx_lm_trial): (linear error at 0, at delta, nonlinear error of the trial)."""
         e0, ed, et = C.c_double(), C.c_double(), C.c_double()

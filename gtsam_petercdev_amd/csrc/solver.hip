@@ -188,6 +188,7 @@ struct gsx_context {
   DevBuf<int> d_f_active;
   DevBuf<unsigned char> d_own_tan, d_sched_tan, d_own_state;
   DevBuf<double> d_xscal;
+  std::vector<double> jac_stage;   // host staging of gsx_set_block_jacobians
   bool sharded() const { return shard_world > 1; }
 };
 
@@ -260,6 +261,27 @@ gsx_status upload_factor_lists(gsx_context* c, const std::vector<char>* owned) {
   return GSX_OK;
 }
 
+// [A b] of a GSX_F_LINEAR factor with its noise model folded in: data preparation of a GIVEN linear factor
+// (JacobianFactor::whiten, gtsam/linear/JacobianFactor.cpp), on the host
+void whiten_linear_factor(const HostProblem& P, int f, const double* src, double* J) {
+  const int m = P.f_rows[f], nc = P.f_cols[f];
+  std::copy(src, src + (size_t)m * nc, J);
+  const double* np = P.noise.data() + P.f_noise_ptr[f];
+  const int kind = P.f_noise_kind[f];
+  for (int cidx = 0; cidx < nc; ++cidx) {
+    if (kind == GSX_NOISE_ISOTROPIC)
+      for (int r = 0; r < m; ++r) J[cidx * m + r] *= 1.0 / np[0];
+    else if (kind == GSX_NOISE_DIAGONAL)
+      for (int r = 0; r < m; ++r) J[cidx * m + r] *= 1.0 / np[r];
+    else if (kind == GSX_NOISE_GAUSSIAN)
+      for (int r = 0; r < m; ++r) {
+        double sacc = 0;
+        for (int k = r; k < m; ++k) sacc += np[r * m + k] * J[cidx * m + k];
+        J[cidx * m + r] = sacc;
+      }
+  }
+}
+
 gsx_status upload_problem(gsx_context* c) {
   const HostProblem& P = c->P;
   hipStream_t st = c->stream;
@@ -296,35 +318,15 @@ gsx_status upload_problem(gsx_context* c) {
   HIPCHK(c, hipHostMalloc((void**)&c->h_status, sizeof(DevStatus)));
   HIPCHK(c, hipMemsetAsync(c->d_scalars.p, 0, SC_COUNT * sizeof(double), st));
   HIPCHK(c, hipMemsetAsync(c->d_delta.p, 0, std::max<int64_t>(P.tan_size, 1) * sizeof(double), st));
-  // LINEAR factors: their (whitened) [A b] is static — written once
+  // LINEAR factors: their (whitened) [A b] as given at creation (gsx_set_block_jacobians refreshes them in place)
   {
     std::vector<double> jac;
     bool any = false;
     for (int f = 0; f < P.n_factors; ++f) any = any || P.f_type[f] == GSX_F_LINEAR;
     if (any) {
       jac.assign(P.jac_size, 0.0);
-      for (int f = 0; f < P.n_factors; ++f) {
-        if (P.f_type[f] != GSX_F_LINEAR) continue;
-        const int m = P.f_rows[f], nc = P.f_cols[f];
-        double* J = jac.data() + P.f_jac_off[f];
-        std::copy(P.meas.begin() + P.f_meas_ptr[f], P.meas.begin() + P.f_meas_ptr[f + 1], J);
-        const double* np = P.noise.data() + P.f_noise_ptr[f];
-        const int kind = P.f_noise_kind[f];
-        // folding a noise model into a GIVEN linear factor is data preparation (JacobianFactor::whiten,
-        // gtsam/linear/JacobianFactor.cpp), done once at creation
-        for (int cidx = 0; cidx < nc; ++cidx) {
-          if (kind == GSX_NOISE_ISOTROPIC)
-            for (int r = 0; r < m; ++r) J[cidx * m + r] *= 1.0 / np[0];
-          else if (kind == GSX_NOISE_DIAGONAL)
-            for (int r = 0; r < m; ++r) J[cidx * m + r] *= 1.0 / np[r];
-          else if (kind == GSX_NOISE_GAUSSIAN)
-            for (int r = 0; r < m; ++r) {
-              double s = 0;
-              for (int k = r; k < m; ++k) s += np[r * m + k] * J[cidx * m + k];
-              J[cidx * m + r] = s;
-            }
-        }
-      }
+      for (int f = 0; f < P.n_factors; ++f)
+        if (P.f_type[f] == GSX_F_LINEAR) whiten_linear_factor(P, f, P.meas.data() + P.f_meas_ptr[f], jac.data() + P.f_jac_off[f]);
       HIPCHK(c, hipMemcpyAsync(c->d_jac.p, jac.data(), jac.size() * sizeof(double), hipMemcpyHostToDevice, st));
       HIPCHK(c, hipStreamSynchronize(st));
     }
@@ -2146,6 +2148,119 @@ gsx_status gsx_marginal_covariance(gsx_handle h, uint64_t key, double* out, int6
   HIPCHK(h, hipMemcpyAsync(out, d_out.p, (size_t)dA * dA * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipGetLastError());
+  return GSX_OK;
+}
+
+gsx_status gsx_set_block_jacobians(gsx_handle h, int32_t first_factor, int32_t n_factors, const double* values,
+                                   int64_t n_values) {
+  if (!h || !values || first_factor < 0 || n_factors < 0 || first_factor + n_factors > h->P.n_factors) return GSX_E_INVALID;
+  gsx_status st = need_device(h);
+  if (st != GSX_OK) return st;
+  const HostProblem& P = h->P;
+  int64_t need = 0;
+  for (int f = first_factor; f < first_factor + n_factors; ++f) {
+    if (P.f_type[f] != GSX_F_LINEAR) {
+      h->err = "gsx_set_block_jacobians: not a GSX_F_LINEAR factor";
+      return GSX_E_INVALID;
+    }
+    need += (int64_t)P.f_rows[f] * P.f_cols[f];
+  }
+  if (need != n_values) return GSX_E_INVALID;
+  if (n_factors == 0) return GSX_OK;
+  hipSetDevice(h->device);
+  // the factors' blocks are consecutive in the Jacobian pool when the factors are: one staging buffer, one copy per run
+  std::vector<double>& stage = h->jac_stage;
+  stage.resize((size_t)need);
+  int64_t src = 0;
+  for (int f = first_factor; f < first_factor + n_factors; ++f) {
+    whiten_linear_factor(P, f, values + src, stage.data() + src);
+    src += (int64_t)P.f_rows[f] * P.f_cols[f];
+  }
+  src = 0;
+  for (int f = first_factor; f < first_factor + n_factors;) {
+    int e = f;
+    int64_t len = 0;
+    while (e < first_factor + n_factors && P.f_jac_off[e] == P.f_jac_off[f] + len) {
+      len += (int64_t)P.f_rows[e] * P.f_cols[e];
+      ++e;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_jac.p + P.f_jac_off[f], stage.data() + src, (size_t)len * sizeof(double),
+                             hipMemcpyHostToDevice, h->stream));
+    src += len;
+    f = e;
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));  // (the staging buffer is reused by the next call)
+  h->h_ready = false;      // H must be re-assembled from the new blocks
+  h->hdiag_ready = false;
+  h->fact_valid = false;
+  h->solved = false;
+  if (h->damp_kind != 0) h->damp_ready = false;
+  return GSX_OK;
+}
+
+gsx_status gsx_solve_gfg_h(gsx_handle h, const double* blocks, int64_t n_blocks, double* delta_out, int64_t n,
+                           uint64_t* bad_key) {
+  if (!h || !delta_out) return GSX_E_INVALID;
+  for (int f = 0; f < h->P.n_factors; ++f)
+    if (h->P.f_type[f] != GSX_F_LINEAR) {
+      h->err = "gsx_solve_gfg_h: the handle must hold GSX_F_LINEAR factors only";
+      return GSX_E_INVALID;
+    }
+  gsx_status st = GSX_OK;
+  if (blocks) st = gsx_set_block_jacobians(h, 0, h->P.n_factors, blocks, n_blocks);
+  if (st != GSX_OK) return st;
+  if (!h->values_set) {
+    std::vector<double> zeros(h->P.state_size, 0.0);
+    st = gsx_set_values(h, zeros.data(), h->P.state_size);
+    if (st != GSX_OK) return st;
+  }
+  h->linearized = true;  // a linear graph IS its linearization
+  return gsx_solve(h, 0.0, 0, 0, 0, delta_out, n, bad_key);
+}
+
+gsx_status gsx_get_conditional(gsx_handle h, int32_t front, int32_t* n_frontal, int32_t* n_cols, double* out,
+                               int64_t n_out) {
+  if (!h) return GSX_E_INVALID;
+  gsx_status st = ensure_ready(h, false, true);
+  if (st != GSX_OK) return st;
+  const Symbolic& S = h->S;
+  if (front < 0 || front >= S.n_fronts) return GSX_E_INVALID;
+  const int F = S.F[front], N = S.N[front];  // N = F + separator + 1 (rhs)
+  if (n_frontal) *n_frontal = F;
+  if (n_cols) *n_cols = N;
+  if (!out) return GSX_OK;
+  if (n_out != (int64_t)F * N) return GSX_E_INVALID;
+  if (!h->fact_valid) {
+    h->err = "gsx_get_conditional: no factorization resident (solve first)";
+    return GSX_E_STATE;
+  }
+  if (h->sharded() && !S.scheduled[front]) {
+    h->err = "gsx_get_conditional: the clique belongs to another rank";
+    return GSX_E_STATE;
+  }
+  hipSetDevice(h->device);
+  // the front keeps L = [R S d]' column by column: L[r][c] at r + c N; blocked (big) fronts keep the rows below each
+  // 32 x 32 diagonal tile in their L-panel area (kernels.h: BigDesc)
+  const bool big = S.cls[front] == 2;
+  const i64 cols = (i64)N * F;
+  std::vector<double> sq((size_t)cols), xp;
+  HIPCHK(h, hipMemcpyAsync(sq.data(), h->d_arena.p + S.off[front], (size_t)cols * sizeof(double), hipMemcpyDeviceToHost,
+                           h->stream));
+  if (big) {
+    xp.resize((size_t)cols);
+    HIPCHK(h, hipMemcpyAsync(xp.data(), h->d_arena.p + S.off[front] + big_panel_offset(N), (size_t)cols * sizeof(double),
+                             hipMemcpyDeviceToHost, h->stream));
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (int c = 0; c < F; ++c)        // column c of L = row c of [R S d]
+    for (int r = 0; r < N; ++r) {
+      double v = 0.0;
+      if (r >= c) {
+        const bool in_tile = big && r < F && (r / kTile) == (c / kTile);
+        v = (big && !in_tile) ? xp[(size_t)r + (size_t)c * N] : sq[(size_t)r + (size_t)c * N];
+      }
+      out[(size_t)c + (size_t)r * F] = v;  // F x N column-major: entry (row c, column r)
+    }
   return GSX_OK;
 }
 

@@ -447,11 +447,36 @@ gsx_status gsx_relinearize_partial(gsx_handle h, const uint64_t* keys, int32_t n
 /* DoglegOptimizerImpl::ComputeDoglegPoint (DoglegOptimizerImpl.cpp:26-86) on plain vectors (host). */
 gsx_status gsx_dogleg_point(double delta, const double* dx_u, const double* dx_n, int64_t n, double* out);
 
+/* ---- factors the backend does not know (seam S5: NonlinearFactor::linearize, gtsam/nonlinear/NonlinearFactor.h:145-146) ----
+ * A graph may carry GSX_F_LINEAR slots for factor types outside the table above: the caller linearizes those on the CPU
+ * at every new linearization point (factor->linearize(values) -> JacobianFactor) and refreshes their [A b] blocks in
+ * place with this call — values = the factors' blocks one after the other, each m x (sum d + 1) column-major exactly as
+ * `meas` at gsx_create (the slot's noise model is folded in here, as at creation).  gsx_linearize leaves these blocks
+ * alone; the Hessian panels are re-assembled at the next solve.  gsx_error counts 0 for such a slot: the caller adds
+ * its factors' nonlinear error itself. */
+gsx_status gsx_set_block_jacobians(gsx_handle h, int32_t first_factor, int32_t n_factors, const double* values,
+                                   int64_t n_values);
+/* [R S d] of clique `front` (numbering of gsx_get_tree) from the factorization resident after a solve — the
+ * GaussianConditional the reference's elimination stores in the Bayes-tree clique (R() / S() / d(),
+ * gtsam/linear/GaussianConditional.h:243-252; BayesTreeCliqueBase-inst.h:27-31): n_frontal x n_cols column-major, the
+ * columns in the order frontal variables, separator variables (both as gsx_get_tree lists them), rhs.  With the
+ * reference's cliques (gsx_set_amalgamation(h, 0, .)) it is the reference's conditional entry for entry; out = NULL
+ * queries the sizes. */
+gsx_status gsx_get_conditional(gsx_handle h, int32_t front, int32_t* n_frontal, int32_t* n_cols, double* out,
+                               int64_t n_out);
+
 /* ---- the linear seam (NonlinearOptimizer::solve override) ------------------- */
 /* desc must contain only GSX_F_LINEAR factors and GSX_VAR_VECTOR variables;
  * ordering may be NULL (own minimum degree).  delta_out in variable-index order. */
 gsx_status gsx_solve_gfg(const gsx_problem_desc* desc, const uint64_t* ordering,
                          int32_t device, double* delta_out, int64_t n, uint64_t* bad_key);
+/* The same seam with the structure kept: NonlinearOptimizer::solve (gtsam/nonlinear/NonlinearOptimizer.h:129-130) is
+ * called once per LM trial on graphs of ONE structure (same keys, dims, ordering; only the numbers and the damping
+ * priors' sigmas change).  Create the handle once (gsx_create on the GSX_F_LINEAR description + gsx_set_ordering: the
+ * symbolic analysis and every device table are built once), then per call hand over only the [A b] blocks of all
+ * factors, one after the other as in `meas` (blocks = NULL: solve what the handle holds).  delta_out as above. */
+gsx_status gsx_solve_gfg_h(gsx_handle h, const double* blocks, int64_t n_blocks, double* delta_out, int64_t n,
+                           uint64_t* bad_key);
 
 /* ---- dense kernel exposed for unit parity (gtsam/base/cholesky.cpp:108-159) -- */
 /* In-place partial Cholesky of an n x n column-major symmetric matrix (upper
