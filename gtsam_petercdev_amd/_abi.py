@@ -233,6 +233,8 @@ class Backend:
         return f
 
     def _check(self, st, what):
+        if st == GSX_E_INDETERMINATE:   # IndeterminantLinearSystemException wherever a factorization is involved
+            raise IndeterminantLinearSystemException(0, self._pfx + what)
         if st != GSX_OK:
             detail = ""
             if self._pfx == "gsx_":

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <new>
 #include <map>
 #include <sstream>
 #include <string>
@@ -228,7 +229,7 @@ bool emit_noise_2d(const double v[6], int format, bool smart, int kernel, gsx_da
 
 extern "C" {
 
-gsx_status gsx_read_g2o(const char* path, int32_t is3d, gsx_dataset** out) {
+static gsx_status read_g2o_impl(const char* path, int32_t is3d, gsx_dataset** out) {
   if (!path || !out) return GSX_E_INVALID;
   std::ifstream in(path);
   if (!in) return GSX_E_INVALID;
@@ -386,7 +387,7 @@ gsx_status gsx_read_g2o(const char* path, int32_t is3d, gsx_dataset** out) {
 }
 
 // load2D — gtsam/slam/dataset.cpp:505-570
-gsx_status gsx_load2d(const char* path, const double* model_sigmas, int64_t max_index, int32_t smart, int32_t noise_format,
+static gsx_status load2d_impl(const char* path, const double* model_sigmas, int64_t max_index, int32_t smart, int32_t noise_format,
                       int32_t kernel, gsx_dataset** out) {
   if (!path || !out || noise_format < GSX_NOISE_FORMAT_G2O || noise_format > GSX_NOISE_FORMAT_AUTO || kernel < 0 ||
       kernel > 2 || max_index < 0)
@@ -503,12 +504,21 @@ gsx_status gsx_load2d(const char* path, const double* model_sigmas, int64_t max_
   return GSX_OK;
 }
 
-gsx_status gsx_read_bal(const char* path, int32_t add_priors, gsx_dataset** out) {
+static gsx_status read_bal_impl(const char* path, int32_t add_priors, gsx_dataset** out) {
   if (!path || !out) return GSX_E_INVALID;
   std::ifstream in(path);
   if (!in) return GSX_E_INVALID;
   long long nc, np, nobs;
   if (!(in >> nc >> np >> nobs) || nc <= 0 || np <= 0 || nobs < 0) return GSX_E_INVALID;
+  {
+    // counts a file of this size cannot hold are refused before anything is sized from them (an observation line is at
+    // least 8 characters, a camera 18, a point 6)
+    const std::streampos here = in.tellg();
+    in.seekg(0, std::ios::end);
+    const long long bytes = (long long)in.tellg();
+    in.seekg(here);
+    if (nobs > bytes / 8 || nc > bytes / 18 || np > bytes / 6 || nc > (1LL << 31) - 2 || np > (1LL << 31) - 2) return GSX_E_INVALID;
+  }
   std::vector<long long> ci(nobs), pj(nobs);
   std::vector<double> u(nobs), v(nobs);
   for (long long k = 0; k < nobs; ++k) {
@@ -627,7 +637,7 @@ void gsx_dataset_free(gsx_dataset* D) { delete D; }
 // save2D — gtsam/slam/dataset.cpp:587-617: VERTEX2 lines for the Pose2 values, and for every BetweenFactor<Pose2> an
 // EDGE2 line with the keys swapped and the measurement inverted, all with the information R'R of the ONE model handed in,
 // in TORO order (the reference does not use the factors' own models either).
-gsx_status gsx_save2d(const gsx_problem_desc* d, const double* values, int64_t n_values, const double* model_sigmas,
+static gsx_status save2d_impl(const gsx_problem_desc* d, const double* values, int64_t n_values, const double* model_sigmas,
                       const char* path) {
   if (!d || !values || !path || !model_sigmas) return GSX_E_INVALID;
   std::vector<int64_t> soff(d->n_vars + 1, 0);
@@ -665,7 +675,7 @@ gsx_status gsx_save2d(const gsx_problem_desc* d, const double* values, int64_t n
 // observations of the GeneralSFMFactors, grouped by point in file order of the factors; pose back to the OpenGL
 // convention (gtsam2openGL, :88-99), rotation as its Rodrigues vector, measurement (u, -v).  17 significant digits
 // (the reference writes its stream's default 6).
-gsx_status gsx_write_bal(const gsx_problem_desc* d, const double* values, int64_t n_values, const char* path) {
+static gsx_status write_bal_impl(const gsx_problem_desc* d, const double* values, int64_t n_values, const char* path) {
   if (!d || !values || !path) return GSX_E_INVALID;
   std::vector<int64_t> soff(d->n_vars + 1, 0);
   std::vector<int> cam_id(d->n_vars, -1), pt_id(d->n_vars, -1);
@@ -717,7 +727,7 @@ gsx_status gsx_write_bal(const gsx_problem_desc* d, const double* values, int64_
   return GSX_OK;
 }
 
-gsx_status gsx_write_g2o(const gsx_problem_desc* d, const double* values, int64_t n_values, const char* path) {
+static gsx_status write_g2o_impl(const gsx_problem_desc* d, const double* values, int64_t n_values, const char* path) {
   if (!d || !values || !path) return GSX_E_INVALID;
   std::vector<int64_t> soff(d->n_vars + 1, 0);
   for (int v = 0; v < d->n_vars; ++v) {
@@ -799,6 +809,41 @@ gsx_status gsx_write_g2o(const gsx_problem_desc* d, const double* values, int64_
   }
   std::fclose(fh);
   return GSX_OK;
+}
+
+
+// No exception crosses the C boundary (include/gsx.h): a malformed or hostile file (absurd counts in a header, a
+// truncated record) ends as GSX_E_INVALID / GSX_E_NOMEM, never as std::terminate in the caller's process.
+#define GSX_NO_THROW(call)                  \
+  try {                                     \
+    return call;                            \
+  } catch (const std::bad_alloc&) {         \
+    return GSX_E_NOMEM;                     \
+  } catch (...) {                           \
+    return GSX_E_INVALID;                   \
+  }
+gsx_status gsx_read_g2o(const char* path, int32_t is3d, gsx_dataset** out) {
+  GSX_NO_THROW(read_g2o_impl(path, is3d, out))
+}
+
+gsx_status gsx_load2d(const char* path, const double* model_sigmas, int64_t max_index, int32_t smart, int32_t noise_format, int32_t kernel, gsx_dataset** out) {
+  GSX_NO_THROW(load2d_impl(path, model_sigmas, max_index, smart, noise_format, kernel, out))
+}
+
+gsx_status gsx_read_bal(const char* path, int32_t add_priors, gsx_dataset** out) {
+  GSX_NO_THROW(read_bal_impl(path, add_priors, out))
+}
+
+gsx_status gsx_save2d(const gsx_problem_desc* d, const double* values, int64_t n_values, const double* model_sigmas, const char* path) {
+  GSX_NO_THROW(save2d_impl(d, values, n_values, model_sigmas, path))
+}
+
+gsx_status gsx_write_bal(const gsx_problem_desc* d, const double* values, int64_t n_values, const char* path) {
+  GSX_NO_THROW(write_bal_impl(d, values, n_values, path))
+}
+
+gsx_status gsx_write_g2o(const gsx_problem_desc* d, const double* values, int64_t n_values, const char* path) {
+  GSX_NO_THROW(write_g2o_impl(d, values, n_values, path))
 }
 
 }  // extern "C"

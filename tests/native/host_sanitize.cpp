@@ -87,5 +87,29 @@ int main(int argc, char** argv) {
     if (gsx_load2d(p.c_str(), nullptr, 0, 1, GSX_NOISE_FORMAT_AUTO, 0, &ds) == GSX_OK) gsx_dataset_free(ds);
     if (gsx_read_bal(p.c_str(), 0, &ds) == GSX_OK) gsx_dataset_free(ds);
   }
+  {
+    // hostile headers: absurd counts must come back as a status (no exception through extern "C", no terminate), and a
+    // file truncated in the middle of a record must be refused
+    const char* texts[] = {"1 1 9000000000000000000\n", "3 7 4611686018427387904\n0 0 1 1\n", "2000000000 2000000000 8000000000\n",
+                           "2 2 3\n0 0 1.5 2.5\n1 1 0.5", "2 2 2\n0 0 1 1\n1 1 2 2\n0.1 0.2 0.3 1 2 3 500 0 0\n0.1 0.2"};
+    for (const char* t : texts) {
+      const std::string p = tmp + "/hostile_bal.txt";
+      FILE* fh = std::fopen(p.c_str(), "w");
+      std::fputs(t, fh);
+      std::fclose(fh);
+      const gsx_status st = gsx_read_bal(p.c_str(), 1, &ds);
+      if (st == GSX_OK) {
+        std::fprintf(stderr, "hostile BAL header accepted: %s\n", t);
+        gsx_dataset_free(ds);
+        bad = 1;
+      }
+    }
+    const std::string p = tmp + "/hostile.g2o";
+    FILE* fh = std::fopen(p.c_str(), "w");
+    std::fputs("VERTEX_SE2 99999999999999999999 0 0 0\nEDGE_SE2 0 18446744073709551615 1 0 0 1 0 0 1 0 1\n", fh);
+    std::fclose(fh);
+    if (gsx_read_g2o(p.c_str(), 0, &ds) == GSX_OK) gsx_dataset_free(ds);
+    if (gsx_load2d(p.c_str(), nullptr, -5, 1, GSX_NOISE_FORMAT_AUTO, 0, &ds) == GSX_OK) gsx_dataset_free(ds);
+  }
   return bad;
 }

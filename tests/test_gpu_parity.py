@@ -892,3 +892,60 @@ def test_assembly_kernel_corner_shapes(gpu, oracle):
         assert relerr(gb.hessian_diagonal(), ob.hessian_diagonal()) < 1e-12
         for lam, diag in ((1e-3, False), (1.0, True)):
             assert relerr(gb.solve(lam, diag), ob.solve(lam, diag)) < 1e-8
+
+
+# ---- a resident factorization never outlives the tree / linearization it was computed for ----------------------------------
+@pytest.mark.parametrize("name", ["bal_small", "pose3"])
+def test_reordering_a_live_handle_drops_the_resident_factorization(gpu, oracle, name):
+    """solve(lambda = 0) / marginals under ordering A leave the undamped factorization resident; gsx_set_ordering(B)
+    (with or without gsx_set_amalgamation) re-allocates the arena for another tree — the fast paths (solve at lambda = 0,
+    marginals) must re-factor, not back-substitute through the new arena laid out for the old tree."""
+    arr = PROBLEMS[name]
+    gb, ob = gpu.product_backend(arr), oracle.oracle_backend(arr)
+    kinds = (A.ORDER_SCHUR_ND, A.ORDER_SCHUR) if name.startswith("bal") else (A.ORDER_ND, A.ORDER_MINDEGREE)
+    oa, obb = gb.compute_ordering(kinds[0]), gb.compute_ordering(kinds[1])
+    gb.set_ordering(oa)
+    ob.set_ordering(oa)
+    gb.linearize()
+    ob.linearize()
+    assert relerr(gb.solve(0.0, False), ob.solve(0.0, False)) < 1e-8
+    key = oa[len(oa) // 2]
+    co = ob.marginal_covariance(key)
+    assert np.max(np.abs(gb.marginal_covariance(key) - co)) <= 1e-7 * np.max(np.abs(co))
+    # new ordering, NO re-linearization: lambda = 0 again
+    gb.set_ordering(obb)
+    ob.set_ordering(obb)
+    ob.linearize()
+    assert relerr(gb.solve(0.0, False), ob.solve(0.0, False)) < 1e-8
+    assert np.max(np.abs(gb.marginal_covariance(key) - co)) <= 1e-7 * np.max(np.abs(co))
+    # ... and a change of amalgamation followed by the first ordering again, marginals first
+    gb.set_amalgamation(0.5, 64)
+    gb.set_ordering(oa)
+    assert np.max(np.abs(gb.marginal_covariance(key) - co)) <= 1e-7 * np.max(np.abs(co))
+    ob.set_ordering(oa)
+    assert relerr(gb.solve(0.0, False), ob.solve(0.0, False)) < 1e-8
+
+
+def test_failed_factorization_is_not_reused(gpu):
+    """An indeterminate Gauss-Newton run (lambda = 0 on a gauge-free graph) leaves a FAILED factorization in the arena:
+    a marginal query afterwards must report the failure again, not read the wreck; once a prior anchors the gauge the same
+    query works."""
+    fg = NonlinearFactorGraph()
+    for i in range(5):
+        fg.add(BetweenFactor(i, i + 1, Pose2(1, 0, 0.1), noiseModel.Isotropic.Sigma(3, 0.1)))
+    v = Values()
+    for i in range(6):
+        v.insert(i, Pose2(1.0 * i + 0.05 * i, 0.02 * i, 0.1 * i))
+    be = gpu.product_backend(fg.to_arrays(v))
+    be.set_ordering(list(range(6)))
+    with pytest.raises(gt.IndeterminantLinearSystemException):
+        be.gn_optimize(max_iterations=3)
+    with pytest.raises(gt.IndeterminantLinearSystemException):
+        be.marginal_covariance(2)
+    with pytest.raises(gt.IndeterminantLinearSystemException):
+        be.solve(0.0, False)
+    # damped: fine; then lambda = 0 again must re-factor (and fail again), not trust the damped factorization
+    be.linearize()
+    assert np.all(np.isfinite(be.solve(1e-3, False)))
+    with pytest.raises(gt.IndeterminantLinearSystemException):
+        be.solve(0.0, False)
