@@ -481,18 +481,20 @@ __global__ void __launch_bounds__(256) big_schur_kernel(const BigDesc* descs, in
   const double* pa = X + (rj + L.cq0 + L.li) + (i64)(c0 + L.lk) * n;
   const double* pb = X + (ri + row) + (i64)(c0 + L.lk) * n;
   v4d acc = {0.0, 0.0, 0.0, 0.0};
-  // the operands of up to 64 columns (16 k-steps) are requested together: the kernel is one or two memory round trips
-  for (int kk = 0; kk < fw; kk += 64) {
-    double a[16], b[16];
+  // the operands of the whole chunk (up to 48 k-steps) are requested together, straight-line: the kernel is ONE memory
+  // round trip (a loop that waits for its loads pays a round trip, > 1 us, per iteration)
+  {
+    constexpr int kSteps = kMaxChunk / 4;
+    double a[kSteps], b[kSteps];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const bool in = kk + 4 * s + L.lk < fw;
-      a[s] = (ain && in) ? pa[(i64)(kk + 4 * s) * n] : 0.0;
-      b[s] = (bin && in) ? pb[(i64)(kk + 4 * s) * n] : 0.0;
+    for (int s = 0; s < kSteps; ++s) {
+      const bool in = 4 * s + L.lk < fw;
+      a[s] = (ain && in) ? pa[(i64)(4 * s) * n] : 0.0;
+      b[s] = (bin && in) ? pb[(i64)(4 * s) * n] : 0.0;
     }
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
-      if (kk + 4 * s < fw) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
+    for (int s = 0; s < kSteps; ++s)
+      if (4 * s < fw) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q)
@@ -597,6 +599,170 @@ void launch_big_rows(const BigDesc* descs, int count, const BigPlan& plan, int r
 void launch_big_schur(const BigDesc* descs, int count, const BigPlan& plan, int round, double* arena, hipStream_t st) {
   if (!count || plan.pairs[round] <= 0) return;
   big_schur_kernel<<<dim3(plan.pairs[round], count), 256, 0, st>>>(descs, round * plan.chunk, plan.chunk, arena);
+}
+
+// ---- back-substitution of the blocked fronts of a level ----------------------------------------------------------------------
+// OptimizeClique (gtsam/linear/linearAlgorithms-inst.h:49-117) for a front kept in the blocked layout:
+//   L11' x_F = d - L21' x_S.
+// One workgroup per front.  Everything the sequential part needs is brought on chip ONCE, with all loads in flight
+// together: the strictly lower 32 x 32 tiles of L11 and the inverses of its diagonal tiles (left by big_diag) go to LDS
+// while the waves form y = d - L21' x_S column by column straight from the L panel (one pass over L21, the bulk of the
+// bytes).  The chain itself — for the column blocks from last to first: x_p = (L_pp^-1)' y_p, then y_k -= L_pk' x_p
+// for every k < p — then runs out of LDS: two barriers and ~64 multiply-adds per thread a block.
+namespace {
+constexpr int kBsThreads = 1024;
+constexpr int kBsMaxSep = 320;  // separator rows (+ rhs) the kernel's straight-line GEMV covers
+__global__ void __launch_bounds__(kBsThreads) backsolve_big_kernel(DevSymbolic S, const int* ids, const double* arena,
+                                                                   double* delta, DevStatus* status) {
+  extern __shared__ double sm[];
+  const int f = ids[blockIdx.x];
+  const int n = S.fr_N[f], F = S.fr_F[f];
+  const double* A = arena + S.fr_off[f];
+  const double* X = A + big_panel_offset(n);
+  const int* gi = S.gidx + S.gidx_ptr[f];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nk = (F + T - 1) / T;
+  // LDS: xs[n] (solution: frontal + separator), y[F rounded], inverse tiles [nk] packed by rows ((L^-1)[r][c], r >= c, at
+  // r (r + 1) / 2 + c), strictly lower tiles [(p, k), k < p][32][32] (L[32 p + r][32 k + c])
+  double* xs = sm;
+  double* y = xs + ((n + 1) & ~1);
+  double* xp = y + nk * T;        // the current block's solution (32)
+  double* inv = xp + T;
+  constexpr int kTri = T * (T + 1) / 2;
+  double* low = inv + (size_t)nk * kTri;
+  for (int r = F + tid; r < n - 1; r += kBsThreads) xs[r] = delta[gi[r]];
+  // tiles -> LDS, every load of a thread in flight before its first LDS store (a load -> store loop would pay one memory
+  // round trip per tile).  The inverse sits transposed in the strictly upper triangle of the diagonal tile
+  // ((L^-1)[r][c] at row c, column r): the fast index of its read is c.
+  {
+    constexpr int kMaxK = kMaxChunk / T, kMaxLow = kMaxK * (kMaxK - 1) / 2;
+    double vi[kMaxK], vl[kMaxLow];
+#pragma unroll
+    for (int q = 0; q < kMaxK; ++q) {  // thread tid: element (c = tid & 31, r = tid >> 5) of diagonal tile q
+      const int c = tid & 31, r = tid >> 5;
+      const int gr = q * T + r, gc = q * T + c;
+      vi[q] = 0.0;
+      if (q < nk && r >= c && gr < F) vi[q] = (r > c) ? A[gc + (i64)gr * n] : X[gr + (i64)gr * n];  // (diagonal: 1 / L_cc)
+    }
+    int tp = 1, tk = 0;  // tile (p, k), k < p, in the order t = p (p - 1) / 2 + k
+#pragma unroll
+    for (int t = 0; t < kMaxLow; ++t) {  // element (r = tid & 31, c = tid >> 5): rows below a diagonal tile, L-panel area
+      const int r = tid & 31, c = tid >> 5;
+      const int gr = tp * T + r, gc = tk * T + c;
+      vl[t] = (t < nk * (nk - 1) / 2 && gr < F) ? X[gr + (i64)gc * n] : 0.0;
+      if (++tk == tp) ++tp, tk = 0;
+    }
+#pragma unroll
+    for (int q = 0; q < kMaxK; ++q) {
+      const int c = tid & 31, r = tid >> 5;
+      if (q < nk && r >= c) inv[(size_t)q * kTri + r * (r + 1) / 2 + c] = vi[q];
+    }
+#pragma unroll
+    for (int t = 0; t < kMaxLow; ++t)
+      if (t < nk * (nk - 1) / 2) low[(size_t)t * T * T + (tid & 31) * T + (tid >> 5)] = vl[t];
+  }
+  __syncthreads();  // xs (separator part) is in place
+  // y[c] = d[c] - sum_{r >= F} L[r][c] xs[r]: wave w takes the columns w, w + 16, ...; lanes over the rows.  Straight-line
+  // code: the loads of six columns (up to 30 a lane) are all in flight before the first use — a loop that waits for its
+  // load costs a memory round trip (> 1 us) per iteration.
+  {
+    constexpr int kRC = kBsMaxSep / 64;  // row chunks of 64
+    double xr[kRC];
+#pragma unroll
+    for (int i = 0; i < kRC; ++i) {
+      const int r = F + lane + 64 * i;
+      xr[i] = (r < n - 1) ? xs[r] : 0.0;
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      double v[6][kRC], dv[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int c = wave + 16 * (6 * half + j);
+        const double* col = X + (i64)c * n;
+#pragma unroll
+        for (int i = 0; i < kRC; ++i) {
+          const int r = F + lane + 64 * i;
+          v[j][i] = (c < F && r < n - 1) ? col[r] : 0.0;
+        }
+        dv[j] = (c < F && lane == 0) ? col[n - 1] : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int c = wave + 16 * (6 * half + j);
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < kRC; ++i) acc += v[j][i] * xr[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+        if (lane == 0 && c < nk * T) y[c] = dv[j] - acc;   // (columns beyond F: 0)
+      }
+    }
+  }
+  __syncthreads();
+  for (int p = nk - 1; p >= 0; --p) {
+    // x_p = (L_pp^-1)' y_p:  x[c] = sum_{r >= c} (L^-1)[r][c] y[r]   (operands first, then the sum: LDS latency once)
+    if (tid < T) {
+      const double* iv = inv + (size_t)p * kTri;
+      double a[T], b[T];
+#pragma unroll
+      for (int r = 0; r < T; ++r) {
+        a[r] = (r >= tid) ? iv[r * (r + 1) / 2 + tid] : 0.0;
+        b[r] = y[p * T + r];
+      }
+      double acc = 0.0;
+#pragma unroll
+      for (int r = 0; r < T; ++r) acc = fma(a[r], b[r], acc);
+      xp[tid] = acc;
+      if (p * T + tid < F) xs[p * T + tid] = acc;
+    }
+    lds_bar();
+    // y_k -= L_pk' x_p for every k < p: thread c of the 32 p columns left of the block
+    if (tid < p * T) {
+      const int k = tid >> 5, c = tid & 31;
+      const double* lt = low + (size_t)(p * (p - 1) / 2 + k) * T * T;
+      double a[T], b[T];
+#pragma unroll
+      for (int r = 0; r < T; ++r) {
+        a[r] = lt[r * T + c];
+        b[r] = xp[r];
+      }
+      double acc = 0.0;
+#pragma unroll
+      for (int r = 0; r < T; ++r) acc = fma(a[r], b[r], acc);
+      y[tid] -= acc;
+    }
+    lds_bar();
+  }
+  int bad = 0;
+  for (int r = tid; r < F; r += kBsThreads) {
+    const double x = xs[r];
+    delta[gi[r]] = x;
+    if (!isfinite(x)) bad = 1;
+  }
+  if (bad) atomicAdd(&status->n_nonfinite, 1);
+}
+}  // namespace
+
+// LDS the kernel needs for a front with F frontal columns and n rows; 0 when it does not fit (the caller keeps the
+// generic back-substitution kernel for such a level)
+size_t backsolve_big_lds(int max_n, int max_F, int max_sep_rows) {
+  if (max_sep_rows > kBsMaxSep || max_F > kMaxChunk) return 0;
+  const size_t nk = (size_t)(max_F + T - 1) / T;
+  const size_t doubles = (((size_t)max_n + 1) & ~(size_t)1) + nk * T + T + nk * (T * (T + 1) / 2) + nk * (nk - 1) / 2 * T * T;
+  const size_t bytes = doubles * sizeof(double);
+  return bytes <= 160 * 1024 - 256 ? bytes : 0;
+}
+
+void launch_backsolve_big(const DevSymbolic& S, const int* ids, int count, int max_n, int max_F, const double* arena,
+                          double* delta, DevStatus* status, hipStream_t st) {
+  if (!count) return;
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)backsolve_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    attr = true;
+  }
+  backsolve_big_kernel<<<count, kBsThreads, backsolve_big_lds(max_n, max_F, 0), st>>>(S, ids, arena, delta, status);
 }
 
 }  // namespace gsx

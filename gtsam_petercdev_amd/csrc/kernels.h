@@ -160,6 +160,10 @@ struct GatherArgs {
 void launch_big_gather(const GatherArgs& G, int seg0, int nseg, int m0, int nm, double* arena, hipStream_t st);
 void launch_backsolve(const DevSymbolic& S, const int* ids, int count, int threads, int max_n, const double* arena,
                       double* delta, DevStatus* status, hipStream_t st);
+// blocked fronts of a level whose L11 tiles fit in LDS (bigfront.hip); backsolve_big_lds = 0: they do not, use the kernel above
+size_t backsolve_big_lds(int max_n, int max_F, int max_sep_rows);
+void launch_backsolve_big(const DevSymbolic& S, const int* ids, int count, int max_n, int max_F, const double* arena,
+                          double* delta, DevStatus* status, hipStream_t st);
 // leaf cliques of a level, a wave per clique
 void launch_backsolve_leaf(const DevSymbolic& S, const LeafRec* recs, int count, const double* arena, double* delta,
                            DevStatus* status, hipStream_t st);

@@ -1496,17 +1496,30 @@ __global__ void front_small_kernel(DevProblem P, DevSymbolic S, const int* ids, 
   int* cml = (int*)(L + (size_t)n * n);  // staging of a child's row map (n ints)
   const int nfv = S.fr_nfv[f];
   const int* fv = S.fvars + S.fr_fvar_ptr[f];
+  // (every loop below keeps several global loads of a lane in flight before their first use: a loop that waits for its
+  //  one load pays a memory round trip, more than a microsecond, per iteration)
   for (int k = wave; k < nfv; k += nw) {
     const VarRec vr = S.var_recs[fv[k]];
     const double* hp = H + vr.h_off;
     const int* hm = S.hmap + vr.hmap_off;
     const float rrows = 1.0f / (float)vr.rows;
-    for (int e = lane; e < vr.rows * vr.dA; e += 64) {
-      int r, j;
-      divmod_small(e, vr.rows, rrows, j, r);
-      double x = hp[e];
-      if (r == j) x += lambda * damp[vr.toff + j];  // rows 0..dA-1 of the panel are the variable itself
-      L[hm[r] + (vr.loc + j) * n] = x;
+    const int total = vr.rows * vr.dA;
+    for (int e0 = lane; e0 < total; e0 += 64 * 4) {
+      double x[4];
+      int hr[4], jj[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + 64 * u;
+        int r = 0, j = 0;
+        if (e < total) divmod_small(e, vr.rows, rrows, j, r);
+        jj[u] = j;
+        x[u] = (e < total) ? hp[e] : 0.0;
+        hr[u] = (e < total) ? hm[r] : 0;
+        if (e < total && r == j) x[u] += lambda * damp[vr.toff + j];  // rows 0..dA-1 of the panel are the variable itself
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (e0 + 64 * u < total) L[hr[u] + (vr.loc + jj[u]) * n] = x[u];
     }
   }
   __syncthreads();
@@ -1517,10 +1530,23 @@ __global__ void front_small_kernel(DevProblem P, DevSymbolic S, const int* ids, 
     for (int r = tid; r < cr.s1; r += nt) cml[r] = S.cmap[cr.cmap_off + r];
     __syncthreads();
     const double* src0 = arena + cr.src0;
-    for (int col = wave; col < cr.s1; col += nw) {
-      const int pc = cml[col] * n;
-      const double* src = src0 + (i64)col * cr.nc;
-      for (int r = col + lane; r < cr.s1; r += 64) L[cml[r] + pc] += src[r];
+    // a wave takes eight columns at a time (the lower part of each: rows col .. s1-1, 64 a pass)
+    for (int col0 = 8 * wave; col0 < cr.s1; col0 += 8 * nw) {
+      for (int rb = col0; rb < cr.s1; rb += 64) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int col = col0 + u, r = rb + lane;
+          v[u] = (col < cr.s1 && r >= col && r < cr.s1) ? src0[(i64)col * cr.nc + r] : 0.0;
+        }
+        const int r = rb + lane;
+        const int pr = (r < cr.s1) ? cml[r] : 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int col = col0 + u;
+          if (col < cr.s1 && r >= col && r < cr.s1) L[pr + cml[col] * n] += v[u];
+        }
+      }
     }
     __syncthreads();
   }

@@ -898,13 +898,35 @@ void dev_backsolve(gsx_context* c) {
     const BigLevel& B = c->big_level[l];
     const int se = S.lvl_small_end[l];
     const int le = S.lvl_leaf_end[l], n_rest = S.lvl_ptr[l + 1] - le;
-    if (n_rest > 0 && n_rest <= 512 && (B.count == 0 || n_rest > B.count)) {
+    // the blocked fronts of the level: their own kernel when L11's tiles fit in LDS (bigfront.hip)
+    int big_maxn = 0, big_maxF = 0, big_maxS = 0;
+    for (int k = se; k < S.lvl_ptr[l + 1]; ++k) {
+      big_maxn = std::max(big_maxn, S.N[S.sched[k]]);
+      big_maxF = std::max(big_maxF, S.F[S.sched[k]]);
+      big_maxS = std::max(big_maxS, S.N[S.sched[k]] - S.F[S.sched[k]]);
+    }
+    const bool big_own = B.count > 0 && backsolve_big_lds(big_maxn, big_maxF, big_maxS) > 0;
+    if (big_own) {
+      if (c->profiling > 0) timer_begin(c, PH_K_BACKSOLVE);
+      launch_backsolve_big(c->DS, c->d_sched.p + se, S.lvl_ptr[l + 1] - se, big_maxn, big_maxF, c->d_arena.p, c->d_delta.p,
+                           c->d_status.p, c->stream);
+      if (c->profiling > 0) timer_end(c, PH_K_BACKSOLVE);
+    }
+    const int n_small = se - le;
+    if (!big_own && n_rest > 0 && n_rest <= 512 && (B.count == 0 || n_rest > B.count)) {
       // few fronts: small and big ones of the level in ONE launch (the level costs one kernel latency, not 2-4)
       int maxn = 0;
       for (int k = le; k < S.lvl_ptr[l + 1]; ++k) maxn = std::max(maxn, S.N[S.sched[k]]);
       if (c->profiling > 0) timer_begin(c, PH_K_BACKSOLVE);
       launch_backsolve(c->DS, c->d_sched.p + le, n_rest, B.count ? 1024 : (maxn <= 48 ? 64 : 256), maxn, c->d_arena.p,
                        c->d_delta.p, c->d_status.p, c->stream);
+      if (c->profiling > 0) timer_end(c, PH_K_BACKSOLVE);
+    } else if (big_own && n_small > 0 && n_small <= 512) {
+      int maxn = 0;
+      for (int k = le; k < se; ++k) maxn = std::max(maxn, S.N[S.sched[k]]);
+      if (c->profiling > 0) timer_begin(c, PH_K_BACKSOLVE);
+      launch_backsolve(c->DS, c->d_sched.p + le, n_small, maxn <= 48 ? 64 : 256, maxn, c->d_arena.p, c->d_delta.p,
+                       c->d_status.p, c->stream);
       if (c->profiling > 0) timer_end(c, PH_K_BACKSOLVE);
     } else {
       // (the cliques of a level only read their parents' solution: their launches are independent — side by side)
@@ -913,7 +935,7 @@ void dev_backsolve(gsx_context* c) {
       const bool side = false;
       unsigned used = 0;
       int gi = 0;
-      if (B.count) {
+      if (B.count && !big_own) {
         int maxn = 0;
         for (int k = se; k < S.lvl_ptr[l + 1]; ++k) maxn = std::max(maxn, S.N[S.sched[k]]);
         if (c->profiling > 0) timer_begin(c, PH_K_BACKSOLVE);
