@@ -744,6 +744,84 @@ __global__ void __launch_bounds__(kBsThreads) backsolve_big_kernel(DevSymbolic S
 }
 }  // namespace
 
+// The LDS-class fronts (n <= kSmallMaxN) with at most 32 frontal columns — every level of a pose graph below the
+// blocked fronts: a level used to cost 20-25 us, a chain of dependent memory round trips (gather, then a loop of dot
+// products, then a substitution with a division per pivot).  Here every global load of the front — indices, the
+// triangle, the whole L21 panel, the right-hand side — is issued before anything waits (two round trips: the indices,
+// then the parents' solution), the dot products are 18 multiply-adds per thread out of registers, and the 32 pivots
+// are a straight-line chain of lane reads with the reciprocals taken beforehand.
+namespace {
+constexpr int kBsSmallF = 32, kBsSmallSep = 144;
+__global__ void __launch_bounds__(256) backsolve_small_kernel(DevSymbolic S, const int* ids, const double* arena,
+                                                              double* delta, DevStatus* status) {
+  __shared__ double xs[kBsSmallSep];
+  __shared__ double tile[kBsSmallF][kBsSmallF + 1];
+  __shared__ double part[2][kBsSmallF];
+  const int f = ids[blockIdx.x];
+  const int n = S.fr_N[f], F = S.fr_F[f], nS = n - 1 - F;
+  const double* A = arena + S.fr_off[f];
+  const int* gi = S.gidx + S.gidx_ptr[f];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = tid < nS ? gi[F + tid] : -1;
+  const int gf = tid < F ? gi[tid] : -1;
+  double tv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = tid + 256 * q, r = e & 31, c = e >> 5;
+    tv[q] = (r < F && c <= r) ? A[r + (i64)c * n] : (r == c ? 1.0 : 0.0);
+  }
+  // L21: the wave pair (wave & 1) takes 16 columns, the pair (wave >> 1) every other group of four rows; a lane reads
+  // four consecutive rows' worth with its three neighbours (lane >> 4)
+  constexpr int kSteps = kBsSmallSep / 8;
+  const int cg = 16 * (wave & 1) + (lane & 15), h = wave >> 1, rq = lane >> 4;
+  double lv[kSteps];
+  const double* col = A + (i64)cg * n + F + rq;
+#pragma unroll
+  for (int k = 0; k < kSteps; ++k) {
+    const int r0 = 4 * (h + 2 * k);
+    lv[k] = (cg < F && r0 + rq < nS) ? col[r0] : 0.0;
+  }
+  const double dv = tid < F ? A[(n - 1) + (i64)tid * n] : 0.0;
+  if (tid < kBsSmallSep) xs[tid] = g >= 0 ? delta[g] : 0.0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = tid + 256 * q;
+    tile[e & 31][e >> 5] = tv[q];
+  }
+  lds_bar();
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < kSteps; ++k) acc = fma(lv[k], xs[4 * (h + 2 * k) + rq], acc);
+  acc += __shfl_xor(acc, 16, 64);
+  acc += __shfl_xor(acc, 32, 64);
+  if (rq == 0) part[h][cg] = acc;
+  lds_bar();
+  if (wave != 0) return;
+  const int l = lane & 31;
+  double lc[kBsSmallF];
+#pragma unroll
+  for (int c = 0; c < kBsSmallF; ++c) lc[c] = tile[c][l];
+  const double dinv = 1.0 / tile[l][l];
+  double yr = lane < F ? dv - part[0][l] - part[1][l] : 0.0;
+#pragma unroll
+  for (int c = kBsSmallF - 1; c >= 0; --c) {
+    const double xc = readlane_f64(yr, c) * readlane_f64(dinv, c);
+    yr = lane == c ? xc : (lane < c ? fma(-lc[c], xc, yr) : yr);
+  }
+  if (lane < F) {
+    delta[gf] = yr;
+    if (!isfinite(yr)) atomicAdd(&status->n_nonfinite, 1);
+  }
+}
+}  // namespace
+
+bool backsolve_small_fits(int max_n, int max_F) { return max_F <= kBsSmallF && max_n <= kSmallMaxN && max_n - 2 <= kBsSmallSep; }
+
+void launch_backsolve_small(const DevSymbolic& S, const int* ids, int count, const double* arena, double* delta,
+                            DevStatus* status, hipStream_t st) {
+  if (count) backsolve_small_kernel<<<count, 256, 0, st>>>(S, ids, arena, delta, status);
+}
+
 // LDS the kernel needs for a front with F frontal columns and n rows; 0 when it does not fit (the caller keeps the
 // generic back-substitution kernel for such a level)
 size_t backsolve_big_lds(int max_n, int max_F, int max_sep_rows) {

@@ -44,6 +44,12 @@ struct ChildRec {
   i64 src0, cmap_off;   // arena offset of the child's Schur complement (top-left), offset of its row map
   int nc, s1, pad0, pad1;
 };
+// One LDS-class front: what front_small needs before its first data load, in one 32-byte record (the chain is
+// id -> record -> variable records (stored per front: fvar_recs) -> data)
+struct FrontRec {
+  i64 off;
+  int n, F, nfv, fvar_ptr, child_ptr, nchild;
+};
 
 // Symbolic tables on the device.
 struct DevSymbolic {
@@ -62,6 +68,8 @@ struct DevSymbolic {
   const TermRec* terms;
   const VarRec* var_recs;
   const ChildRec* child_recs;
+  const FrontRec* front_recs;   // per front
+  const VarRec* fvar_recs;      // var_recs in the order of fvars (a front's frontal variables are contiguous)
 };
 
 // status words written by the factorization / back-substitution kernels
@@ -164,6 +172,10 @@ void launch_backsolve(const DevSymbolic& S, const int* ids, int count, int threa
 size_t backsolve_big_lds(int max_n, int max_F, int max_sep_rows);
 void launch_backsolve_big(const DevSymbolic& S, const int* ids, int count, int max_n, int max_F, const double* arena,
                           double* delta, DevStatus* status, hipStream_t st);
+// LDS-class fronts with <= 32 frontal columns (bigfront.hip): all loads of a front in flight together
+bool backsolve_small_fits(int max_n, int max_F);
+void launch_backsolve_small(const DevSymbolic& S, const int* ids, int count, const double* arena, double* delta,
+                            DevStatus* status, hipStream_t st);
 // leaf cliques of a level, a wave per clique
 void launch_backsolve_leaf(const DevSymbolic& S, const LeafRec* recs, int count, const double* arena, double* delta,
                            DevStatus* status, hipStream_t st);

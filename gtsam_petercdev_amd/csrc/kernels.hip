@@ -1461,10 +1461,151 @@ __device__ inline int lds_partial_cholesky_t(double* L, int n, int F) {
   }
   return fail;
 }
+// ---------------------------------------------------------------------------------------------
+// The same partial Cholesky with the sequential part in REGISTERS (the scheme of bigfront.hip's big_diag): the
+// row-per-thread panel above costs ~1300 cycles a pivot (an LDS write -> barrier -> read round, an rsqrt and a chain of
+// dependent LDS reads), 16 us for the 30 frontal scalars of a typical pose-graph front — most of a front's life.
+// Here, per panel of 16 columns:
+//   D. wave 0 holds the diagonal 16 x 16 tile in the matrix-core accumulator layout (lane (li, lk): entries (row li,
+//      column 4 q + lk)) and factors it with no LDS traffic and no barrier: per pivot one v_readlane, an rsqrt, and ONE
+//      rank-1 matrix-core update of the tile; an identity tile carried through the same column operations comes out as
+//      L_pp^-T (~280 cycles a pivot, measured).  Columns / rows beyond F are identity padding.
+//   X. every 16-row tile below: X = A_ip L_pp^-T, four matrix-core instructions (the tile itself is the row-side
+//      operand), in place.
+//   U. rank-16 update of the trailing matrix from the panel's columns, one wave per 16 x 16 tile.
+// Three workgroup barriers a panel (free for the one-wave fronts).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double tile_rsqrt(double d) {  // 1 / sqrt(d) from the hardware seed + one cubic correction
+  const double y0 = __builtin_amdgcn_rsq(d);
+  const double e = fma(-d * y0, y0, 1.0);
+  return fma(y0 * e, fma(e, 0.375, 0.5), y0);
+}
+__device__ __forceinline__ double tile_readlane(double v, int src_lane) {  // src_lane wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+__device__ inline int lds_partial_cholesky_mfma(double* Lm, int n, int F) {
+  __shared__ double Eb[16 * 17];  // (L_pp^-1)[i][c] of the current panel at i * 17 + c
+  __shared__ int failed;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  if (tid == 0) failed = 0;
+  for (int jb = 0; jb < F; jb += 16) {
+    const int w = min(16, F - jb), rb = jb + w;
+    if (wave == 0) {
+      v4d pt, E;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = jb + li, c = jb + 4 * q + lk;
+        pt[q] = (r < F && c < F) ? (r >= c ? Lm[r + c * n] : 0.0) : (r == c ? 1.0 : 0.0);
+        E[q] = (li == 4 * q + lk) ? 1.0 : 0.0;
+      }
+      // (straight-line: a branch between a matrix-core instruction and the v_readlane of its result hides the
+      //  dependency from the compiler's hazard padding)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int q = j >> 2, lkj = j & 3;
+        __builtin_amdgcn_sched_barrier(0);
+        int lj = li;
+        asm volatile("" : "+v"(lj));
+        const double dj = tile_readlane(pt[q], lkj * 16 + j);
+        const double sj = tile_rsqrt(dj);  // (a non-positive pivot makes L_jj a NaN: caught below)
+        const bool colj = lk == lkj;
+        const double xj = pt[q] * sj;
+        const double xm = (colj && lj >= j) ? xj : 0.0;
+        const double ej = colj ? E[q] * sj : 0.0;
+        pt[q] = colj ? xm : pt[q];
+        E[q] = colj ? ej : E[q];
+        if (j < 15) {
+          const double xu = (lj > j) ? xm : 0.0;
+          pt = __builtin_amdgcn_mfma_f64_16x16x4f64(-xu, xu, pt, 0, 0, 0);
+          E = __builtin_amdgcn_mfma_f64_16x16x4f64(-xu, ej, E, 0, 0, 0);
+        }
+      }
+      if (lk == (li & 3)) {  // entry (li, li) sits in the lane with lk = li & 3, register li >> 2
+        const int qd = li >> 2;
+        const double l = (qd == 0) ? pt[0] : ((qd == 1) ? pt[1] : ((qd == 2) ? pt[2] : pt[3]));
+        if (jb + li < F && !(l > 0)) failed = 1;  // non-positive or non-finite pivot (Eigen::LLT NumericalIssue)
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = jb + li, c = jb + 4 * q + lk;
+        if (r < F && c < F && r >= c) Lm[r + c * n] = pt[q];
+        Eb[(4 * q + lk) * 17 + li] = E[q];  // E[row li][col 4q+lk] = (L^-1)[4q+lk][li]
+      }
+    }
+    __syncthreads();
+    const int m = n - rb, T16 = (m + 15) >> 4;
+    for (int t = wave; t < T16; t += nw) {
+      const int r = rb + 16 * t + li;
+      v4d nv = {0.0, 0.0, 0.0, 0.0};
+      double pv[4], av[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        pv[s] = (r < n && 4 * s + lk < w) ? Lm[r + (jb + 4 * s + lk) * n] : 0.0;
+        av[s] = Eb[li * 17 + 4 * s + lk];
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) nv = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], pv[s], nv, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (r < n && 4 * q + lk < w) Lm[r + (jb + 4 * q + lk) * n] = nv[q];
+    }
+    __syncthreads();
+    {
+      const int ntiles = T16 * (T16 + 1) / 2;
+      for (int t = wave; t < ntiles; t += nw) {
+        int ti = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        while (ti * (ti + 1) / 2 > t) --ti;
+        const int tj = t - ti * (ti + 1) / 2;
+        const int i0 = rb + ti * 16, c0 = rb + tj * 16;
+        const int col = c0 + li;
+        v4d acc;
+        double av[4], bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int rr = i0 + lk + 4 * q;
+          acc[q] = (rr < n && col < n) ? Lm[rr + col * n] : 0.0;
+          const int k = 4 * q + lk;
+          av[q] = (k < w && i0 + li < n) ? -Lm[(i0 + li) + (jb + k) * n] : 0.0;
+          bv[q] = (k < w && c0 + li < n) ? Lm[(c0 + li) + (jb + k) * n] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int rr = i0 + lk + 4 * q;
+          if (rr < n && col < n) Lm[rr + col * n] = acc[q];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  int fail = failed;
+  // conditioning test on the last two pivots — cholesky.cpp:145-158
+  if (F >= 2) {
+    int e2, e1;
+    (void)frexp(Lm[(F - 2) + (F - 2) * n], &e2);
+    (void)frexp(Lm[(F - 1) + (F - 1) * n], &e1);
+    if (!(e2 - e1 < 12)) fail = 1;
+  } else if (F == 1) {
+    int e1;
+    (void)frexp(Lm[0], &e1);
+    if (!(e1 > -12)) fail = 1;
+  }
+  return fail;
+}
 // panel width by frontal size: narrow panels keep the per-pivot register work small for the many cliques
 // with a handful of frontal scalars, wide panels halve the number of trailing sweeps of the larger ones
 __device__ inline int lds_partial_cholesky(double* L, int n, int F) {
+#ifdef GSX_OLD_LDS_CHOLESKY
   return (F <= 24) ? lds_partial_cholesky_t<8>(L, n, F) : lds_partial_cholesky_t<16>(L, n, F);
+#else
+  return lds_partial_cholesky_mfma(L, n, F);
+#endif
 }
 
 __device__ inline void report_failure(DevStatus* status, int front) {
@@ -1480,77 +1621,145 @@ __device__ inline void report_failure(DevStatus* status, int front) {
 //   4. L panel -> arena (kept for back-substitution); Schur complement -> arena (pulled by a small
 //      parent, gathered by a big one).
 // ---------------------------------------------------------------------------------------------
-__global__ void front_small_kernel(DevProblem P, DevSymbolic S, const int* ids, const double* H, const double* damp,
+constexpr int kVarStage = 32, kChildStage = 16;
+#ifdef GSX_STAMP
+__device__ unsigned long long g_fs_stamp[12];
+#define FS_BEGIN unsigned long long fs0__ = wall_clock64();
+#define FS_ADD(slot)                                                                  \
+  {                                                                                   \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                       \
+    unsigned long long t__ = wall_clock64();                                          \
+    if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) g_fs_stamp[slot] = t__ - fs0__; \
+    fs0__ = t__;                                                                      \
+  }
+#else
+#define FS_BEGIN
+#define FS_ADD(slot)
+#endif
+__global__ void __launch_bounds__(512) front_small_kernel(DevProblem P, DevSymbolic S, const int* ids, const double* H, const double* damp,
                                    const double* scalars, double* arena, DevStatus* status) {
   extern __shared__ double L[];
+  __shared__ VarRec vrec[kVarStage];
+  __shared__ int vpre[kVarStage + 1];
+  __shared__ ChildRec crec[kChildStage];
+  FS_BEGIN
   const int f = ids[blockIdx.x];
-  const int n = S.fr_N[f], F = S.fr_F[f];
-  const i64 off = S.fr_off[f];
+  const FrontRec fr = S.front_recs[f];
+  const int n = fr.n, F = fr.F;
+  const i64 off = fr.off;
   const int tid = threadIdx.x, nt = blockDim.x;
   const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
   const double lambda = scalars[SC_LAMBDA];
+  // A front this small is a chain of dependent memory round trips (more than a microsecond each), not bytes or flops:
+  // the records of its variables and children are staged in LDS by one round trip, and every loop below puts all the
+  // loads of a lane in flight before the first LDS store that needs one.
+  int* cml = (int*)(L + (size_t)n * n);  // staging of two children's row maps (2 x n ints)
+  const int nfv = fr.nfv, nchild = fr.nchild;
+  if (tid < min(nfv, kVarStage)) vrec[tid] = S.fvar_recs[fr.fvar_ptr + tid];
+  if (tid < min(nchild, kChildStage)) crec[tid] = S.child_recs[fr.child_ptr + tid];
   for (int e = tid; e < n * n; e += nt) L[e] = 0;
-  __syncthreads();
-  // H panels of the frontal variables: one wave per variable (disjoint columns), metadata packed in one
-  // 32-byte record per variable so that the dependent-load chain is record -> data.
-  int* cml = (int*)(L + (size_t)n * n);  // staging of a child's row map (n ints)
-  const int nfv = S.fr_nfv[f];
-  const int* fv = S.fvars + S.fr_fvar_ptr[f];
-  // (every loop below keeps several global loads of a lane in flight before their first use: a loop that waits for its
-  //  one load pays a memory round trip, more than a microsecond, per iteration)
-  for (int k = wave; k < nfv; k += nw) {
-    const VarRec vr = S.var_recs[fv[k]];
-    const double* hp = H + vr.h_off;
-    const int* hm = S.hmap + vr.hmap_off;
-    const float rrows = 1.0f / (float)vr.rows;
-    const int total = vr.rows * vr.dA;
-    for (int e0 = lane; e0 < total; e0 += 64 * 4) {
-      double x[4];
-      int hr[4], jj[4];
+  FS_ADD(0)
+  for (int k0 = 0; k0 < nfv; k0 += kVarStage) {
+    const int nb = min(kVarStage, nfv - k0);
+    if (k0 > 0) {
+      __syncthreads();
+      if (tid < nb) vrec[tid] = S.fvar_recs[fr.fvar_ptr + k0 + tid];
+    }
+    __syncthreads();
+    if (tid <= nb) {
+      int s = 0;
+      for (int k = 0; k < tid; ++k) s += vrec[k].rows * vrec[k].dA;
+      vpre[tid] = s;
+    }
+    __syncthreads();
+    // H panels of the staged variables, one flat index space over (variable, entry)
+    const int total = vpre[nb];
+    constexpr int U = 8;
+    for (int e0 = tid; e0 < total; e0 += nt * U) {
+      double x[U];
+      int dst[U];
+      int k = 0;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int e = e0 + 64 * u;
-        int r = 0, j = 0;
-        if (e < total) divmod_small(e, vr.rows, rrows, j, r);
-        jj[u] = j;
-        x[u] = (e < total) ? hp[e] : 0.0;
-        hr[u] = (e < total) ? hm[r] : 0;
-        if (e < total && r == j) x[u] += lambda * damp[vr.toff + j];  // rows 0..dA-1 of the panel are the variable itself
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + nt * u;
+        x[u] = 0.0;
+        dst[u] = -1;
+        if (e < total) {
+          while (e >= vpre[k + 1]) ++k;
+          const VarRec vr = vrec[k];
+          const int el = e - vpre[k];
+          int r, j;
+          divmod_small(el, vr.rows, 1.0f / (float)vr.rows, j, r);
+          x[u] = H[vr.h_off + el];
+          dst[u] = S.hmap[vr.hmap_off + r] + (vr.loc + j) * n;
+          if (r == j) x[u] += lambda * damp[vr.toff + j];  // rows 0..dA-1 of the panel are the variable itself
+        }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (e0 + 64 * u < total) L[hr[u] + (vr.loc + jj[u]) * n] = x[u];
+      for (int u = 0; u < U; ++u)
+        if (dst[u] >= 0) L[dst[u]] = x[u];
     }
   }
+  // extend-add of the children, in child order.  A child's row map is staged in LDS (no dependent global loads in the
+  // entry loop) while the previous child is being added; its Schur complement is one flat index space over the lower
+  // triangle, sixteen loads a lane in flight.
+  FS_ADD(1)
+  auto child = [&](int k) -> ChildRec { return k < kChildStage ? crec[k] : S.child_recs[fr.child_ptr + k]; };
+  if (nchild > 0) {
+    const ChildRec c0 = child(0);
+    for (int r = tid; r < c0.s1; r += nt) cml[r] = S.cmap[c0.cmap_off + r];
+  }
   __syncthreads();
-  // extend-add of the children, in child order; the child's row map is staged in LDS first so that the
-  // column loop has no dependent global loads (only the streaming reads of the Schur complement).
-  for (int ci = S.fr_child_ptr[f]; ci < S.fr_child_ptr[f + 1]; ++ci) {
-    const ChildRec cr = S.child_recs[ci];
-    for (int r = tid; r < cr.s1; r += nt) cml[r] = S.cmap[cr.cmap_off + r];
-    __syncthreads();
+  for (int ci = 0; ci < nchild; ++ci) {
+    const ChildRec cr = child(ci);
+    const int* cm = cml + (ci & 1) * n;
+    // the next child's row map: requested now, stored after this child's entries
+    int nxt[3] = {0, 0, 0};
+    ChildRec cn = cr;
+    if (ci + 1 < nchild) {
+      cn = child(ci + 1);
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+        if (tid + nt * u < cn.s1) nxt[u] = S.cmap[cn.cmap_off + tid + nt * u];
+    }
     const double* src0 = arena + cr.src0;
-    // a wave takes eight columns at a time (the lower part of each: rows col .. s1-1, 64 a pass)
-    for (int col0 = 8 * wave; col0 < cr.s1; col0 += 8 * nw) {
-      for (int rb = col0; rb < cr.s1; rb += 64) {
-        double v[8];
+    const int s1 = cr.s1, tot = s1 * (s1 + 1) / 2;
+    const float b = (float)(2 * s1 + 1);
+    constexpr int U = 16;
+    for (int e0 = tid; e0 < tot; e0 += nt * U) {
+      double v[U];
+      int dst[U];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int col = col0 + u, r = rb + lane;
-          v[u] = (col < cr.s1 && r >= col && r < cr.s1) ? src0[(i64)col * cr.nc + r] : 0.0;
-        }
-        const int r = rb + lane;
-        const int pr = (r < cr.s1) ? cml[r] : 0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int col = col0 + u;
-          if (col < cr.s1 && r >= col && r < cr.s1) L[pr + cml[col] * n] += v[u];
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + nt * u;
+        v[u] = 0.0;
+        dst[u] = -1;
+        if (e < tot) {
+          // column c of the lower triangle starts at entry c s1 - c (c - 1) / 2
+          int c = (int)((b - sqrtf(b * b - 8.0f * (float)e)) * 0.5f);
+          c = max(0, min(c, s1 - 1));
+          if (c + 1 < s1 && (c + 1) * s1 - (c + 1) * c / 2 <= e) ++c;
+          if (c * s1 - c * (c - 1) / 2 > e) --c;
+          const int r = c + (e - (c * s1 - c * (c - 1) / 2));
+          v[u] = src0[(i64)c * cr.nc + r];
+          dst[u] = cm[r] + cm[c] * n;
         }
       }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (dst[u] >= 0) L[dst[u]] += v[u];
+    }
+    if (ci + 1 < nchild) {
+      int* cmn = cml + ((ci + 1) & 1) * n;
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+        if (tid + nt * u < cn.s1) cmn[tid + nt * u] = nxt[u];
     }
     __syncthreads();
   }
+  FS_ADD(2)
   const int fail = lds_partial_cholesky(L, n, F);
+  FS_ADD(3)
   if (fail && tid == 0) report_failure(status, f);
   // L panel
   double* A = arena + off;
@@ -1560,6 +1769,10 @@ __global__ void front_small_kernel(DevProblem P, DevSymbolic S, const int* ids, 
   const int s1 = n - F;
   for (int col = wave; col < s1; col += nw)
     for (int r = col + lane; r < s1; r += 64) A[(F + r) + (i64)(F + col) * n] = L[(F + r) + (F + col) * n];
+  FS_ADD(4)
+#ifdef GSX_STAMP
+  if (tid == 0 && blockIdx.x == gridDim.x / 2) { g_fs_stamp[5] = n; g_fs_stamp[6] = F; g_fs_stamp[7] = nchild; g_fs_stamp[8] = nfv; }
+#endif
 }
 
 void launch_front_small(const DevProblem& P, const DevSymbolic& S, const int* ids, int count, int max_n, int threads,
@@ -1567,12 +1780,21 @@ void launch_front_small(const DevProblem& P, const DevSymbolic& S, const int* id
                         hipStream_t st) {
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute((const void*)front_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    hipFuncSetAttribute((const void*)front_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
     attr = true;
   }
   if (count)
     front_small_kernel<<<count, threads, ((size_t)max_n * max_n + max_n) * sizeof(double), st>>>(P, S, ids, H, damp, scalars,
                                                                                          arena, status);
+#ifdef GSX_STAMP
+  if (count) {
+    unsigned long long h[12];
+    hipStreamSynchronize(st);
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fs_stamp), sizeof(h));
+    printf("[fs] count %6d thr %3d max_n %3d | wg n=%3llu F=%3llu ch=%llu nfv=%llu | x10ns: head %llu  H %llu  children %llu  chol %llu  store %llu\n",
+           count, threads, max_n, h[5], h[6], h[7], h[8], h[0], h[1], h[2], h[3], h[4]);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2469,7 +2691,7 @@ void launch_dense_partial(double* a, int n, int nf, DevStatus* status, hipStream
   if (n <= kSmallMaxN) {
     static bool attr = false;
     if (!attr) {
-      hipFuncSetAttribute((const void*)dense_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+      hipFuncSetAttribute((const void*)dense_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
       attr = true;
     }
     dense_small_kernel<<<1, 512, (size_t)n * n * sizeof(double), st>>>(a, n, nf, status);

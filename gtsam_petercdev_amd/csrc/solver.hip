@@ -112,6 +112,8 @@ struct gsx_context {
   DevBuf<TermRec> d_terms;
   DevBuf<VarRec> d_var_recs;
   DevBuf<ChildRec> d_child_recs;
+  DevBuf<FrontRec> d_front_recs;
+  DevBuf<VarRec> d_fvar_recs;
   DevBuf<LeafRec> d_leaf_recs;   // leaf-kernel cliques of level 0, in schedule order
   int leaf_base = 0;             // schedule position of d_leaf_recs[0]
   DevBuf<int> d_fr_N, d_fr_F, d_fr_nfv, d_fr_fvar_ptr, d_fvars, d_fr_parent, d_fr_lean, d_fr_child_ptr, d_children, d_cmap,
@@ -418,8 +420,16 @@ gsx_status upload_symbolic(gsx_context* c) {
       crec[i] = ChildRec{(i64)S.off[ch] + (i64)S.F[ch] * S.N[ch] + S.F[ch], (i64)S.cmap_ptr[ch], S.N[ch],
                          S.N[ch] - S.F[ch], 0, 0};
     }
+    std::vector<VarRec> fvrec(S.fvars.size());
+    for (size_t i = 0; i < fvrec.size(); ++i) fvrec[i] = vrec[S.fvars[i]];
+    std::vector<FrontRec> frec(S.n_fronts);
+    for (int f = 0; f < S.n_fronts; ++f)
+      frec[f] = FrontRec{(i64)S.off[f], S.N[f], S.F[f], S.nfrontal_vars[f], S.fvar_ptr[f], S.child_ptr[f],
+                         S.child_ptr[f + 1] - S.child_ptr[f]};
     HIPCHK(c, c->d_var_recs.upload(vrec, st));
     HIPCHK(c, c->d_child_recs.upload(crec, st));
+    HIPCHK(c, c->d_front_recs.upload(frec, st));
+    HIPCHK(c, c->d_fvar_recs.upload(fvrec, st));
     HIPCHK(c, hipStreamSynchronize(st));
   }
   HIPCHK(c, c->d_sched.upload(S.sched, st));
@@ -706,6 +716,7 @@ gsx_status upload_symbolic(gsx_context* c) {
   D.h_loc = c->d_h_loc.p;
   D.term_ptr = c->d_term_ptr.p; D.terms = c->d_terms.p;
   D.var_recs = c->d_var_recs.p; D.child_recs = c->d_child_recs.p;
+  D.front_recs = c->d_front_recs.p; D.fvar_recs = c->d_fvar_recs.p;
   HIPCHK(c, hipStreamSynchronize(st));
   // a new tree: the arena and H were re-allocated for it — nothing computed for the old one may be reused
   c->h_ready = false;
@@ -912,54 +923,44 @@ void dev_backsolve(gsx_context* c) {
                            c->d_status.p, c->stream);
       if (c->profiling > 0) timer_end(c, PH_K_BACKSOLVE);
     }
+    // the LDS-class fronts: their own kernel when every one of them has at most 32 frontal columns
     const int n_small = se - le;
-    if (!big_own && n_rest > 0 && n_rest <= 512 && (B.count == 0 || n_rest > B.count)) {
-      // few fronts: small and big ones of the level in ONE launch (the level costs one kernel latency, not 2-4)
+    int small_maxn = 0, small_maxF = 0;
+    for (int k = le; k < se; ++k) {
+      small_maxn = std::max(small_maxn, S.N[S.sched[k]]);
+      small_maxF = std::max(small_maxF, S.F[S.sched[k]]);
+    }
+    const bool small_own = n_small > 0 && backsolve_small_fits(small_maxn, small_maxF);
+    if (small_own) {
+      if (c->profiling > 0) timer_begin(c, PH_K_BACKSOLVE);
+      launch_backsolve_small(c->DS, c->d_sched.p + le, n_small, c->d_arena.p, c->d_delta.p, c->d_status.p, c->stream);
+      if (c->profiling > 0) timer_end(c, PH_K_BACKSOLVE);
+    }
+    const bool big_left = B.count > 0 && !big_own, small_left = n_small > 0 && !small_own;
+    if (big_left && small_left && n_rest <= 512 && n_rest > B.count) {
+      // few fronts: small and big ones of the level in ONE launch of the generic kernel
       int maxn = 0;
       for (int k = le; k < S.lvl_ptr[l + 1]; ++k) maxn = std::max(maxn, S.N[S.sched[k]]);
       if (c->profiling > 0) timer_begin(c, PH_K_BACKSOLVE);
-      launch_backsolve(c->DS, c->d_sched.p + le, n_rest, B.count ? 1024 : (maxn <= 48 ? 64 : 256), maxn, c->d_arena.p,
-                       c->d_delta.p, c->d_status.p, c->stream);
-      if (c->profiling > 0) timer_end(c, PH_K_BACKSOLVE);
-    } else if (big_own && n_small > 0 && n_small <= 512) {
-      int maxn = 0;
-      for (int k = le; k < se; ++k) maxn = std::max(maxn, S.N[S.sched[k]]);
-      if (c->profiling > 0) timer_begin(c, PH_K_BACKSOLVE);
-      launch_backsolve(c->DS, c->d_sched.p + le, n_small, maxn <= 48 ? 64 : 256, maxn, c->d_arena.p, c->d_delta.p,
-                       c->d_status.p, c->stream);
+      launch_backsolve(c->DS, c->d_sched.p + le, n_rest, 1024, maxn, c->d_arena.p, c->d_delta.p, c->d_status.p, c->stream);
       if (c->profiling > 0) timer_end(c, PH_K_BACKSOLVE);
     } else {
-      // (the cliques of a level only read their parents' solution: their launches are independent — side by side)
-      // — measured: the launches of a back-substitution level are too short (20-50 us each) to pay for the ~85 us of
-      // cross-queue event latency of a fork + join; kept on the main stream
-      const bool side = false;
-      unsigned used = 0;
-      int gi = 0;
-      if (B.count && !big_own) {
+      if (big_left) {
         int maxn = 0;
         for (int k = se; k < S.lvl_ptr[l + 1]; ++k) maxn = std::max(maxn, S.N[S.sched[k]]);
         if (c->profiling > 0) timer_begin(c, PH_K_BACKSOLVE);
         launch_backsolve(c->DS, c->d_sched.p + se, S.lvl_ptr[l + 1] - se, 1024, maxn, c->d_arena.p, c->d_delta.p,
-                         c->d_status.p, side ? side_stream(c, gi++, &used) : c->stream);
+                         c->d_status.p, c->stream);
         if (c->profiling > 0) timer_end(c, PH_K_BACKSOLVE);
       }
-      // the size groups of the factorization (split by LDS footprint) mean nothing here — the back-substitution keeps
-      // only n - 1 doubles per clique in LDS: all the level's LDS-class cliques go in ONE launch (a level's
-      // launches are each bound by the latency of one clique, 20-50 us)
-      const std::vector<SmallLaunch>& G = c->small_launch[l];
-      for (size_t k = 0; k < G.size();) {
-        size_t e = k;
-        int total = 0, maxn = 0;
-        while (e < G.size() && G[e].begin == G[k].begin + total) {
-          total += G[e].count;
-          maxn = std::max(maxn, G[e].max_n);
-          ++e;
-        }
-        launch_backsolve(c->DS, c->d_sched.p + G[k].begin, total, maxn <= 48 ? 64 : 256, maxn, c->d_arena.p, c->d_delta.p,
-                         c->d_status.p, side ? side_stream(c, gi++, &used) : c->stream);
-        k = e;
+      if (small_left) {
+        // the size groups of the factorization (split by LDS footprint) mean nothing here — the generic kernel keeps
+        // only n - 1 doubles per clique in LDS: all the level's LDS-class cliques go in ONE launch
+        if (c->profiling > 0) timer_begin(c, PH_K_BACKSOLVE);
+        launch_backsolve(c->DS, c->d_sched.p + le, n_small, small_maxn <= 48 ? 64 : 256, small_maxn, c->d_arena.p,
+                         c->d_delta.p, c->d_status.p, c->stream);
+        if (c->profiling > 0) timer_end(c, PH_K_BACKSOLVE);
       }
-      if (side) side_join(c, used);
     }
     // all leaf-kernel cliques of the level in one launch (a wave each)
     if (S.lvl_leaf_end[l] > S.lvl_ptr[l])
