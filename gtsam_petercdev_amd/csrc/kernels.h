@@ -177,8 +177,8 @@ bool backsolve_small_fits(int max_n, int max_F);
 void launch_backsolve_small(const DevSymbolic& S, const int* ids, int count, const double* arena, double* delta,
                             DevStatus* status, hipStream_t st);
 // leaf cliques of a level, a wave per clique
-void launch_backsolve_leaf(const DevSymbolic& S, const LeafRec* recs, int count, const double* arena, double* delta,
-                           DevStatus* status, hipStream_t st);
+void launch_backsolve_leaf(const DevSymbolic& S, const LeafRec* recs, int count, int max_F, const double* arena,
+                           double* delta, DevStatus* status, hipStream_t st);
 // Dogleg (gtsam/nonlinear/DoglegOptimizerImpl.*): gradient g = A'b out of the H panels' rhs rows, |A x|^2 over the
 // linearized graph, dot products and out = alpha a + beta b on tangent vectors (deterministic two-stage reductions)
 void launch_gradient(const DevProblem& P, const DevSymbolic& S, const double* H, double* g, hipStream_t st);

@@ -1829,12 +1829,27 @@ __global__ void front_leaf_kernel(DevProblem P, DevSymbolic S, const LeafRec* re
       hm = S.hmap + vr.hmap_off;
     }
     const float rrows = 1.0f / (float)rows;
-    for (int e = tid; e < rows * dA; e += nt) {
-      int r, j;
-      divmod_small(e, rows, rrows, j, r);
-      double x = hp[e];
-      if (r == j) x += lambda * damp[toff + j];
-      Pn[hm[r] + (c0 + j) * n] = x;
+    const int total = rows * dA;
+    // (four loads a lane in flight before the first LDS store: a load -> store loop pays a memory round trip per pass)
+    for (int e0 = tid; e0 < total; e0 += nt * 4) {
+      double x[4];
+      int dst[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + nt * u;
+        x[u] = 0.0;
+        dst[u] = -1;
+        if (e < total) {
+          int r, j;
+          divmod_small(e, rows, rrows, j, r);
+          x[u] = hp[e];
+          if (r == j) x[u] += lambda * damp[toff + j];
+          dst[u] = hm[r] + (c0 + j) * n;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (dst[u] >= 0) Pn[dst[u]] = x[u];
     }
   }
   __syncthreads();
@@ -1949,7 +1964,13 @@ __device__ __forceinline__ void lean_group_mfma(const LeanGroup& g, v4d& acc) {
 
 __global__ void __launch_bounds__(256) big_gather_seg_kernel(GatherArgs G, int seg0, int nseg, double* arena) {
   const int lane = threadIdx.x & 63;
-  const int sw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  // Workgroups go round-robin over the 8 XCDs, each with its own L2.  The segments are sorted by destination front and
+  // a child's panel is read by every destination block it touches — all in its parent: XCD x takes the x-th contiguous
+  // eighth of the segments, so that a panel is fetched into ONE L2 instead of all eight (measured before: 5.6 x the
+  // algorithmic bytes fetched from HBM).
+  const int per_xcd = gridDim.x >> 3;
+  const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int sw = __builtin_amdgcn_readfirstlane(wg * 4 + (threadIdx.x >> 6));
   if (sw >= nseg) return;
   const GatherSeg sg = G.segs[seg0 + sw];  // one 32-byte record through the scalar path
   const int dB = sg.dims & 255, dA = (sg.dims >> 8) & 255, diag = sg.dims >> 16;
@@ -2059,7 +2080,7 @@ __global__ void __launch_bounds__(256) big_gather_combine_kernel(GatherArgs G, i
 }
 
 void launch_big_gather(const GatherArgs& G, int seg0, int nseg, int m0, int nm, double* arena, hipStream_t st) {
-  if (nseg > 0) big_gather_seg_kernel<<<(nseg + 3) / 4, 256, 0, st>>>(G, seg0, nseg, arena);
+  if (nseg > 0) big_gather_seg_kernel<<<((nseg + 31) / 32) * 8, 256, 0, st>>>(G, seg0, nseg, arena);  // a multiple of 8 workgroups
   if (nm > 0) big_gather_combine_kernel<<<(nm + 3) / 4, 256, 0, st>>>(G, m0, nm, arena);
 }
 
@@ -2601,8 +2622,11 @@ __global__ void backsolve_kernel(DevSymbolic S, const int* ids, const double* ar
 // (A thread-per-column, right-looking variant for big fronts — separator part first, panel rows prefetched into
 //  registers two panels ahead — was built and measured: 36-65 us per level against 25-39 us for the kernel above.)
 // Leaf cliques (F <= kLeafMaxF: BAL landmarks, pose-graph leaves): one WAVE per clique, four per workgroup, no
-// barriers.  The separator part of the solution is gathered once per lane (rows lane, lane + 64, ...), each frontal
-// column is a wave-wide dot product, and the F x F triangle is solved by substitution on the reduced values.
+// barriers.  A wave is a chain of dependent memory round trips and nothing else, so everything that needs only the
+// clique's record — the row indices, the rows of L21 for the first 128 separator rows, the rhs row, the F x F
+// triangle — is requested together; the parents' solution is the second round trip, the store the third.
+// FM = the launch's largest F rounded up (register arrays are sized by it).
+template <int FM>
 __global__ void __launch_bounds__(256) backsolve_leaf_kernel(DevSymbolic S, const LeafRec* recs, int count,
                                                              const double* arena, double* delta, DevStatus* status) {
   const int lane = threadIdx.x & 63;
@@ -2612,52 +2636,74 @@ __global__ void __launch_bounds__(256) backsolve_leaf_kernel(DevSymbolic S, cons
   const int n = rec.n, F = rec.F;
   const double* A = arena + rec.off;
   const int* gi = S.gidx + rec.gidx_ptr;
-  // y_c = d_c - sum_{r >= F} L[r][c] x_r, c < F
-  double yc[kLeafMaxF];
+  constexpr int U = 2;
+  int g[U];
+  double a[U][FM];
 #pragma unroll
-  for (int cidx = 0; cidx < kLeafMaxF; ++cidx) yc[cidx] = 0.0;
-  for (int r = F + lane; r < n - 1; r += 64) {
+  for (int u = 0; u < U; ++u) {
+    const int r = F + lane + 64 * u;
+    const bool ok = r < n - 1;
+    g[u] = ok ? gi[r] : -1;
+#pragma unroll
+    for (int c = 0; c < FM; ++c) a[u][c] = (ok && c < F) ? A[r + (i64)c * n] : 0.0;
+  }
+  const int gf = lane < F ? gi[lane] : -1;
+  // lane e holds entry (e % F, e / F) of the triangle and lane c the rhs of column c (F * F <= 64 when F <= 8; wider
+  // leaves read the triangle from memory in the substitution)
+  const int tr = lane % max(F, 1), tc = lane / max(F, 1);
+  const double tri = (FM <= 8 && tc < F) ? A[tr + (i64)tc * n] : 0.0;
+  const double dl = lane < F ? A[(n - 1) + (i64)lane * n] : 0.0;
+  // y_c = d_c - sum_{r >= F} L[r][c] x_r
+  double yc[FM];
+#pragma unroll
+  for (int c = 0; c < FM; ++c) yc[c] = 0.0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const double x = g[u] >= 0 ? delta[g[u]] : 0.0;
+#pragma unroll
+    for (int c = 0; c < FM; ++c) yc[c] = fma(a[u][c], x, yc[c]);
+  }
+  for (int r = F + lane + 64 * U; r < n - 1; r += 64) {  // (separators of more than 128 rows: rare)
     const double x = delta[gi[r]];
 #pragma unroll
-    for (int cidx = 0; cidx < kLeafMaxF; ++cidx)
-      if (cidx < F) yc[cidx] += A[r + (i64)cidx * n] * x;
+    for (int c = 0; c < FM; ++c)
+      if (c < F) yc[c] += A[r + (i64)c * n] * x;
   }
 #pragma unroll
-  for (int cidx = 0; cidx < kLeafMaxF; ++cidx) {
-    if (cidx < F) {
+  for (int c = 0; c < FM; ++c) {
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) yc[cidx] += __shfl_xor(yc[cidx], o, 64);
-      yc[cidx] = A[(n - 1) + (i64)cidx * n] - yc[cidx];
+    for (int o = 32; o > 0; o >>= 1) yc[c] += __shfl_xor(yc[c], o, 64);
+    yc[c] = tile_readlane(dl, c) - yc[c];
+  }
+  // L11' x = y, backwards (every lane computes the same values)
+  double xv[FM];
+#pragma unroll
+  for (int c = FM - 1; c >= 0; --c) {
+    xv[c] = 0.0;
+    if (c < F) {
+      double acc = yc[c];
+#pragma unroll
+      for (int r = c + 1; r < FM; ++r)
+        if (r < F) acc -= (FM <= 8 ? tile_readlane(tri, r + c * F) : A[r + (i64)c * n]) * xv[r];
+      xv[c] = acc / (FM <= 8 ? tile_readlane(tri, c + c * F) : A[c + (i64)c * n]);
     }
   }
-  // L11' x = y, backwards (every lane computes the same values; lane 0 stores)
-  double xv[kLeafMaxF];
+  double mine = 0.0;
 #pragma unroll
-  for (int cidx = kLeafMaxF - 1; cidx >= 0; --cidx) {
-    xv[cidx] = 0.0;
-    if (cidx < F) {
-      double acc = yc[cidx];
-#pragma unroll
-      for (int r = cidx + 1; r < kLeafMaxF; ++r)
-        if (r < F) acc -= A[r + (i64)cidx * n] * xv[r];
-      xv[cidx] = acc / A[cidx + (i64)cidx * n];
-    }
-  }
-  if (lane == 0) {
-    int bad = 0;
-#pragma unroll
-    for (int cidx = 0; cidx < kLeafMaxF; ++cidx)
-      if (cidx < F) {
-        delta[gi[cidx]] = xv[cidx];
-        if (!isfinite(xv[cidx])) bad = 1;
-      }
-    if (bad) atomicAdd(&status->n_nonfinite, 1);
+  for (int c = 0; c < FM; ++c) mine = (lane == c) ? xv[c] : mine;
+  if (lane < F) {
+    delta[gf] = mine;
+    if (!isfinite(mine)) atomicAdd(&status->n_nonfinite, 1);
   }
 }
 
-void launch_backsolve_leaf(const DevSymbolic& S, const LeafRec* recs, int count, const double* arena, double* delta,
-                           DevStatus* status, hipStream_t st) {
-  if (count) backsolve_leaf_kernel<<<(count + 3) / 4, 256, 0, st>>>(S, recs, count, arena, delta, status);
+void launch_backsolve_leaf(const DevSymbolic& S, const LeafRec* recs, int count, int max_F, const double* arena,
+                           double* delta, DevStatus* status, hipStream_t st) {
+  if (!count) return;
+  const int grid = (count + 3) / 4;
+  if (max_F <= 4) backsolve_leaf_kernel<4><<<grid, 256, 0, st>>>(S, recs, count, arena, delta, status);
+  else if (max_F <= 8) backsolve_leaf_kernel<8><<<grid, 256, 0, st>>>(S, recs, count, arena, delta, status);
+  else backsolve_leaf_kernel<kLeafMaxF><<<grid, 256, 0, st>>>(S, recs, count, arena, delta, status);
 }
 
 void launch_backsolve(const DevSymbolic& S, const int* ids, int count, int threads, int max_n, const double* arena,

@@ -123,6 +123,7 @@ struct gsx_context {
   // schedule
   std::vector<std::vector<SmallLaunch>> small_launch;  // per level
   std::vector<std::vector<SmallLaunch>> leaf_launch;   // per level (panel-only leaf kernel)
+  std::vector<int> leaf_max_F;                         // per level: largest F among its leaf-kernel fronts
   DevBuf<i64> d_gt_dst;  // gather tasks / segments for big parents
   DevBuf<GatherSeg> d_gsegs;
   DevBuf<GatherSrc> d_gsrcs;
@@ -564,8 +565,10 @@ gsx_status upload_symbolic(gsx_context* c) {
   c->big_descs.clear();
   c->big_max_n = c->big_max_nfv = 0;
   c->leaf_launch.assign(S.n_levels, {});
+  c->leaf_max_F.assign(S.n_levels, 0);
   for (int l = 0; l < S.n_levels; ++l) {
     int i = S.lvl_ptr[l];
+    for (int k = i; k < S.lvl_leaf_end[l]; ++k) c->leaf_max_F[l] = std::max(c->leaf_max_F[l], S.F[S.sched[k]]);
     // leaf-kernel fronts: sorted by (F, N); a launch = same F, panel size within 1.5x
     const int le = S.lvl_leaf_end[l];
     while (i < le) {
@@ -965,7 +968,7 @@ void dev_backsolve(gsx_context* c) {
     // all leaf-kernel cliques of the level in one launch (a wave each)
     if (S.lvl_leaf_end[l] > S.lvl_ptr[l])
       launch_backsolve_leaf(c->DS, c->d_leaf_recs.p + (S.lvl_ptr[l] - c->leaf_base), S.lvl_leaf_end[l] - S.lvl_ptr[l],
-                            c->d_arena.p, c->d_delta.p, c->d_status.p, c->stream);
+                            c->leaf_max_F[l], c->d_arena.p, c->d_delta.p, c->d_status.p, c->stream);
   }
   timer_end(c, PH_BACKSOLVE);
 }
