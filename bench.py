@@ -135,13 +135,16 @@ def front_split(be, arrays, small_max_n=140, leaf_max_f=16, tile=32, leaf_max_pa
 
 def pmc_traffic(kernel, workload):
     """HBM bytes per launch (FETCH_SIZE + WRITE_SIZE) of `kernel` from the committed rocprofv3 --pmc passes of this
-    same command (hardware counters cannot be read from inside the process; tools/pmc_summary.py made the file)."""
-    path = os.path.join(ROOT, "profiles", f"r01_{workload}_pmc_traffic.json")
-    try:
-        k = json.load(open(path))["kernels"][kernel.split("(")[0]]
-        return k["fetch_bytes"] + k["write_bytes"], os.path.relpath(path, ROOT)
-    except (OSError, KeyError, ValueError):
-        return None, None
+    same command (hardware counters cannot be read from inside the process; tools_pmc.sh + tools/pmc_summary.py made
+    the file).  The newest round's file that knows the kernel is used; None when no committed pass covers it."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_pmc_traffic.json")), reverse=True):
+        try:
+            k = json.load(open(path))["kernels"][kernel.split("(")[0]]
+            return k["fetch_bytes"] + k["write_bytes"], os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def run_shard_child(world, workload, backend, timeout_s):

@@ -12,7 +12,16 @@ import collections
 import csv
 import glob
 import json
+import re
+import subprocess
 import sys
+
+
+def kernel_name(full):
+    """'void gsx::(anonymous namespace)::big_diag_kernel<12, 7>(gsx::BigDesc const*, ...)' -> 'big_diag_kernel'"""
+    n = full.replace("(anonymous namespace)::", "")
+    n = re.sub(r"^void\s+", "", n).split("(")[0].replace("gsx::", "")
+    return re.sub(r"<.*$", "", n).strip()
 
 
 def load(d, counter):
@@ -21,7 +30,7 @@ def load(d, counter):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
             continue
-        n = r["Kernel_Name"].split("(")[0].replace("gsx::", "")
+        n = kernel_name(r["Kernel_Name"])
         agg[n][0] += 1
         agg[n][1] += float(r["Counter_Value"])
     return agg
@@ -30,8 +39,12 @@ def load(d, counter):
 def main():
     fetch, write, out = sys.argv[1:4]
     f, w = load(fetch, "FETCH_SIZE"), load(write, "WRITE_SIZE")
-    res = {"unit": "bytes per launch (average over the run)", "fetch_calibration": "raw (8 B/lane accesses: uncalibrated)",
-           "kernels": {}}
+    try:
+        sha = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except OSError:
+        sha = ""
+    res = {"unit": "bytes per launch (average over the run; template instances of a kernel pooled)",
+           "fetch_calibration": "raw (8 B/lane accesses: uncalibrated)", "code": sha, "kernels": {}}
     for k in sorted(set(f) | set(w)):
         fl, fv = f.get(k, [0, 0.0])
         wl, wv = w.get(k, [0, 0.0])
