@@ -107,8 +107,9 @@ void launch_linearize(const DevProblem& P, const int* const type_lists[6], const
                       const double* values, double* jac, DevStatus* status, hipStream_t st);
 void launch_error(const DevProblem& P, const double* values, double* partials, int n_partials_cap,
                   double* scalars, int slot, hipStream_t st);
+// slice > 0: the staged kernel (doubles of LDS per wave = the largest [A b] range of 64 consecutive factors); 0: the direct one
 void launch_linear_error(const DevProblem& P, const double* jac, const double* delta, double* partials,
-                         int n_partials_cap, double* scalars, hipStream_t st);
+                         int n_partials_cap, double* scalars, int slice, hipStream_t st);
 void launch_retract(const DevProblem& P, const double* values, const double* delta, double* out, hipStream_t st);
 void launch_assemble_h_group(const DevProblem& P, const DevSymbolic& S, const int* vars, int count, int threads,
                              int lds_bytes, bool global, const double* jac, double* H, hipStream_t st);

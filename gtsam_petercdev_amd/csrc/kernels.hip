@@ -588,11 +588,82 @@ __global__ void __launch_bounds__(256) linear_error_kernel(DevProblem P, const d
   }
 }
 
+// The same sums with the Jacobian blocks read ONCE and coalesced: a wave takes 64 consecutive factors, whose [A b]
+// blocks are one contiguous range of `jac`, copies the range into its LDS slice (eight loads a lane in flight) and
+// every lane then walks its own block out of LDS.  (A lane walking its 208-byte block in global memory touches a new
+// cache line per load: 1.9 x the algorithmic bytes fetched from HBM, r01_bal1723_pmc_traffic.json.)
+// `slice` = doubles per wave, the largest range of any 64 consecutive factors (host: upload_problem).
+__global__ void __launch_bounds__(128) linear_error_staged_kernel(DevProblem P, const double* jac, const double* delta,
+                                                                  double* partials, int slice) {
+  extern __shared__ double stage[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double* W = stage + (size_t)wave * slice;
+  const int ngroups = (P.n_factors + 63) >> 6;
+  double acc0 = 0, accd = 0;
+  for (int g = blockIdx.x * 2 + wave; g < ngroups; g += gridDim.x * 2) {
+    const int i0 = g * 64;
+    const bool live = i0 + lane < P.n_factors;
+    const int f = live ? i0 + lane : P.n_factors - 1;
+    const int m = P.f_rows[f], nc = P.f_cols[f];
+    const i64 off = P.f_jac_off[f];
+    const i64 base = readlane_i64(off, 0);
+    const int last = min(63, P.n_factors - 1 - i0);
+    const int len = (int)(readlane_i64(off + (i64)m * nc, last) - base);
+    const double* src = jac + base;
+    for (int e0 = lane; e0 < len; e0 += 64 * 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (e0 + 64 * u < len) ? src[e0 + 64 * u] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (e0 + 64 * u < len) W[e0 + 64 * u] = v[u];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (live) {
+      const double* J = W + (off - base);
+      for (int r = 0; r < m; ++r) {
+        const double b = J[(nc - 1) * m + r];
+        double e = -b;
+        int col = 0;
+        for (int k = P.f_key_ptr[f]; k < P.f_key_ptr[f + 1]; ++k) {
+          const int v = P.f_vars[k];
+          const double* x = delta + P.var_tan_off[v];
+          const int d = P.var_dim[v];
+          for (int c = 0; c < d; ++c, ++col) e += J[col * m + r] * x[c];
+        }
+        acc0 += b * b;
+        accd += e * e;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+  const double s0 = block_sum(0.5 * acc0);
+  const double sd = block_sum(0.5 * accd);
+  if (threadIdx.x == 0) {
+    partials[2 * blockIdx.x] = s0;
+    partials[2 * blockIdx.x + 1] = sd;
+  }
+}
+
 void launch_linear_error(const DevProblem& P, const double* jac, const double* delta, double* partials, int cap,
-                         double* scalars, hipStream_t st) {
-  int nb = (P.n_active + 255) / 256;
-  nb = nb < 1 ? 1 : (nb > cap / 2 ? cap / 2 : nb);
-  linear_error_kernel<<<nb, 256, 0, st>>>(P, jac, delta, partials);
+                         double* scalars, int slice, hipStream_t st) {
+  int nb;
+  if (slice > 0 && !P.f_active) {
+    static bool attr = false;
+    if (!attr) {
+      hipFuncSetAttribute((const void*)linear_error_staged_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      attr = true;
+    }
+    nb = ((P.n_factors + 63) / 64 + 1) / 2;
+    nb = nb < 1 ? 1 : (nb > cap / 2 ? cap / 2 : nb);
+    linear_error_staged_kernel<<<nb, 128, (size_t)2 * slice * sizeof(double), st>>>(P, jac, delta, partials, slice);
+  } else {
+    nb = (P.n_active + 255) / 256;
+    nb = nb < 1 ? 1 : (nb > cap / 2 ? cap / 2 : nb);
+    linear_error_kernel<<<nb, 256, 0, st>>>(P, jac, delta, partials);
+  }
   reduce_final_kernel<<<1, 256, 0, st>>>(partials, nb, 2, scalars, SC_LIN0);
   reduce_final_kernel<<<1, 256, 0, st>>>(partials + 1, nb, 2, scalars, SC_LIND);
 }
@@ -2087,11 +2158,15 @@ void launch_big_gather(const GatherArgs& G, int seg0, int nseg, int m0, int nm, 
 // ---------------------------------------------------------------------------------------------
 // big fronts (n > kSmallMaxN): blocked right-looking partial Cholesky in HBM, tile T = 32
 // ---------------------------------------------------------------------------------------------
+// Only what the factorization reads before writing is cleared: of column c the rows from the top of its diagonal 32-tile
+// down (the lower triangle in tile granularity — the tiles above the diagonal are never touched by any kernel).
 __global__ void big_zero_kernel(const BigDesc* descs, double* arena) {
   const BigDesc d = descs[blockIdx.y];
-  const i64 total = (i64)d.N * d.N;
   double* A = arena + d.off;
-  for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (i64)gridDim.x * blockDim.x) A[e] = 0;
+  for (int c = blockIdx.x; c < d.N; c += gridDim.x) {
+    double* col = A + (i64)c * d.N;
+    for (int r = (c & ~(T - 1)) + threadIdx.x; r < d.N; r += blockDim.x) col[r] = 0;
+  }
 }
 __global__ void big_add_h_kernel(DevProblem P, DevSymbolic S, const BigDesc* descs, const double* H, const double* damp,
                                  const double* scalars, double* arena) {
@@ -2117,9 +2192,8 @@ __global__ void big_add_h_kernel(DevProblem P, DevSymbolic S, const BigDesc* des
 void launch_big_init(const DevProblem& P, const DevSymbolic& S, const BigDesc* descs, int count, int max_n, int max_nfv,
                      const double* H, const double* damp, const double* scalars, double* arena, hipStream_t st) {
   if (!count) return;
-  i64 tot = (i64)max_n * max_n;
-  int bx = (int)((tot + 256 * 8 - 1) / (256 * 8));
-  bx = bx < 1 ? 1 : (bx > 4096 ? 4096 : bx);
+  // (columns per workgroup so that the whole launch is a few thousand workgroups)
+  int bx = std::max(1, std::min(max_n, 8192 / std::max(count, 1)));
   big_zero_kernel<<<dim3(bx, count), 256, 0, st>>>(descs, arena);
   big_add_h_kernel<<<dim3(max_nfv, count), 128, 0, st>>>(P, S, descs, H, damp, scalars, arena);
 }
@@ -2129,358 +2203,7 @@ void launch_big_init(const DevProblem& P, const DevSymbolic& S, const BigDesc* d
 // just-issued stores on the critical path of the latency-bound kernels below.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// ---- big-front kernels: 256 threads = 4 waves, one per SIMD; every thread owns 4 entries of a 32 x 32 tile in
-// the FP64 matrix-core accumulator layout of its wave's 16 x 16 quadrant:
-//   wave wv: row half qr = wv & 1, column half qc = wv >> 1;  lane: li = lane & 15, lk = lane >> 4
-//   entry q (0..3): row r = 16 qr + li, column c_q = 16 qc + 4 q + lk
-// (the quadrant is computed TRANSPOSED on the matrix cores — D[i = column][j = row] — so that the 16 lanes li run
-//  down a column of the column-major front: 128-byte segments for the tile's global loads and stores).
-constexpr int NT = 256;
-constexpr int KP = 4;             // pivots per barrier in the tile factorization
-typedef double (*TilePtr)[T + 1];
-constexpr size_t kTileBytes = sizeof(double) * T * (T + 1);
-
-struct TileLane {
-  int r, c[4], r0, cq0, li, lk;   // r0 = 16 qr, cq0 = 16 qc
-  __device__ __forceinline__ TileLane() {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    li = lane & 15;
-    lk = lane >> 4;
-    r0 = 16 * (wv & 1);
-    cq0 = 16 * (wv >> 1);
-    r = r0 + li;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) c[q] = cq0 + 4 * q + lk;
-  }
-};
-
-// acc[q] = sum_{k < KMAX} Pc[c_q][k] * Pr[r][k]  (both tiles row-major in LDS, zero-padded)
-template <int KMAX>
-__device__ __forceinline__ v4d tile_product(const TileLane& L, TilePtr Pc, TilePtr Pr) {
-  v4d acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int k0 = 0; k0 < KMAX; k0 += 4) {
-    const double a = Pc[L.cq0 + L.li][k0 + L.lk];  // A[i = column][k]
-    const double b = Pr[L.r0 + L.li][k0 + L.lk];   // B[k][j = row]
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-  }
-  return acc;
-}
-
-// Factor the diagonal tile (c0, w) of a big front ONCE.  The tile arrives in registers (v[q] = entry (r, c_q),
-// zero above the diagonal and beyond w) — straight from the trailing update that produced it.
-//   The front gets L in the tile's lower triangle and (L^-1)' in its strictly upper triangle, so that the panel
-//   solve is a plain tile product, and 1 / L_cc at the diagonal position of the front's L-panel area (Xp);
-//   pivots are checked with choleskyPartial's failure semantics (gtsam/base/cholesky.cpp:145-158).
-// Instruction issue of a lone wave (~1 / 5 cycles), barriers and LDS round trips — not flops — are what a 32 x 32
-// factorization costs, so it runs KP = 4 pivots per stage, two 4-wave barriers each:
-//   A. the KP current columns are in LDS; every thread re-derives the KP x KP pivot block and the KP entries
-//      L[r][j..j+KP) of its own row in registers (KP dependent rsqrt's) and row owners publish them; the wave whose
-//      quadrant lies above the diagonal inverts the pivot block instead;
-//   B. every thread applies the rank-KP update to its four entries from its row's and its columns' published
-//      values, and the owners of the next KP columns publish them.
-// The inverse then takes three levels of recursive doubling X21 = -X22 (L21 X11) (fixed-length zero-padded dots).
-template <int B>
-__device__ __forceinline__ void inverse_doubling_level(TilePtr Ls, TilePtr Xs, TilePtr Tm) {
-  constexpr int total = (T / (2 * B)) * B * B;
-  const int e = threadIdx.x;
-  const int pair = e / (B * B), loc = e % (B * B), i = loc % B, jx = loc / B, s0 = pair * 2 * B;
-  if (e < total) {
-    double acc = 0;
-#pragma unroll
-    for (int k = 0; k < B; ++k) acc += Ls[s0 + B + i][s0 + k] * Xs[s0 + k][s0 + jx];
-    Tm[s0 + B + i][s0 + jx] = acc;
-  }
-  lds_barrier();
-  if (e < total) {
-    double acc = 0;
-#pragma unroll
-    for (int k = 0; k < B; ++k) acc += Xs[s0 + B + i][s0 + B + k] * Tm[s0 + B + k][s0 + jx];
-    Xs[s0 + B + i][s0 + jx] = -acc;
-  }
-  lds_barrier();
-}
-
-__device__ __forceinline__ void diag_tile_factor(const TileLane& L, double v[4], double* A, double* Xp, int n, int F,
-                                                 int c0, int w, TilePtr Ls, TilePtr Xs, TilePtr Tm, DevStatus* status,
-                                                 int front) {
-  __shared__ double colb[2][KP][T];  // the KP current columns (updated through the previous stage), double-buffered
-  __shared__ double dinv[T];         // 1 / L_cc
-  STAMP_BEGIN
-  const int tid = threadIdx.x, r = L.r;
-  const int wv = tid >> 6;
-  const int xc = L.cq0 + L.li;  // the column whose L values this lane feeds to the matrix core (its row is r)
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    if (L.c[q] < KP) colb[0][L.c[q]][r] = v[q];
-    Xs[r][L.c[q]] = 0.0;  // the diagonal KP x KP blocks are filled in by the stages
-    Ls[r][L.c[q]] = 0.0;  // L columns are filled in by the stages as they become final
-  }
-  if (tid < T) dinv[tid] = 0.0;
-  v4d acc = {v[0], v[1], v[2], v[3]};
-  const bool row_owner = L.cq0 == 0 && L.lk == 0;  // one lane per tile row (waves 0 and 1)
-  int fail = 0;
-  for (int j = 0, stage = 0; j < w; j += KP, ++stage) {
-    lds_barrier();
-    const double(*cur)[T] = colb[stage & 1];
-    double(*nxt)[T] = colb[(stage + 1) & 1];
-    // The pivot block is eliminated in root-free (L D L') form: u = unnormalised entries, d_k the pivots,
-    // rk = 1 / d_k.  A dependent FP64 operation costs a lone wave ~40 cycles and a transcendental ~90, so the
-    // chain from one pivot to the next is kept at  d_k -> rcp -> 3 FMAs -> 1 FMA -> d_{k+1};  the reciprocal
-    // square roots that scale the OUTPUT (L = u / sqrt(d)) are off that chain.
-    double am[KP][KP], u[KP][KP], wg[KP][KP], dk[KP], rk[KP], ur[KP], uc[KP];
-#pragma unroll
-    for (int k = 0; k < KP; ++k) {
-      ur[k] = cur[k][r];
-      uc[k] = cur[k][xc];
-#pragma unroll
-      for (int m = k; m < KP; ++m) am[m][k] = cur[k][j + m];
-    }
-#pragma unroll
-    for (int k = 0; k < KP; ++k) {
-      // wg[k][t] = u[k][t] / d_t, t < k
-#pragma unroll
-      for (int t = 0; t < k; ++t) wg[k][t] = u[k][t] * rk[t];
-      double d = am[k][k];
-#pragma unroll
-      for (int t = 0; t + 1 < k; ++t) d -= u[k][t] * wg[k][t];
-      if (k > 0) d = fma(-(u[k][k - 1] * u[k][k - 1]), rk[k - 1], d);  // the only use of rk[k-1] on the chain
-      const bool live = j + k < w;  // uniform: columns beyond the tile width do not exist
-      if (live && !(d > 0)) fail = 1;
-      dk[k] = d;
-      {
-        const double y0 = __builtin_amdgcn_rcp(d);
-        const double e = fma(-d, y0, 1.0);
-        const double t2 = fma(e, e, e);
-        const double y = fma(y0, t2, y0);  // y0 (1 + e + e^2): cubic convergence
-        rk[k] = (live && d > 0) ? y : (live ? 1.0 : 0.0);
-      }
-#pragma unroll
-      for (int m = k + 1; m < KP; ++m) {
-        double x = am[m][k];
-#pragma unroll
-        for (int t = 0; t < k; ++t) x -= u[m][t] * wg[k][t];
-        u[m][k] = x;
-      }
-#pragma unroll
-      for (int t = 0; t < k; ++t) {
-        ur[k] -= ur[t] * wg[k][t];
-        uc[k] -= uc[t] * wg[k][t];
-      }
-    }
-    // output scaling
-    double pinv[KP];
-#pragma unroll
-    for (int k = 0; k < KP; ++k) {
-      const bool live = j + k < w;
-      const double y0 = __builtin_amdgcn_rsq(dk[k]);
-      const double e = fma(-dk[k] * y0, y0, 1.0);
-      const double y = fma(y0 * e, fma(e, 0.375, 0.5), y0);  // y0 (1 + e/2 + 3 e^2 / 8)
-      pinv[k] = (live && dk[k] > 0) ? y : (live ? 1.0 : 0.0);
-    }
-    if (wv == 2 && L.li < KP && L.lk < KP) {
-      // (wave 2's quadrant lies above the diagonal) inverse of the pivot block L_jj: P[m][k], m = li, k = lk
-      double piv[KP][KP], P[KP][KP];
-#pragma unroll
-      for (int k = 0; k < KP; ++k)
-#pragma unroll
-        for (int m = k + 1; m < KP; ++m) piv[m][k] = u[m][k] * pinv[k];
-#pragma unroll
-      for (int k = 0; k < KP; ++k) {
-        P[k][k] = pinv[k];
-#pragma unroll
-        for (int m = k + 1; m < KP; ++m) {
-          double sacc = 0.0;
-#pragma unroll
-          for (int t = k; t < m; ++t) sacc += piv[m][t] * P[t][k];
-          P[m][k] = -sacc * pinv[m];
-        }
-      }
-      double out = 0.0;
-#pragma unroll
-      for (int k = 0; k < KP; ++k)
-#pragma unroll
-        for (int m = k; m < KP; ++m)
-          if (L.li == m && L.lk == k) out = P[m][k];
-      Xs[j + L.li][j + L.lk] = out;
-      if (L.li == L.lk) dinv[j + L.li] = out;
-    }
-    // the pivot columns are final: L[r][j+k] = u / sqrt(d), written once per row (zero above the diagonal)
-    if (row_owner) {
-#pragma unroll
-      for (int k = 0; k < KP; ++k) {
-        const double below = ur[k] * pinv[k], diag = dk[k] * pinv[k];
-        Ls[r][j + k] = (r > j + k) ? below : ((r == j + k) ? diag : 0.0);
-      }
-    }
-    // rank-KP update of the wave's quadrant in ONE v_mfma_f64_16x16x4: D[c][r] -= sum_k (u_ck / d_k) u_rk;
-    // rows / columns up to the pivot block contribute zero operands
-    double a = 0.0, bb = 0.0;
-#pragma unroll
-    for (int k = 0; k < KP; ++k) {
-      a = (L.lk == k) ? uc[k] * rk[k] : a;
-      bb = (L.lk == k) ? ur[k] : bb;
-    }
-    a = (xc >= j + KP) ? -a : 0.0;
-    bb = (r >= j + KP) ? bb : 0.0;
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
-    {
-      // the next KP columns are entry q* of the lanes of the waves whose column half holds them (wave-uniform)
-      const int qs = (j + KP - L.cq0) >> 2;
-      if (j + KP >= L.cq0 && qs < 4) {
-        const double pub = (qs == 0) ? acc[0] : ((qs == 1) ? acc[1] : ((qs == 2) ? acc[2] : acc[3]));
-        nxt[L.lk][r] = pub;
-      }
-    }
-  }
-  lds_barrier();
-  STAMP_ADD(2)
-  STAMP_ADD(3)
-  inverse_doubling_level<4>(Ls, Xs, Tm);
-  inverse_doubling_level<8>(Ls, Xs, Tm);
-  inverse_doubling_level<16>(Ls, Xs, Tm);
-  STAMP_ADD(4)
-  // write back: L in the lower triangle (incl. diagonal), (L^-1)' in the strictly upper triangle
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int rr = tid % T, cc = tid / T + 8 * q;
-    if (rr < w && cc < w) A[(c0 + rr) + (i64)(c0 + cc) * n] = (rr >= cc) ? Ls[rr][cc] : Xs[cc][rr];
-  }
-  if (tid < w) Xp[(c0 + tid) + (i64)(c0 + tid) * n] = dinv[tid];
-  STAMP_ADD(5)
-  if (tid == 0) {
-    if (c0 + w == F) {  // last panel: conditioning test on the last two pivots
-      const double p1 = Ls[w - 1][w - 1];
-      int e1, e2;
-      (void)frexp(p1, &e1);
-      if (F >= 2) {
-        const double p2 = (w >= 2) ? Ls[w - 2][w - 2] : A[(F - 2) + (i64)(F - 2) * n];
-        (void)frexp(p2, &e2);
-        if (!(e2 - e1 < 12)) fail = 1;
-      } else if (!(e1 > -12)) {
-        fail = 1;
-      }
-    }
-    if (fail) report_failure(status, front);
-  }
-}
-
-// first diagonal tile of every big front of a level
-// (passing the descriptors of small levels by value as kernel arguments was measured: slower, not faster)
-__global__ void __launch_bounds__(NT) big_potrf0_kernel(const BigDesc* descs, double* arena, DevStatus* status) {
-  extern __shared__ double dyn_lds[];
-  TilePtr Ls = (TilePtr)dyn_lds, Xs = (TilePtr)(dyn_lds + T * (T + 1)), Tm = (TilePtr)(dyn_lds + 2 * T * (T + 1));
-  const BigDesc d = descs[blockIdx.x];
-  double* A = arena + d.off;
-  const int n = d.N, w = min(T, d.F);
-  const TileLane L;
-  double v[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) v[q] = (L.r >= L.c[q] && L.r < w) ? A[L.r + (i64)L.c[q] * n] : 0.0;
-  diag_tile_factor(L, v, A, arena + d.xoff, n, d.F, 0, w, Ls, Xs, Tm, status, d.front);
-}
-
-// Panel step kb of every big front of a level, ONE launch: the block of lower tile pair (i, j)
-//   1. forms the two panel tiles it needs itself, X_i = A_ik L_kk^-T and X_j likewise, as tile products with the
-//      explicit inverse parked in the diagonal tile's upper triangle (a separate triangular-solve launch would
-//      cost more than recomputing them: the chain of panel steps is latency-bound),
-//   2. the diagonal pair (i, i) stores X_i — the final L rows — in the front's L-panel area (d.xoff; the raw panel
-//      stays untouched in the front, so no block races with another block's reads),
-//   3. applies the trailing update C[i,j] -= X_i X_j',
-//   4. pair (0,0) then factors the NEXT diagonal tile (look-ahead) straight from its accumulator registers.
-// All three tile products run on the FP64 matrix cores (v_mfma_f64_16x16x4, one 16 x 16 quadrant per wave): with
-// VALU dot products the kernel was bound by LDS operand reads (2 per FMA).
-__global__ void __launch_bounds__(NT) big_panel_kernel(const BigDesc* descs, int kb, double* arena, DevStatus* status) {
-  extern __shared__ double dyn_lds[];
-  constexpr int TS = T * (T + 1);
-  // three tiles of LDS (25 KB: six workgroups per CU): the solved tiles X_i, X_j overwrite the raw ones
-  TilePtr Ri = (TilePtr)dyn_lds, Rj = (TilePtr)(dyn_lds + TS), Li = (TilePtr)(dyn_lds + 2 * TS);
-  const TilePtr Xi = Ri, Xj = Rj;
-  STAMP_BEGIN
-  const BigDesc d = descs[blockIdx.y];
-  const int n = d.N, F = d.F, c0 = kb * T;
-  if (c0 >= F) return;
-  const int w = min(T, F - c0);
-  const int base = c0 + w;
-  const int ntile = (n - base + T - 1) / T;
-  const int npairs = ntile * (ntile + 1) / 2;
-  const int t = blockIdx.x;
-  if (t >= npairs) return;
-  double* A = arena + d.off;
-  double* X = arena + d.xoff;
-  const int tid = threadIdx.x;
-  int i = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-  while ((i + 1) * (i + 2) / 2 <= t) ++i;
-  while (i * (i + 1) / 2 > t) --i;
-  const int j = t - i * (i + 1) / 2;
-  const int ri = base + i * T, rj = base + j * T;
-  const int hi = min(T, n - ri), hj = min(T, n - rj);
-  const TileLane L;
-  // the C tile entries this thread updates: loads in flight while the panel tiles are formed
-  double cv[4];
-  bool live[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    live[q] = L.r < hi && L.c[q] < hj && !(i == j && L.r < L.c[q]);
-    cv[q] = live[q] ? A[(ri + L.r) + (i64)(rj + L.c[q]) * n] : 0.0;
-  }
-  {
-    const int rr = tid % T;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int cc = tid / T + 8 * q;
-      // Li[c][k] = (L_kk^-1)[c][k], k <= c (row rr plays k); zero beyond w
-      double lv = 0.0;
-      if (rr < w && cc < w) {
-        if (rr < cc) lv = A[(c0 + rr) + (i64)(c0 + cc) * n];
-        else if (rr == cc) lv = X[(c0 + cc) + (i64)(c0 + cc) * n];  // 1 / L_cc, left there by the tile factorization
-      }
-      Li[cc][rr] = lv;
-      Ri[rr][cc] = (rr < hi && cc < w) ? A[(ri + rr) + (i64)(c0 + cc) * n] : 0.0;
-      if (i != j) Rj[rr][cc] = (rr < hj && cc < w) ? A[(rj + rr) + (i64)(c0 + cc) * n] : 0.0;
-    }
-  }
-  lds_barrier();
-  {
-    // X[r][c] = sum_{k <= c} R[r][k] Linv[c][k]: columns of the first half only need k < 16
-    const bool half = L.cq0 == 0;  // wave-uniform
-    const v4d xi = half ? tile_product<16>(L, Li, Ri) : tile_product<T>(L, Li, Ri);
-    v4d xj = xi;
-    if (i != j) xj = half ? tile_product<16>(L, Li, Rj) : tile_product<T>(L, Li, Rj);
-    lds_barrier();  // every wave has read the raw tiles
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      Xi[L.r][L.c[q]] = xi[q];
-      if (i == j && L.r < hi && L.c[q] < w) X[(ri + L.r) + (i64)(c0 + L.c[q]) * n] = xi[q];
-    }
-    if (i != j) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) Xj[L.r][L.c[q]] = xj[q];
-    }
-  }
-  const TilePtr Xjj = (i != j) ? Xj : Xi;
-  lds_barrier();
-  double v[4];
-  {
-    const v4d acc = tile_product<T>(L, Xjj, Xi);  // acc[q] = sum_k Xj[c_q][k] Xi[r][k]
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      v[q] = cv[q] - acc[q];
-      if (live[q]) A[(ri + L.r) + (i64)(rj + L.c[q]) * n] = v[q];
-    }
-  }
-  if (t == 0 && base < F) {
-    // look-ahead: this block owns the next diagonal tile and factors it from its registers
-    const int wn = min(T, F - base);
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (!(live[q] && L.r < wn && L.c[q] < wn)) v[q] = 0.0;
-    lds_barrier();  // every wave is done reading the panel tiles: Ri / Rj / Li become the factorization's scratch
-    STAMP_ADD(6)
-    diag_tile_factor(L, v, A, X, n, F, base, wn, Ri, Rj, Li, status, d.front);
-  }
-}
-
+// (The blocked fronts' factorization kernels live in bigfront.hip.)
 // gsx_cholesky_partial's large case: move the L panel back under the diagonal tiles of the matrix
 __global__ void big_copy_panel_kernel(const BigDesc* descs, double* arena) {
   const BigDesc d = descs[0];
@@ -2491,26 +2214,6 @@ __global__ void big_copy_panel_kernel(const BigDesc* descs, double* arena) {
     const int r = (int)(e % d.N), c = (int)(e / d.N);
     if (r >= min((c / T + 1) * T, d.F)) A[r + (i64)c * d.N] = X[r + (i64)c * d.N];
   }
-}
-
-static void big_kernels_attr() {
-  static bool done = false;
-  if (done) return;
-  hipFuncSetAttribute((const void*)big_potrf0_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (int)kTileBytes);
-  hipFuncSetAttribute((const void*)big_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (int)kTileBytes);
-  done = true;
-}
-
-void launch_big_potrf0(const BigDesc* descs, int count, double* arena, DevStatus* status, hipStream_t st) {
-  big_kernels_attr();
-  if (count) big_potrf0_kernel<<<count, NT, 3 * kTileBytes, st>>>(descs, arena, status);
-}
-
-void launch_big_step(const BigDesc* descs, int count, int kb, int max_pairs, double* arena, DevStatus* status,
-                     hipStream_t st) {
-  if (!count || max_pairs <= 0) return;
-  big_kernels_attr();
-  big_panel_kernel<<<dim3(max_pairs, count), NT, 3 * kTileBytes, st>>>(descs, kb, arena, status);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2535,7 +2238,7 @@ __global__ void backsolve_kernel(DevSymbolic S, const int* ids, const double* ar
   for (int r = F + tid; r < n - 1; r += nt) xs[r] = delta[gi[r]];
   __syncthreads();
   // big fronts carry (L^-1)' of every 32x32 diagonal tile in that tile's strictly upper triangle and 1 / L_cc in
-  // the L-panel area (diag_tile_factor; kTile == TB): the tile solve is then a 32-term dot product per lane instead
+  // the L-panel area (big_diag, bigfront.hip; kTile == TB): the tile solve is then a 32-term dot product per lane instead
   // of a 32-step serial substitution with divisions.
   const bool has_inv = big && (T == TB);
   const int nblk = (F + TB - 1) / TB;

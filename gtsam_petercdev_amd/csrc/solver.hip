@@ -116,6 +116,7 @@ struct gsx_context {
   DevBuf<VarRec> d_fvar_recs;
   DevBuf<LeafRec> d_leaf_recs;   // leaf-kernel cliques of level 0, in schedule order
   int leaf_base = 0;             // schedule position of d_leaf_recs[0]
+  int lin_err_slice = 0;         // LDS doubles per wave of the staged linear-error kernel (0: blocks too large, direct kernel)
   DevBuf<int> d_fr_N, d_fr_F, d_fr_nfv, d_fr_fvar_ptr, d_fvars, d_fr_parent, d_fr_lean, d_fr_child_ptr, d_children, d_cmap,
       d_gidx, d_h_rows, d_hmap, d_h_loc, d_sched, d_hvars;
   DevBuf<BigDesc> d_big;
@@ -303,6 +304,18 @@ gsx_status upload_problem(gsx_context* c) {
   HIPCHK(c, c->d_f_meas_off.upload(mo, st));
   HIPCHK(c, c->d_f_noise_off.upload(no, st));
   HIPCHK(c, c->d_f_jac_off.upload(jo, st));
+  {
+    // the largest [A b] range of 64 consecutive factors (the blocks are laid out in factor order)
+    int64_t worst = 0;
+    bool ordered = true;
+    for (int i0 = 0; i0 < P.n_factors; i0 += 64) {
+      const int l = std::min(P.n_factors, i0 + 64) - 1;
+      worst = std::max<int64_t>(worst, P.f_jac_off[l] + (int64_t)P.f_rows[l] * P.f_cols[l] - P.f_jac_off[i0]);
+    }
+    for (int f = 1; f < P.n_factors; ++f) ordered = ordered && P.f_jac_off[f] >= P.f_jac_off[f - 1];
+    worst = (worst + 1) & ~(int64_t)1;
+    c->lin_err_slice = (ordered && worst > 0 && 2 * worst * (int64_t)sizeof(double) <= 96 * 1024) ? (int)worst : 0;
+  }
   HIPCHK(c, c->d_meas.upload(P.meas, st));
   HIPCHK(c, c->d_noise.upload(P.noise, st));
   gsx_status fl = upload_factor_lists(c, nullptr);
@@ -976,7 +989,7 @@ void dev_backsolve(gsx_context* c) {
 void dev_linear_error(gsx_context* c) {
   timer_begin(c, PH_LINERR);
   launch_linear_error(c->DP, c->d_jac.p, c->d_delta.p, c->d_partials.p, gsx_context::kPartials, c->d_scalars.p,
-                      c->stream);
+                      c->lin_err_slice, c->stream);
   c->sc_dirty |= (1u << SC_LIN0) | (1u << SC_LIND);
   timer_end(c, PH_LINERR);
 }
@@ -1744,7 +1757,7 @@ gsx_status gsx_dogleg_optimize(gsx_handle h, double delta_initial, int32_t max_i
         dev_retract(h, h->d_dld.p);
         dev_error(h, h->d_trial.p, SC_TRIAL_ERR);
         launch_linear_error(h->DP, h->d_jac.p, h->d_dld.p, h->d_partials.p, gsx_context::kPartials, h->d_scalars.p,
-                            h->stream);
+                            h->lin_err_slice, h->stream);
         st = readback(h);
         if (st != GSX_OK) return st;
         result_f = h->h_scalars[SC_TRIAL_ERR];
