@@ -1,4 +1,5 @@
 // problem.cpp — validation and lowering of gsx_problem_desc into host tables.
+#include <cmath>
 #include <algorithm>
 
 #include "gsx_internal.h"
@@ -117,6 +118,19 @@ gsx_status lower_problem(const gsx_problem_desc* d, HostProblem& P, std::string&
         default: ok = false;
       }
       if (loss && ok) ok = P.noise[P.f_noise_ptr[f + 1] - 1] > 0;
+      // a zero sigma is the reference's noiseModel::Constrained (NoiseModel.h:389-500): it needs the QR / constrained
+      // elimination path, which is not built — refused here instead of turning into infinities later
+      if (ok && ((kind & GSX_NOISE_BASE_MASK) == GSX_NOISE_ISOTROPIC || (kind & GSX_NOISE_BASE_MASK) == GSX_NOISE_DIAGONAL)) {
+        const int64_t ns = (kind & GSX_NOISE_BASE_MASK) == GSX_NOISE_ISOTROPIC ? 1 : m;
+        for (int64_t k = 0; k < ns; ++k) {
+          const double sg = P.noise[P.f_noise_ptr[f] + k];
+          if (!(sg > 0) || !std::isfinite(sg)) {
+            err = "factor " + std::to_string(f) + ": sigma " + std::to_string(sg) +
+                  " — constrained (zero-sigma) noise models need QR elimination, which this backend does not implement";
+            return GSX_E_INVALID;
+          }
+        }
+      }
     }
     if (!ok) {
       err = "malformed factor " + std::to_string(f);

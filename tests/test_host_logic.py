@@ -157,6 +157,18 @@ def test_malformed_description_is_rejected(lib):
     assert ei.value.status == A.GSX_E_INVALID
 
 
+def test_constrained_noise_model_is_refused_not_turned_into_infinities(lib):
+    """A zero sigma is the reference's noiseModel::Constrained (gtsam/linear/NoiseModel.h:389-500), which eliminates through
+    QR (not built).  gsx_create must say so instead of whitening with 1/0."""
+    arr = PROBLEMS["pose2"]()
+    f = next(i for i in range(arr.n_factors)
+             if (int(arr.f_noise_kind[i]) & A.NOISE_BASE_MASK) in (A.NOISE_ISOTROPIC, A.NOISE_DIAGONAL))
+    arr.noise[int(arr.f_noise_ptr[f])] = 0.0
+    with pytest.raises(gt.GsxError) as ei:
+        _lib.ProductBackend(arr, host_only=True)
+    assert ei.value.status == A.GSX_E_INVALID   # (the reason goes to stderr: "constrained (zero-sigma) noise models need QR elimination")
+
+
 def test_schur_ordering_puts_landmarks_first(lib):
     arr = PROBLEMS["bal"]()
     pb = _lib.ProductBackend(arr, host_only=True)
