@@ -51,6 +51,12 @@ class PartialStats(C.Structure):
                 ("n_fronts_reeliminated", C.c_int32), ("n_fronts", C.c_int32)]
 
 
+class UpdateStats(C.Structure):
+    _fields_ = [("n_vars_added", C.c_int32), ("n_vars_removed", C.c_int32), ("n_factors_added", C.c_int32),
+                ("n_factors_removed", C.c_int32), ("n_vars_affected", C.c_int32), ("n_fronts", C.c_int32),
+                ("host_symbolic_s", C.c_double), ("device_s", C.c_double)]
+
+
 class ProductBackend(A.Backend):
     def __init__(self, arrays: A.ProblemArrays, device: int = 0, host_only: bool = False):
         """host_only=True skips the upload of the initial values: only the host-side entry points
@@ -105,6 +111,32 @@ class ProductBackend(A.Backend):
         self._check(self._fn("relinearize_partial")(self._h, ks.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int32(ks.size),
                                                     sp, C.c_int64(ns), C.byref(st)), "relinearize_partial")
         return {k: getattr(st, k) for k, _ in PartialStats._fields_}
+
+    def get_ordering(self) -> np.ndarray:
+        """gsx_get_ordering: the keys in the handle's current elimination order."""
+        out = np.zeros(self.arrays.n_vars, dtype=np.uint64)
+        self._check(self._fn("get_ordering")(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64))), "get_ordering")
+        return out
+
+    def update(self, arrays: A.ProblemArrays, factor_origin, new_values) -> dict:
+        """gsx_update (include/gsx.h) — ISAM2::update's structural part on the live handle: `arrays` is the WHOLE graph
+        after the update, factor_origin[i] the index of its factor i in the current graph (-1: new; current factors not
+        named are removed), new_values the packed states of the new variables in ascending-key order.  Kept variables
+        keep their linearization point and kept factors their [A b]; only the new factors are linearized."""
+        fo = np.ascontiguousarray(factor_origin, dtype=np.int32)
+        nv = np.ascontiguousarray(new_values, dtype=np.float64)
+        if fo.size != arrays.n_factors:
+            raise ValueError("factor_origin must have one entry per factor of the updated graph")
+        desc = arrays.desc()
+        st = UpdateStats()
+        self._check(self._fn("update")(self._h, C.byref(desc), fo.ctypes.data_as(C.POINTER(C.c_int32)),
+                                       nv.ctypes.data_as(C.POINTER(C.c_double)) if nv.size else None,
+                                       C.c_int64(nv.size), C.byref(st)), "update")
+        self.arrays, self._desc = arrays, desc
+        self.state_size = int(self._fn("state_size", C.c_int64)(self._h))
+        self.tangent_size = int(self._fn("tangent_size", C.c_int64)(self._h))
+        self.jacobian_size = int(self._fn("jacobian_size", C.c_int64)(self._h))
+        return {k: getattr(st, k) for k, _ in UpdateStats._fields_}
 
     def set_block_jacobians(self, first_factor: int, blocks):
         """gsx_set_block_jacobians: refresh the [A b] blocks of the GSX_F_LINEAR factors first_factor.. in place (blocks =

@@ -135,13 +135,14 @@ void compute_ordering(const HostProblem& P, int kind, std::vector<int>& order) {
     multilevel_nested_dissection(adj, P.dims, all, nd_leaf(24), min_degree, order);
     return;
   }
-  // SCHUR: landmarks = VECTOR(3) variables all of whose neighbours are cameras
+  // SCHUR: landmarks = VECTOR(3) variables all of whose neighbours are cameras (SFM) or poses (visual SLAM with a fixed
+  // calibration: GenericProjectionFactor<Pose3, Point3>)
   std::vector<char> is_lm(P.n_vars, 0);
   int n_lm = 0;
   for (int v = 0; v < P.n_vars; ++v) {
     if (P.types[v] != GSX_VAR_VECTOR || P.dims[v] != 3 || adj[v].empty()) continue;
     bool ok = true;
-    for (int u : adj[v]) ok = ok && P.types[u] == GSX_VAR_CAMERA;
+    for (int u : adj[v]) ok = ok && (P.types[u] == GSX_VAR_CAMERA || P.types[u] == GSX_VAR_POSE3);
     if (ok) {
       is_lm[v] = 1;
       ++n_lm;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -330,8 +331,8 @@ gsx_status upload_problem(gsx_context* c) {
   HIPCHK(c, c->d_partials.alloc(gsx_context::kPartials));
   HIPCHK(c, c->d_scalars.alloc(SC_COUNT));
   HIPCHK(c, c->d_status.alloc(1));
-  HIPCHK(c, hipHostMalloc((void**)&c->h_scalars, SC_COUNT * sizeof(double)));
-  HIPCHK(c, hipHostMalloc((void**)&c->h_status, sizeof(DevStatus)));
+  if (!c->h_scalars) HIPCHK(c, hipHostMalloc((void**)&c->h_scalars, SC_COUNT * sizeof(double)));  // (gsx_update comes here again)
+  if (!c->h_status) HIPCHK(c, hipHostMalloc((void**)&c->h_status, sizeof(DevStatus)));
   HIPCHK(c, hipMemsetAsync(c->d_scalars.p, 0, SC_COUNT * sizeof(double), st));
   HIPCHK(c, hipMemsetAsync(c->d_delta.p, 0, std::max<int64_t>(P.tan_size, 1) * sizeof(double), st));
   // LINEAR factors: their (whitened) [A b] as given at creation (gsx_set_block_jacobians refreshes them in place)
@@ -1811,101 +1812,13 @@ gsx_status gsx_dogleg_optimize(gsx_handle h, double delta_initial, int32_t max_i
 // factorization and every clean subtree's Schur complement stay resident in HBM; only what the moved variables touch
 // is redone — their factors' Jacobians, the H panels of those factors' variables, and the cliques holding them plus all
 // ancestors (a re-done clique is re-assembled from H and from ALL its children, whose stored contributions are intact).
-gsx_status gsx_relinearize_partial(gsx_handle h, const uint64_t* keys, int32_t n_keys, const double* states,
-                                   int64_t n_states, gsx_partial_stats* out) {
-  if (!h || (n_keys > 0 && !keys) || n_keys < 0) return GSX_E_INVALID;
-  gsx_status st = ensure_ready(h, true, true);
-  if (st != GSX_OK) return st;
-  if (h->sharded()) {
-    h->err = "partial re-elimination is not available on a sharded handle";
-    return GSX_E_STATE;
-  }
-  if (!h->linearized || !h->h_ready || !h->fact_valid || h->fact_lambda != 0.0) {
-    h->err = "gsx_relinearize_partial needs the resident undamped factorization of the current linearization "
-             "(gsx_linearize + gsx_solve with lambda = 0 first)";
-    return GSX_E_STATE;
-  }
-  hipSetDevice(h->device);
+namespace {
+// The three stages of a partial update (gsx_relinearize_partial, gsx_update), each driven by explicit dirty lists.
+// 1. Jacobians of the listed factors (graph order inside each family, as in the full lists)
+gsx_status partial_linearize(gsx_handle h, std::vector<int>& dfac) {
   const HostProblem& P = h->P;
-  const Symbolic& S = h->S;
   hipStream_t sm = h->stream;
-  // marked variables, and their new states
-  std::vector<int> marked(n_keys), src_off(n_keys);
-  std::vector<char> is_marked(P.n_vars, 0);
-  int64_t need = 0;
-  for (int k = 0; k < n_keys; ++k) {
-    auto it = std::lower_bound(P.keys.begin(), P.keys.end(), keys[k]);
-    if (it == P.keys.end() || *it != keys[k]) {
-      h->err = "gsx_relinearize_partial: a key is not a variable of the graph";
-      return GSX_E_INVALID;
-    }
-    const int v = (int)(it - P.keys.begin());
-    if (is_marked[v]) return GSX_E_INVALID;
-    is_marked[v] = 1;
-    marked[k] = v;
-    src_off[k] = (int)need;
-    need += (v + 1 < P.n_vars ? P.state_off[v + 1] : (int)P.state_size) - P.state_off[v];
-  }
-  if (states && n_states != need) return GSX_E_INVALID;
   gsx_context::PartialScratch& ps = h->ps;
-  if (states && n_keys > 0) {
-    HIPCHK(h, ps.marked.stage(marked, sm));
-    HIPCHK(h, ps.src_off.stage(src_off, sm));
-    HIPCHK(h, ps.states.stage(std::vector<double>(states, states + need), sm));
-    launch_scatter_states(h->DP, ps.marked.p, ps.src_off.p, n_keys, ps.states.p, h->d_values.p, sm);
-    h->values_synced = true;
-  }
-  // what is dirty: factors touching a marked variable; the H panels of all their variables; those variables' cliques and
-  // every ancestor.  (Everything below is driven by the dirty lists, not by the size of the graph.)
-  std::vector<char> f_dirty(P.n_factors, 0), v_dirty(P.n_vars, 0), fr_dirty(S.n_fronts, 0);
-  std::vector<int> dfac, dvar, dfr;
-  for (int v : marked)
-    for (int k = S.vf_ptr[v]; k < S.vf_ptr[v + 1]; ++k) {
-      const int f = S.vf[k];
-      if (f_dirty[f]) continue;
-      f_dirty[f] = 1;
-      dfac.push_back(f);
-      for (int q = P.f_key_ptr[f]; q < P.f_key_ptr[f + 1]; ++q) {
-        const int u = P.f_vars[q];
-        if (!v_dirty[u]) {
-          v_dirty[u] = 1;
-          dvar.push_back(u);
-        }
-      }
-    }
-  for (int v : dvar)
-    for (int f = S.front_of_var[v]; f >= 0 && !fr_dirty[f]; f = S.parent[f]) {
-      fr_dirty[f] = 1;
-      dfr.push_back(f);
-    }
-  if (dfac.empty()) {
-    if (out) *out = gsx_partial_stats{0, 0, 0, S.n_fronts};
-    return GSX_OK;
-  }
-  {
-    // When most of the extend-add work of the tree is dirty anyway (the big cliques near the root carry most gather
-    // segments), filtering costs more on the host than it saves on the device: take the full path — same bits.
-    int64_t dseg = 0;
-    for (int f : dfr) dseg += h->fr_seg_ptr[f + 1] - h->fr_seg_ptr[f];
-    if ((dseg * 10 > (int64_t)h->h_gsegs.size() * 3 && (int64_t)dfr.size() * 20 > S.n_fronts) ||
-        (int64_t)dfr.size() * 100 > (int64_t)S.n_fronts * 15) {
-      if (out) *out = gsx_partial_stats{P.n_factors, P.n_vars, S.n_fronts, S.n_fronts};
-      dev_linearize(h);
-      dev_assemble_h(h);
-      dev_damping(h, 0, 0, 0);
-      dev_factorize(h, 0.0);
-      st = readback(h);
-      if (st != GSX_OK) return st;
-      if (h->h_status->n_fail > 0) {
-        h->fact_valid = false;
-        h->err = "indeterminate linear system";
-        return GSX_E_INDETERMINATE;
-      }
-      return GSX_OK;
-    }
-  }
-  if (out) *out = gsx_partial_stats{(int)dfac.size(), (int)dvar.size(), (int)dfr.size(), S.n_fronts};
-  // 1. the dirty factors' Jacobians (graph order inside each family, as in the full lists)
   {
     std::sort(dfac.begin(), dfac.end());
     std::vector<int> lists[6];
@@ -1930,7 +1843,12 @@ gsx_status gsx_relinearize_partial(gsx_handle h, const uint64_t* keys, int32_t n
     launch_linearize(h->DP, lp, cnt, h->d_values.p, h->d_jac.p, h->d_status.p, sm);
     timer_end(h, PH_LINEARIZE);
   }
-  // 2. the H panels of their variables, group by group with the groups' own launch shapes
+  return GSX_OK;
+}
+// 2. the H panels of the listed variables, group by group with the groups' own launch shapes
+gsx_status partial_assemble(gsx_handle h, std::vector<int>& dvar) {
+  hipStream_t sm = h->stream;
+  gsx_context::PartialScratch& ps = h->ps;
   {
     std::sort(dvar.begin(), dvar.end(), [&](int a, int b) { return h->hv_pos[a] < h->hv_pos[b]; });
     std::vector<std::pair<int, int>> ranges(h->hgroups.size(), {0, 0});
@@ -1948,7 +1866,15 @@ gsx_status gsx_relinearize_partial(gsx_handle h, const uint64_t* keys, int32_t n
     timer_end(h, PH_ASSEMBLE_H);
     h->hdiag_ready = false;
   }
-  // 3. the dirty cliques, level by level, in the order and with the launch shapes of the full schedule
+  return GSX_OK;
+}
+// 3. the listed cliques, level by level, in the order and with the launch shapes of the full schedule (a re-done clique is
+//    re-assembled from H and from ALL its children, whose Schur complements / L panels are resident in the arena)
+gsx_status partial_factor(gsx_handle h, std::vector<int>& dfr) {
+  const Symbolic& S = h->S;
+  hipStream_t sm = h->stream;
+  gsx_context::PartialScratch& ps = h->ps;
+  gsx_status st = GSX_OK;
   {
     std::sort(dfr.begin(), dfr.end(), [&](int a, int b) { return h->fr_sched_pos[a] < h->fr_sched_pos[b]; });
     std::vector<LeafRec> leaf;
@@ -2057,6 +1983,298 @@ gsx_status gsx_relinearize_partial(gsx_handle h, const uint64_t* keys, int32_t n
     h->fact_valid = false;
     h->err = "indeterminate linear system";
     return GSX_E_INDETERMINATE;
+  }
+  return GSX_OK;
+}
+}  // namespace
+
+gsx_status gsx_relinearize_partial(gsx_handle h, const uint64_t* keys, int32_t n_keys, const double* states,
+                                   int64_t n_states, gsx_partial_stats* out) {
+  if (!h || (n_keys > 0 && !keys) || n_keys < 0) return GSX_E_INVALID;
+  gsx_status st = ensure_ready(h, true, true);
+  if (st != GSX_OK) return st;
+  if (h->sharded()) {
+    h->err = "partial re-elimination is not available on a sharded handle";
+    return GSX_E_STATE;
+  }
+  if (!h->linearized || !h->h_ready || !h->fact_valid || h->fact_lambda != 0.0) {
+    h->err = "gsx_relinearize_partial needs the resident undamped factorization of the current linearization "
+             "(gsx_linearize + gsx_solve with lambda = 0 first)";
+    return GSX_E_STATE;
+  }
+  hipSetDevice(h->device);
+  const HostProblem& P = h->P;
+  const Symbolic& S = h->S;
+  hipStream_t sm = h->stream;
+  // marked variables, and their new states
+  std::vector<int> marked(n_keys), src_off(n_keys);
+  std::vector<char> is_marked(P.n_vars, 0);
+  int64_t need = 0;
+  for (int k = 0; k < n_keys; ++k) {
+    auto it = std::lower_bound(P.keys.begin(), P.keys.end(), keys[k]);
+    if (it == P.keys.end() || *it != keys[k]) {
+      h->err = "gsx_relinearize_partial: a key is not a variable of the graph";
+      return GSX_E_INVALID;
+    }
+    const int v = (int)(it - P.keys.begin());
+    if (is_marked[v]) return GSX_E_INVALID;
+    is_marked[v] = 1;
+    marked[k] = v;
+    src_off[k] = (int)need;
+    need += (v + 1 < P.n_vars ? P.state_off[v + 1] : (int)P.state_size) - P.state_off[v];
+  }
+  if (states && n_states != need) return GSX_E_INVALID;
+  gsx_context::PartialScratch& ps = h->ps;
+  if (states && n_keys > 0) {
+    HIPCHK(h, ps.marked.stage(marked, sm));
+    HIPCHK(h, ps.src_off.stage(src_off, sm));
+    HIPCHK(h, ps.states.stage(std::vector<double>(states, states + need), sm));
+    launch_scatter_states(h->DP, ps.marked.p, ps.src_off.p, n_keys, ps.states.p, h->d_values.p, sm);
+    h->values_synced = true;
+  }
+  // what is dirty: factors touching a marked variable; the H panels of all their variables; those variables' cliques and
+  // every ancestor.  (Everything below is driven by the dirty lists, not by the size of the graph.)
+  std::vector<char> f_dirty(P.n_factors, 0), v_dirty(P.n_vars, 0), fr_dirty(S.n_fronts, 0);
+  std::vector<int> dfac, dvar, dfr;
+  for (int v : marked)
+    for (int k = S.vf_ptr[v]; k < S.vf_ptr[v + 1]; ++k) {
+      const int f = S.vf[k];
+      if (f_dirty[f]) continue;
+      f_dirty[f] = 1;
+      dfac.push_back(f);
+      for (int q = P.f_key_ptr[f]; q < P.f_key_ptr[f + 1]; ++q) {
+        const int u = P.f_vars[q];
+        if (!v_dirty[u]) {
+          v_dirty[u] = 1;
+          dvar.push_back(u);
+        }
+      }
+    }
+  for (int v : dvar)
+    for (int f = S.front_of_var[v]; f >= 0 && !fr_dirty[f]; f = S.parent[f]) {
+      fr_dirty[f] = 1;
+      dfr.push_back(f);
+    }
+  if (dfac.empty()) {
+    if (out) *out = gsx_partial_stats{0, 0, 0, S.n_fronts};
+    return GSX_OK;
+  }
+  {
+    // When most of the extend-add work of the tree is dirty anyway (the big cliques near the root carry most gather
+    // segments), filtering costs more on the host than it saves on the device: take the full path — same bits.
+    int64_t dseg = 0;
+    for (int f : dfr) dseg += h->fr_seg_ptr[f + 1] - h->fr_seg_ptr[f];
+    if ((dseg * 10 > (int64_t)h->h_gsegs.size() * 3 && (int64_t)dfr.size() * 20 > S.n_fronts) ||
+        (int64_t)dfr.size() * 100 > (int64_t)S.n_fronts * 15) {
+      if (out) *out = gsx_partial_stats{P.n_factors, P.n_vars, S.n_fronts, S.n_fronts};
+      dev_linearize(h);
+      dev_assemble_h(h);
+      dev_damping(h, 0, 0, 0);
+      dev_factorize(h, 0.0);
+      st = readback(h);
+      if (st != GSX_OK) return st;
+      if (h->h_status->n_fail > 0) {
+        h->fact_valid = false;
+        h->err = "indeterminate linear system";
+        return GSX_E_INDETERMINATE;
+      }
+      return GSX_OK;
+    }
+  }
+  if (out) *out = gsx_partial_stats{(int)dfac.size(), (int)dvar.size(), (int)dfr.size(), S.n_fronts};
+  st = partial_linearize(h, dfac);
+  if (st != GSX_OK) return st;
+  st = partial_assemble(h, dvar);
+  if (st != GSX_OK) return st;
+  return partial_factor(h, dfr);
+}
+
+// ISAM2::update's structural part on a live handle (include/gsx.h).  The numeric state that survives: the values of the
+// kept variables and the [A b] blocks of the kept factors (iSAM2's fixed linearization point).
+gsx_status gsx_update(gsx_handle h, const gsx_problem_desc* desc, const int32_t* factor_origin, const double* new_values,
+                      int64_t n_new_values, gsx_update_stats* out) {
+  if (!h || !desc || (desc->n_factors > 0 && !factor_origin)) return GSX_E_INVALID;
+  gsx_status st = need_device(h);
+  if (st != GSX_OK) return st;
+  if (h->sharded()) {
+    h->err = "gsx_update is not available on a sharded handle";
+    return GSX_E_STATE;
+  }
+  if (!h->has_symbolic || !h->values_set) {
+    h->err = "gsx_update needs a handle with values and an ordering (gsx_set_values, gsx_set_ordering first)";
+    return GSX_E_STATE;
+  }
+  hipSetDevice(h->device);
+  HostProblem P2;
+  st = lower_problem(desc, P2, h->err);
+  if (st != GSX_OK) return st;
+  const HostProblem& P1 = h->P;
+  auto state_len = [](const HostProblem& P, int v) {
+    return (v + 1 < P.n_vars ? (int64_t)P.state_off[v + 1] : P.state_size) - P.state_off[v];
+  };
+  // variables: kept by key
+  std::vector<int> old_of(P2.n_vars, -1), new_of(P1.n_vars, -1);
+  int64_t need = 0;
+  int n_added = 0;
+  for (int v = 0; v < P2.n_vars; ++v) {
+    auto it = std::lower_bound(P1.keys.begin(), P1.keys.end(), P2.keys[v]);
+    if (it != P1.keys.end() && *it == P2.keys[v]) {
+      const int o = (int)(it - P1.keys.begin());
+      if (P1.types[o] != P2.types[v] || P1.dims[o] != P2.dims[v]) {
+        h->err = "gsx_update: a kept variable changed its type or dimension";
+        return GSX_E_INVALID;
+      }
+      old_of[v] = o;
+      new_of[o] = v;
+    } else {
+      need += state_len(P2, v);
+      ++n_added;
+    }
+  }
+  if (need != n_new_values || (need > 0 && !new_values)) {
+    h->err = "gsx_update: new_values does not hold exactly the states of the new variables";
+    return GSX_E_INVALID;
+  }
+  // factors: kept by origin (same shape), and which variables the change touches
+  std::vector<char> used(P1.n_factors, 0), affected(P2.n_vars, 0);
+  int n_fadd = 0;
+  for (int f = 0; f < P2.n_factors; ++f) {
+    const int o = factor_origin[f];
+    if (o < -1 || o >= P1.n_factors || (o >= 0 && used[o])) {
+      h->err = "gsx_update: factor_origin is not an injective map into the current factors";
+      return GSX_E_INVALID;
+    }
+    if (o >= 0) {
+      bool same = P1.f_rows[o] == P2.f_rows[f] && P1.f_cols[o] == P2.f_cols[f] && P1.f_type[o] == P2.f_type[f] &&
+                  P1.f_key_ptr[o + 1] - P1.f_key_ptr[o] == P2.f_key_ptr[f + 1] - P2.f_key_ptr[f];
+      for (int q = 0; same && q < P2.f_key_ptr[f + 1] - P2.f_key_ptr[f]; ++q)
+        same = old_of[P2.f_vars[P2.f_key_ptr[f] + q]] == P1.f_vars[P1.f_key_ptr[o] + q];
+      if (!same) {
+        h->err = "gsx_update: a kept factor changed its shape or its variables";
+        return GSX_E_INVALID;
+      }
+      used[o] = 1;
+    } else {
+      ++n_fadd;
+      for (int q = P2.f_key_ptr[f]; q < P2.f_key_ptr[f + 1]; ++q) affected[P2.f_vars[q]] = 1;
+    }
+  }
+  int n_frem = 0, n_vrem = 0;
+  for (int o = 0; o < P1.n_factors; ++o)
+    if (!used[o]) {
+      ++n_frem;
+      for (int q = P1.f_key_ptr[o]; q < P1.f_key_ptr[o + 1]; ++q)
+        if (new_of[P1.f_vars[q]] >= 0) affected[new_of[P1.f_vars[q]]] = 1;
+    }
+  for (int o = 0; o < P1.n_vars; ++o) n_vrem += new_of[o] < 0;
+  for (int v = 0; v < P2.n_vars; ++v)
+    if (old_of[v] < 0) affected[v] = 1;
+  // the states: current ones of the kept variables + the given ones of the new variables
+  std::vector<double> vals1(std::max<int64_t>(P1.state_size, 1)), vals2(std::max<int64_t>(P2.state_size, 1));
+  {
+    double tmp = 0;
+    st = gsx_get_values(h, P1.state_size > 0 ? vals1.data() : &tmp, P1.state_size);
+    if (st != GSX_OK) return st;
+    int64_t src = 0;
+    for (int v = 0; v < P2.n_vars; ++v) {
+      const int64_t len = state_len(P2, v);
+      if (old_of[v] >= 0) std::copy_n(vals1.data() + P1.state_off[old_of[v]], len, vals2.data() + P2.state_off[v]);
+      else {
+        std::copy_n(new_values + src, len, vals2.data() + P2.state_off[v]);
+        src += len;
+      }
+    }
+  }
+  const bool keep_jac = h->linearized;
+  // elimination order: unaffected variables in their current relative order, then the affected ones by static degree
+  std::vector<int> ord;
+  ord.reserve(P2.n_vars);
+  for (int pos = 0; pos < P1.n_vars; ++pos) {
+    const int v = new_of[h->S.order[pos]];
+    if (v >= 0 && !affected[v]) ord.push_back(v);
+  }
+  {
+    std::vector<int> deg(P2.n_vars, 0), aff;
+    for (int f = 0; f < P2.n_factors; ++f) {
+      const int nk = P2.f_key_ptr[f + 1] - P2.f_key_ptr[f];
+      for (int q = P2.f_key_ptr[f]; q < P2.f_key_ptr[f + 1]; ++q) deg[P2.f_vars[q]] += nk - 1;
+    }
+    for (int v = 0; v < P2.n_vars; ++v)
+      if (affected[v]) aff.push_back(v);
+    std::stable_sort(aff.begin(), aff.end(), [&](int a, int b) { return deg[a] < deg[b]; });
+    ord.insert(ord.end(), aff.begin(), aff.end());
+  }
+  // switch the handle over
+  const double relax = h->S.relax;
+  const int relax_max_f = h->S.relax_max_f;
+  HostProblem P_old = std::move(h->P);
+  DevBuf<double> jac_old;
+  std::swap(jac_old.p, h->d_jac.p);
+  std::swap(jac_old.n, h->d_jac.n);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const auto t0 = std::chrono::steady_clock::now();
+  h->P = std::move(P2);
+  const HostProblem& P = h->P;
+  st = upload_problem(h);
+  if (st != GSX_OK) return st;
+  HIPCHK(h, hipMemcpyAsync(h->d_values.p, vals2.data(), (size_t)P.state_size * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  h->values_set = true;
+  h->values_synced = true;
+  if (keep_jac) {
+    // kept [A b] blocks, device to device, contiguous runs merged
+    int64_t src0 = 0, dst0 = 0, len0 = 0;
+    auto flush = [&]() -> hipError_t {
+      if (!len0) return hipSuccess;
+      const hipError_t e = hipMemcpyAsync(h->d_jac.p + dst0, jac_old.p + src0, (size_t)len0 * sizeof(double),
+                                          hipMemcpyDeviceToDevice, h->stream);
+      len0 = 0;
+      return e;
+    };
+    for (int f = 0; f < P.n_factors; ++f) {
+      const int o = factor_origin[f];
+      if (o < 0) continue;
+      const int64_t s0 = P_old.f_jac_off[o], d0 = P.f_jac_off[f], len = (int64_t)P.f_rows[f] * P.f_cols[f];
+      if (len0 && s0 == src0 + len0 && d0 == dst0 + len0) len0 += len;
+      else {
+        HIPCHK(h, flush());
+        src0 = s0;
+        dst0 = d0;
+        len0 = len;
+      }
+    }
+    HIPCHK(h, flush());
+  }
+  const auto t1 = std::chrono::steady_clock::now();
+  h->relax = relax;
+  h->relax_max_f = relax_max_f;
+  st = symbolic_analysis(h->P, ord, h->relax, h->relax_max_f, 0, 1, h->S, h->err);
+  if (st != GSX_OK) return st;
+  h->order = ord;
+  h->has_symbolic = true;
+  st = upload_symbolic(h);
+  if (st != GSX_OK) return st;
+  const auto t2 = std::chrono::steady_clock::now();
+  h->linearized = h->h_ready = h->solved = h->fact_valid = false;
+  h->hdiag_ready = h->damp_ready = false;
+  if (keep_jac) {
+    std::vector<int> dfac;
+    for (int f = 0; f < P.n_factors; ++f)
+      if (factor_origin[f] < 0) dfac.push_back(f);
+    hipMemsetAsync(&h->d_status.p->n_cheirality, 0, sizeof(int), h->stream);
+    st = partial_linearize(h, dfac);
+    if (st != GSX_OK) return st;
+    h->sc_dirty |= kXLin;
+    h->linearized = true;  // every factor has its [A b]: the kept ones at their old linearization point
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const auto t3 = std::chrono::steady_clock::now();
+  if (out) {
+    int n_aff = 0;
+    for (char a : affected) n_aff += a;
+    auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+      return std::chrono::duration<double>(b - a).count();
+    };
+    *out = gsx_update_stats{n_added, n_vrem, n_fadd, n_frem, n_aff, h->S.n_fronts, sec(t1, t2), sec(t0, t1) + sec(t2, t3)};
   }
   return GSX_OK;
 }

@@ -510,3 +510,88 @@ def _quat_from_R(R):
     q[1 + j] = (R[j, i] + R[i, j]) / s
     q[1 + k] = (R[k, i] + R[i, k]) / s
     return tuple(q)
+
+
+# ------------------------------------------------------------------------------------------
+# visual SLAM (GenericProjectionFactor<Pose3,Point3,Cal3_S2>) at scale, and its growth by one keyframe
+# ------------------------------------------------------------------------------------------
+def synth_visual_slam(n_poses: int, n_points: int, n_obs: int, seed: int = 9, upto: int = None):
+    """A vehicle driving along a street (examples/VisualISAM2Example.cpp, SURVEY §8 config 5, scaled): keyframe i at
+    (i, 0, 0) looking sideways (+y), landmarks 6-14 m to the side, each seen from a window of k >= 2 consecutive keyframes
+    centred on it (sum k = n_obs) — parallax does not shrink as the trajectory grows.  Fixed Cal3_S2 calibration
+    (f = 800), pixel sigma 0.5; a prior on the first pose and odometry BetweenFactors along the trajectory.
+    `upto` = only the keyframes [0, upto) and the landmarks seen at least twice from them (a landmark enters the graph at
+    its second sighting).  Factor order: prior, odometry, then the projections sorted by (keyframe, landmark);
+    `factor_ids` (one 64-bit id per factor, stable across `upto`) lets a caller build gsx_update's factor_origin.
+    Returns (ProblemArrays, factor_ids)."""
+    rng = np.random.default_rng(seed)
+    upto = n_poses if upto is None else int(upto)
+    f = 800.0
+    k = np.full(n_points, 2, np.int64)
+    extra = n_obs - 2 * n_points
+    if extra < 0:
+        raise ValueError("need n_obs >= 2 n_points")
+    cap = min(n_poses, 24)
+    while extra > 0:
+        add = rng.multinomial(extra, np.full(n_points, 1.0 / n_points))
+        newk = np.minimum(k + add, cap)
+        extra -= int((newk - k).sum())
+        k = newk
+        if np.all(k == cap):
+            raise ValueError("too many observations for this many keyframes")
+    start = (rng.random(n_points) * (n_poses - k + 1)).astype(np.int64)
+    pt = np.repeat(np.arange(n_points), k)
+    cam = np.repeat(start, k) + (np.arange(pt.size) - np.repeat(_csr(k)[:-1], k))
+    points = np.stack([start + 0.5 * (k - 1) + rng.uniform(-0.5, 0.5, n_points), rng.uniform(6, 14, n_points),
+                       rng.uniform(-2, 2, n_points)], axis=1)
+    R1 = np.array([[1.0, 0.0, 0.0], [0.0, 0.0, 1.0], [0.0, -1.0, 0.0]])   # columns: x_c = +x, y_c = -z, z_c = +y (world)
+    R = np.broadcast_to(R1, (n_poses, 3, 3)).copy()
+    t = np.stack([np.arange(n_poses, dtype=float), np.zeros(n_poses), np.zeros(n_poses)], axis=1)
+    q = np.einsum("nji,nj->ni", R[cam], points[pt] - t[cam])
+    assert np.all(q[:, 2] > 0)
+    uv = f * q[:, :2] / q[:, 2:3] + rng.normal(0, 0.5, (cam.size, 2))
+    dR, dt = _pose3_expmap(rng.normal(0, 0.01, (n_poses, 6)))
+    init_R = R @ dR
+    init_t = t + np.einsum("nij,nj->ni", R, dt)
+    init_pts = points + rng.normal(0, 0.05, points.shape)
+    keep = cam < upto
+    cnt = np.bincount(pt[keep], minlength=n_points)
+    keep &= cnt[pt] >= 2
+    o = np.lexsort((pt[keep], cam[keep]))
+    cam_k, pt_k, uv_k = cam[keep][o], pt[keep][o], uv[keep][o]
+    lm = np.flatnonzero(cnt >= 2)
+    lm_pos = np.full(n_points, -1, np.int64)
+    lm_pos[lm] = np.arange(lm.size)
+    n_l, n_x = lm.size, upto
+    keys = np.concatenate([(np.uint64(ord("l")) << np.uint64(56)) | lm.astype(np.uint64),
+                           (np.uint64(ord("x")) << np.uint64(56)) | np.arange(n_x, dtype=np.uint64)])
+    types = np.concatenate([np.full(n_l, A.VAR_VECTOR), np.full(n_x, A.VAR_POSE3)])
+    dims = np.concatenate([np.full(n_l, 3), np.full(n_x, 6)])
+    # factors: prior on x0, odometry x_{i-1} -> x_i (true relative pose), projections
+    Rt = np.concatenate([R.reshape(-1, 9), t], axis=1)[:upto]   # (the prior and the odometry carry the true poses)
+    n_odo, n_proj = upto - 1, cam_k.size
+    Rrel = np.einsum("nji,njk->nik", R[:upto - 1], R[1:upto])
+    trel = np.einsum("nji,nj->ni", R[:upto - 1], t[1:upto] - t[:upto - 1])
+    odo_meas = np.concatenate([Rrel.reshape(-1, 9), trel], axis=1)
+    nf = 1 + n_odo + n_proj
+    f_type = np.concatenate([[A.F_PRIOR], np.full(n_odo, A.F_BETWEEN), np.full(n_proj, A.F_PROJECTION)])
+    f_rows = np.concatenate([[6], np.full(n_odo, 6), np.full(n_proj, 2)])
+    nk = np.concatenate([[1], np.full(n_odo, 2), np.full(n_proj, 2)])
+    xi = n_l + np.arange(upto)
+    fv = np.concatenate([[xi[0]], np.stack([xi[:-1], xi[1:]], axis=1).reshape(-1),
+                         np.stack([n_l + cam_k, lm_pos[pt_k]], axis=1).reshape(-1)])
+    Kv = np.array([f, f, 0.0, 0.0, 0.0])
+    meas = np.concatenate([Rt[0], odo_meas.reshape(-1),
+                           np.concatenate([uv_k, np.broadcast_to(Kv, (n_proj, 5))], axis=1).reshape(-1)])
+    nmeas = np.concatenate([[12], np.full(n_odo, 12), np.full(n_proj, 7)])
+    nkind = np.concatenate([[A.NOISE_DIAGONAL], np.full(n_odo, A.NOISE_DIAGONAL), np.full(n_proj, A.NOISE_ISOTROPIC)])
+    nnoise = np.concatenate([[6], np.full(n_odo, 6), np.full(n_proj, 1)])
+    noise = np.concatenate([[0.01] * 3 + [0.05] * 3, np.tile([0.02] * 3 + [0.1] * 3, n_odo), np.full(n_proj, 0.5)])
+    values = np.concatenate([init_pts[lm].reshape(-1),
+                             np.concatenate([init_R[:upto].reshape(-1, 9), init_t[:upto]], axis=1).reshape(-1)])
+    ids = np.concatenate([[0], 1 + np.arange(n_odo), (1 << 40) + cam_k * np.int64(n_points) + pt_k]).astype(np.int64)
+    arr = A.ProblemArrays(
+        var_keys=keys, var_types=types, var_dims=dims, f_type=f_type, f_rows=f_rows, f_key_ptr=_csr(nk), f_vars=fv,
+        f_meas_ptr=_csr(nmeas), meas=meas, f_noise_kind=nkind, f_noise_ptr=_csr(nnoise), noise=noise, values=values,
+        meta=dict(kind="visual_slam", n_poses=upto, n_landmarks=int(n_l), n_obs=int(n_proj), seed=seed))
+    return arr, ids

@@ -437,13 +437,36 @@ gsx_status gsx_joint_marginal_covariance(gsx_handle h, const uint64_t* keys, int
  * factorization at the same values.  Needs the resident undamped factorization of the current linearization
  * (GSX_E_STATE otherwise); follow with gsx_solve(h, 0, ...) — which then only back-substitutes — or the marginal queries.
  * When most of the tree is dirty anyway the call takes the full path (same bits; the stats then report everything).
- * Not here yet: adding factors / variables (tree surgery with constrained re-ordering) and the partial ("wildfire")
- * back-substitution. */
+ * Adding / removing factors and variables: gsx_update below.  Not here yet: the partial ("wildfire") back-substitution. */
 typedef struct gsx_partial_stats {
   int32_t n_factors_relinearized, n_panels_reassembled, n_fronts_reeliminated, n_fronts;
 } gsx_partial_stats;
 gsx_status gsx_relinearize_partial(gsx_handle h, const uint64_t* keys, int32_t n_keys, const double* states,
                                    int64_t n_states, gsx_partial_stats* out);
+/* ---- structural update of a live handle: ISAM2::update(newFactors, newTheta, removeFactorIndices) ------------------------
+ * (gtsam/nonlinear/ISAM2.cpp:395-484; the reference then detaches the affected part of the Bayes tree, re-orders it with
+ * constrained COLAMD and re-eliminates it, ISAM2.cpp:117-362.)
+ * `desc` describes the WHOLE graph after the update: the variables and factors that stay plus the new ones, in any
+ * position.  factor_origin[i] = index, in the handle's current graph, of new factor i, or -1 for a factor that is new;
+ * current factors that no entry names are removed.  A variable is kept when its key exists on both sides (type and
+ * dimension must agree); new_values = the states of the NEW variables, packed in ascending-key order.
+ * Semantics (iSAM2's): kept variables keep their current linearization point and kept factors their current [A b]
+ * (copied on the device, not re-linearized); only the new factors are linearized.  Elimination order: the unaffected
+ * variables keep their relative order, the affected ones — the variables of added / removed factors and the new
+ * variables — are moved to the end, least-connected first (the constrained ordering of ISAM2.cpp:265-299, with a static
+ * degree rule in place of CCOLAMD); the amalgamation setting of the current tree is kept; gsx_set_ordering afterwards
+ * replaces the ordering like on any handle.
+ * What is NOT incremental: the symbolic analysis is redone for the whole graph on the host (O(graph), not O(affected)),
+ * and the next solve re-eliminates the whole tree on the device (milliseconds; gsx_relinearize_partial remains
+ * available afterwards for moved variables).  The stats say what the update cost.  Not on a sharded handle. */
+typedef struct gsx_update_stats {
+  int32_t n_vars_added, n_vars_removed, n_factors_added, n_factors_removed, n_vars_affected, n_fronts;
+  double host_symbolic_s;        /* ordering + symbolic analysis + upload of the tables */
+  double device_s;               /* copies + linearization of the new factors (stream time, synchronised) */
+} gsx_update_stats;
+gsx_status gsx_update(gsx_handle h, const gsx_problem_desc* desc, const int32_t* factor_origin, const double* new_values,
+                      int64_t n_new_values, gsx_update_stats* out);
+
 /* DoglegOptimizerImpl::ComputeDoglegPoint (DoglegOptimizerImpl.cpp:26-86) on plain vectors (host). */
 gsx_status gsx_dogleg_point(double delta, const double* dx_u, const double* dx_n, int64_t n, double* out);
 

@@ -179,6 +179,26 @@ def test_schur_ordering_puts_landmarks_first(lib):
     assert all(t == A.VAR_VECTOR for t in types[:n_pts]) and all(t == A.VAR_CAMERA for t in types[n_pts:])
 
 
+def test_schur_orderings_know_pose_landmark_graphs(lib):
+    """Visual SLAM with a fixed calibration (GenericProjectionFactor<Pose3, Point3>: SURVEY §8 config 5) has the same
+    bipartite shape as SFM: its landmarks go first too, and the nested dissection of the reduced pose graph keeps the
+    tree of a 600-keyframe street shallow (minimum degree over everything gives a chain as long as the street)."""
+    arr, ids = datasets.synth_visual_slam(600, 20000, 90000, seed=4)
+    assert len(set(ids.tolist())) == arr.n_factors
+    pb = _lib.ProductBackend(arr, host_only=True)
+    idx = {int(k): i for i, k in enumerate(arr.var_keys)}
+    for kind in (A.ORDER_SCHUR, A.ORDER_SCHUR_ND):
+        o = pb.compute_ordering(kind)
+        types = [int(arr.var_types[idx[int(k)]]) for k in o]
+        n_l = arr.meta["n_landmarks"]
+        assert all(t == A.VAR_VECTOR for t in types[:n_l]) and all(t == A.VAR_POSE3 for t in types[n_l:])
+    pb.set_ordering(pb.compute_ordering(A.ORDER_SCHUR_ND))
+    assert pb.stats()["n_levels"] <= 12
+    # growth by one keyframe: the smaller graph's factors keep their ids
+    a1, id1 = datasets.synth_visual_slam(600, 20000, 90000, seed=4, upto=599)
+    assert set(id1.tolist()) <= set(ids.tolist()) and a1.n_vars < arr.n_vars
+
+
 @pytest.mark.skipif(_lib.device_count() > 0, reason="only meaningful without a GPU")
 def test_no_gpu_means_loud_failure_not_fallback(lib):
     arr = PROBLEMS["pose2"]()
