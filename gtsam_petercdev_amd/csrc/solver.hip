@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <chrono>
 #include <climits>
 #include <cmath>
@@ -362,10 +363,12 @@ gsx_status upload_problem(gsx_context* c) {
 }
 
 int small_threads_for(int n) {
-  if (n <= 48) return 64;
-  if (n <= 72) return 128;
-  if (n <= 100) return 256;
-  return 512;
+  static const int shift = std::getenv("GSX_SMALL_THREADS_SHIFT") ? std::atoi(std::getenv("GSX_SMALL_THREADS_SHIFT")) : 0;
+  int t = 512;
+  if (n <= 48) t = 64;
+  else if (n <= 72) t = 128;
+  else if (n <= 100) t = 256;
+  return std::min(512, t << shift);
 }
 
 // Build the launch plan (host) and upload the symbolic tables.

@@ -9,12 +9,28 @@
 // build everything the device needs: per-front variable lists and scalar row maps, the
 // per-variable Hessian panels with their assembly term lists, the level schedule and the arena
 // layout.  The reference redoes this work at every solve (EliminateableFactorGraph-inst.h:123-146).
+#include <cstdio>
+#include <cstdlib>
+#include <chrono>
 #include <algorithm>
 #include <numeric>
 
 #include "gsx_internal.h"
 
 namespace gsx {
+
+namespace {
+struct PhaseClock {   // GSX_TIME_SYMBOLIC=1: phase times of the analysis on stderr
+  bool on = std::getenv("GSX_TIME_SYMBOLIC") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void mark(const char* what) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[symbolic] %-28s %8.3f s\n", what, std::chrono::duration<double>(now - t).count());
+    t = now;
+  }
+};
+}  // namespace
 
 gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order, double relax, int relax_max_f,
                              int shard_rank, int shard_world, Symbolic& S, std::string& err) {
@@ -23,6 +39,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     err = "ordering size differs from the number of variables";
     return GSX_E_BAD_ORDERING;
   }
+  PhaseClock clk;
   S = Symbolic();
   S.relax = relax;
   S.relax_max_f = relax_max_f;
@@ -50,6 +67,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
   }
   S.vf_ptr = vf_ptr;
   S.vf = vf;
+  clk.mark("variable-factor lists");
   // ---- elimination tree (nodes are elimination positions) -------------------------------------
   std::vector<int> eparent(n, -1), ancestor(n, -1), prevCol(m, -1);
   std::vector<int> ech_ptr(n + 1, 0);
@@ -89,6 +107,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     std::vector<int> fill(ech_ptr.begin(), ech_ptr.end() - 1);
     for (auto& e : child_edges) ech[fill[e.first]++] = e.second;  // attachment order preserved
   }
+  clk.mark("elimination tree");
   // ---- symbolic column structures: struct[j] = later positions coupled to j, ascending ----------
   std::vector<std::vector<int>> st(n);
   std::vector<int> stamp(n, -1);
@@ -114,6 +133,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
         }
     std::sort(s.begin(), s.end());
   }
+  clk.mark("column structures");
   // ---- supernodes: the reference's merge rule ------------------------------------------------------
   // merged[j] = true when node j was merged into its etree parent's cluster.
   std::vector<char> merged(n, 0);
@@ -267,6 +287,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     S.children.resize(S.child_ptr[nfr]);
     for (int f = 0; f < nfr; ++f) std::copy(kids[f].begin(), kids[f].end(), S.children.begin() + S.child_ptr[f]);
   }
+  clk.mark("supernodes + amalgamation");
   // ---- per-front variable lists (frontals by position, then separator = struct of the top) -------
   S.fvar_ptr.assign(nfr + 1, 0);
   {
@@ -284,6 +305,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
       for (int pj : st[top_of_front[f]]) S.fvars[fill[f]++] = order[pj];
   }
   std::vector<std::vector<int>>().swap(st);
+  clk.mark("front variable lists");
   // ---- dims, arena layout, levels ---------------------------------------------------------------------
   S.F.assign(nfr, 0);
   S.S.assign(nfr, 0);
@@ -307,6 +329,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
   }
   for (int f = 0; f < nfr; ++f)  // children have smaller ids
     if (S.parent[f] >= 0) S.level[S.parent[f]] = std::max(S.level[S.parent[f]], S.level[f] + 1);
+  clk.mark("dims, arena, levels");
   // ---- sharding: cap + subtrees dealt to the ranks (proportional mapping of the assembly tree) -------------------
   // sub[f] = flop estimate of f's whole subtree.  Fronts with sub[f] above a share of the total form the cap (an
   // upward-closed set: a parent's subtree contains its children's); what hangs below the cap is a forest of independent
@@ -465,6 +488,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
   }
   S.n_levels = 0;
   for (int f = 0; f < nfr; ++f) S.n_levels = std::max(S.n_levels, S.level[f] + 1);
+  clk.mark("sharding");
   // ---- H panels and assembly terms (per variable) -----------------------------------------------------
   S.h_off.assign(n + 1, 0);
   S.h_rows.assign(n, 0);
@@ -555,6 +579,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
       }
     }
   }
+  clk.mark("H panels and terms");
   // ---- scalar row maps ----------------------------------------------------------------------------------
   S.cmap_ptr.assign(nfr + 1, 0);
   S.gidx_ptr.assign(nfr + 1, 0);
@@ -609,6 +634,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
       for (int k = S.fvar_ptr[f]; k < S.fvar_ptr[f + 1]; ++k) loc[S.fvars[k]] = -1;
     }
   }
+  clk.mark("row maps");
   // ---- schedule: by level; inside a level: leaf-kernel fronts, other small (LDS) fronts by N, big fronts ----
   auto cls = [&](int f) { return (int)S.cls[f]; };
   S.sched.clear();
@@ -633,97 +659,145 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     while (e < S.lvl_ptr[l + 1] && cls(S.sched[e]) == 1) ++e;
     S.lvl_small_end[l] = e;
   }
+  clk.mark("schedule");
   // ---- gather tasks for big parents ------------------------------------------------------------------------
   {
-    struct Contribution {
-      int level, front;
-      int64_t dst;
-      int ld, dims, child, loc, loc2;   // loc2 >= 0: lean child, product form (rows loc.., rows loc2.. of its L panel)
+    // A task = one destination block of a big parent at one level; its sources in child order.  Tasks are wanted sorted
+    // by (level, destination).  The parents' arena blocks are disjoint, so that order is: levels ascending, inside a level
+    // the parents by arena offset, inside a parent the blocks column by column — each parent's contributions are
+    // bucketed by (level, block) with a counting sort while they are generated (a global sort of the 48-byte
+    // contribution records was 3/4 of the whole analysis at 10^6 landmarks).
+    struct Local {
+      int key, child, loc, loc2;   // key = level rank << 24 | column block * (nvp + 1) + row block
     };
-    std::vector<Contribution> cs;
-    std::vector<int> lo;  // local scalar offsets of the parent's variables
-    for (int p = 0; p < nfr; ++p) {
-      if (S.cls[p] != 2 || !S.scheduled[p]) continue;
-      // parent local offset of each variable
-      std::vector<std::pair<int, int>> ploc;  // (var, offset)
+    struct Src {
+      int child, loc, loc2;
+    };
+    struct LevelOut {
+      std::vector<int64_t> dst, ptr;   // per task: destination, first source
+      std::vector<int> ld, dims, front;
+      std::vector<Src> src;
+    };
+    std::vector<LevelOut> lout(S.n_levels);
+    std::vector<int> parents;
+    for (int p = 0; p < nfr; ++p)
+      if (S.cls[p] == 2 && S.scheduled[p]) parents.push_back(p);
+    std::sort(parents.begin(), parents.end(), [&](int x, int y) { return S.off[x] < S.off[y]; });
+    std::vector<Local> loc, loc_sorted;
+    std::vector<int> pvar_idx(n, -1), poffv, pdim, cidx, coff, bucket;
+    for (int p : parents) {
+      // parent-local index and scalar offset of each of its variables (+ the rhs as one more "variable")
+      const int nvp = S.fvar_ptr[p + 1] - S.fvar_ptr[p];
+      poffv.assign(nvp + 1, 0);
+      pdim.assign(nvp + 1, 1);
       int o = 0;
-      for (int k = S.fvar_ptr[p]; k < S.fvar_ptr[p + 1]; ++k) {
-        ploc.push_back({S.fvars[k], o});
-        o += P.dims[S.fvars[k]];
+      for (int k = 0; k < nvp; ++k) {
+        const int u = S.fvars[S.fvar_ptr[p] + k];
+        pvar_idx[u] = k;
+        poffv[k] = o;
+        pdim[k] = P.dims[u];
+        o += P.dims[u];
       }
+      poffv[nvp] = S.N[p] - 1;
+      // the (at most three) levels its contributions run at: 0 for lean children, the first cap level for a subtree's
+      // contribution to a cap front, its own level otherwise
+      int lv[3] = {0, S.level[p], S.level[p]};
+      if (S.owner[p] < 0) lv[1] = S.cap_level0;
+      loc.clear();
       for (int ci = S.child_ptr[p]; ci < S.child_ptr[p + 1]; ++ci) {
         const int ch = S.children[ci];
         if (!S.scheduled[ch]) continue;  // another rank's subtree: its contribution arrives with the exchange
         const int Fc = S.F[ch], Nc = S.N[ch];
-        // child's separator blocks: (parent offset, child offset, dim); the rhs is the last block
-        std::vector<int> poff, coff, dim;
+        cidx.clear();
+        coff.clear();
         int co = 0;
-        size_t pi = 0;
         for (int k = S.fvar_ptr[ch] + nfv[ch]; k < S.fvar_ptr[ch + 1]; ++k) {
           const int u = S.fvars[k];
-          while (pi < ploc.size() && ploc[pi].first != u) ++pi;  // both lists are in elimination order
-          if (pi == ploc.size()) {
+          if (pvar_idx[u] < 0) {
             err = "internal: child separator variable missing from big parent";
             return GSX_E_INVALID;
           }
-          poff.push_back(ploc[pi].second);
+          cidx.push_back(pvar_idx[u]);
           coff.push_back(co);
-          dim.push_back(P.dims[u]);
           co += P.dims[u];
         }
-        poff.push_back(S.N[p] - 1);
+        cidx.push_back(nvp);
         coff.push_back(co);
-        dim.push_back(1);
-        const int nb = (int)dim.size();
+        const int nb = (int)cidx.size();
+        // product-form sources (lean children) depend on the leaf kernel only: all of them, for every parent level, go
+        // into gather group 0, launched once right after the leaves (throughput-bound), which leaves the per-level
+        // gathers on the latency-bound chain with the few stored complements of big children
+        const int rank = S.lean[ch] ? 0 : ((S.owner[p] < 0 && S.owner[ch] >= 0) ? 1 : 2);
         for (int a = 0; a < nb; ++a)
           for (int b = a; b < nb; ++b) {  // block (row b, col a), b >= a
-            Contribution c;
-            // a subtree's contribution to a cap front goes in with the first cap level, before the exchange; the cap
-            // fronts' own contributions follow level by level after it, the same on every rank
-            c.level = (S.owner[p] < 0 && S.owner[ch] >= 0) ? S.cap_level0 : S.level[p];
-            c.front = p;
-            c.dst = S.off[p] + poff[b] + (int64_t)poff[a] * S.N[p];
-            c.ld = S.N[p];
-            c.dims = dim[b] | (dim[a] << 8) | ((a == b) ? (1 << 16) : 0);
+            Local c;
+            c.key = (rank << 24) | (cidx[a] * (nvp + 1) + cidx[b]);
             c.child = ch;
             if (S.lean[ch]) {
-              // product-form sources depend on the leaf kernel only: all of them, for every parent level, go into
-              // gather group 0, launched once right after the leaves (throughput-bound), which leaves the
-              // per-level gathers on the latency-bound chain with the few stored complements of big children
-              c.level = 0;
               c.loc = Fc + coff[b];
               c.loc2 = Fc + coff[a];
             } else {
               c.loc = (Fc + coff[b]) + (Fc + coff[a]) * Nc;
               c.loc2 = -1;
             }
-            cs.push_back(c);
+            loc.push_back(c);
           }
       }
-    }
-    std::stable_sort(cs.begin(), cs.end(), [](const Contribution& x, const Contribution& y) {
-      if (x.level != y.level) return x.level < y.level;
-      return x.dst < y.dst;
-    });
-    S.gt_lvl_ptr.assign(S.n_levels + 1, 0);
-    S.gs_child.resize(cs.size());
-    S.gs_loc.resize(cs.size());
-    S.gs_loc2.resize(cs.size());
-    for (size_t i = 0; i < cs.size(); ++i) {
-      if (i == 0 || cs[i].dst != cs[i - 1].dst || cs[i].level != cs[i - 1].level) {
-        S.gt_dst.push_back(cs[i].dst);
-        S.gt_ld.push_back(cs[i].ld);
-        S.gt_dims.push_back(cs[i].dims);
-        S.gt_front.push_back(cs[i].front);
-        S.gt_ptr.push_back((int64_t)i);
-        S.gt_lvl_ptr[cs[i].level + 1]++;
+      for (int k = 0; k < nvp; ++k) pvar_idx[S.fvars[S.fvar_ptr[p] + k]] = -1;
+      if (loc.empty()) continue;
+      // stable counting sort by key (3 ranks x (nvp + 1)^2 blocks)
+      const int nblk = (nvp + 1) * (nvp + 1);
+      bucket.assign((size_t)3 * nblk + 1, 0);
+      auto slot = [&](int key) { return (key >> 24) * nblk + (key & 0xFFFFFF); };
+      for (const Local& c : loc) bucket[slot(c.key) + 1]++;
+      for (size_t k = 1; k < bucket.size(); ++k) bucket[k] += bucket[k - 1];
+      loc_sorted.resize(loc.size());
+      for (const Local& c : loc) loc_sorted[bucket[slot(c.key)]++] = c;
+      for (size_t i = 0; i < loc_sorted.size(); ++i) {
+        const Local& c = loc_sorted[i];
+        const int rank = c.key >> 24, blk = c.key & 0xFFFFFF, pa = blk / (nvp + 1), pb = blk % (nvp + 1);
+        LevelOut& L = lout[lv[rank]];
+        if (i == 0 || loc_sorted[i - 1].key != c.key) {
+          L.dst.push_back(S.off[p] + poffv[pb] + (int64_t)poffv[pa] * S.N[p]);
+          L.ld.push_back(S.N[p]);
+          L.dims.push_back(pdim[pb] | (pdim[pa] << 8) | ((pa == pb) ? (1 << 16) : 0));
+          L.front.push_back(p);
+          L.ptr.push_back((int64_t)L.src.size());
+        }
+        L.src.push_back({c.child, c.loc, c.loc2});
       }
-      S.gs_child[i] = cs[i].child;
-      S.gs_loc[i] = cs[i].loc;
-      S.gs_loc2[i] = cs[i].loc2;
     }
-    S.gt_ptr.push_back((int64_t)cs.size());
+    clk.mark("  gather: contributions");
+    S.gt_lvl_ptr.assign(S.n_levels + 1, 0);
+    size_t n_src = 0;
+    for (const LevelOut& L : lout) n_src += L.src.size();
+    S.gs_child.resize(n_src);
+    S.gs_loc.resize(n_src);
+    S.gs_loc2.resize(n_src);
+    {
+      size_t base = 0;
+      for (int l = 0; l < S.n_levels; ++l) {
+        LevelOut& L = lout[l];
+        for (size_t t = 0; t < L.dst.size(); ++t) {
+          S.gt_dst.push_back(L.dst[t]);
+          S.gt_ld.push_back(L.ld[t]);
+          S.gt_dims.push_back(L.dims[t]);
+          S.gt_front.push_back(L.front[t]);
+          S.gt_ptr.push_back((int64_t)(base + L.ptr[t]));
+        }
+        S.gt_lvl_ptr[l + 1] = (int)L.dst.size();
+        for (size_t i = 0; i < L.src.size(); ++i) {
+          S.gs_child[base + i] = L.src[i].child;
+          S.gs_loc[base + i] = L.src[i].loc;
+          S.gs_loc2[base + i] = L.src[i].loc2;
+        }
+        base += L.src.size();
+        L = LevelOut();
+      }
+    }
+    S.gt_ptr.push_back((int64_t)n_src);
     for (int l = 0; l < S.n_levels; ++l) S.gt_lvl_ptr[l + 1] += S.gt_lvl_ptr[l];
+    clk.mark("  gather: tasks");
     // Segments: a task's source list is cut into chunks of at most kGatherChunk sources, one wave each.
     // Single-segment tasks add straight into the destination; multi-segment tasks write partial sums
     // to scratch slots which a second pass adds in slot order (fixed order => deterministic).
@@ -766,6 +840,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     }
     (void)ntasks;
   }
+  clk.mark("gather plan + stats");
   return GSX_OK;
 }
 
