@@ -136,14 +136,25 @@ def front_split(be, arrays, small_max_n=140, leaf_max_f=16, tile=32, leaf_max_pa
 def pmc_traffic(kernel, workload):
     """HBM bytes per launch (FETCH_SIZE + WRITE_SIZE) of `kernel` from the committed rocprofv3 --pmc passes of this
     same command (hardware counters cannot be read from inside the process; tools_pmc.sh + tools/pmc_summary.py made
-    the file).  The newest round's file that knows the kernel is used; None when no committed pass covers it."""
+    the file).  The newest round's file is used, and only while the sources it was captured from (`csrc_sha1`) are the
+    sources of this tree: a stale file gives traffic = null, not an old number."""
     import glob
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from pmc_summary import csrc_digest
+        now = csrc_digest(ROOT)
+    except Exception:   # noqa: BLE001
+        now = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_pmc_traffic.json")), reverse=True):
         try:
-            k = json.load(open(path))["kernels"][kernel.split("(")[0]]
-            return k["fetch_bytes"] + k["write_bytes"], os.path.relpath(path, ROOT)
+            doc = json.load(open(path))
+            k = doc["kernels"][kernel.split("(")[0]]
         except (OSError, KeyError, ValueError):
             continue
+        rel = os.path.relpath(path, ROOT)
+        if now is None or doc.get("csrc_sha1") != now:
+            return None, rel + " (stale: captured from other kernel sources)"
+        return k["fetch_bytes"] + k["write_bytes"], rel
     return None, None
 
 
@@ -207,12 +218,14 @@ def main():
     arrays, default_order = make_problem(args.workload, seed=42 if sharded else D.replica_seed(42))
     be = _lib.product_backend(arrays, device=device)
     exchange = {"calls": 0, "doubles": 0, "seconds": 0.0}
+    exchange_path = None
     if sharded:
         if args.shard_share > 1:
             inner = lambda ptr, count: None
             shard_rank, shard_world = 0, args.shard_share
         else:
-            inner = D.torch_allreduce(dist, torch.device("cuda", device))
+            # (a known-answer run of the in-place RCCL path first; all ranks fall back to a bounce buffer together if it fails)
+            inner, exchange_path = D.checked_allreduce(dist, torch.device("cuda", device))
             shard_rank, shard_world = rank, world
 
         def allreduce(ptr, count):
@@ -360,7 +373,7 @@ def main():
     }
     if sharded:
         info, owner, _ = be.shard_info()
-        out["shard"] = dict(info, trial_vs_single_gpu_max_rel_diff=shard_check[0] if shard_check else None,
+        out["shard"] = dict(info, exchange_path=exchange_path, trial_vs_single_gpu_max_rel_diff=shard_check[0] if shard_check else None,
                             single_gpu_ms_per_step=shard_check[1] if shard_check else None, exchange_calls_per_step=exchange_timed["calls"] / args.steps,
                             exchange_mb_per_step=8e-6 * exchange_timed["doubles"] / args.steps,
                             exchange_ms_per_step=1e3 * exchange_timed["seconds"] / args.steps,

@@ -54,10 +54,11 @@ class _DeviceDoubles:
         self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
 
 
-def torch_allreduce(dist, device, group=None):
+def torch_allreduce(dist, device, group=None, bounce=False):
     """allreduce(ptr, count) for ProductBackend.set_shard on top of torch.distributed.  backend "nccl": RCCL sums the
     library's own buffer in place (over xGMI between the GPUs of a node); backend "gloo" (rehearsals with several ranks
-    on one GPU, where RCCL refuses duplicate devices): staged through host memory."""
+    on one GPU, where RCCL refuses duplicate devices): staged through host memory.  bounce=True sums a torch-allocated
+    copy instead of the library's buffer (the fallback checked_allreduce takes when the in-place path misbehaves)."""
     import torch
     staged = dist.get_backend(group) != "nccl"
 
@@ -67,7 +68,37 @@ def torch_allreduce(dist, device, group=None):
             h = t.cpu()
             dist.all_reduce(h, group=group)
             t.copy_(h)
+        elif bounce:
+            b = t.clone()
+            dist.all_reduce(b, group=group)
+            t.copy_(b)
         else:
             dist.all_reduce(t, group=group)
         torch.cuda.synchronize(device)
     return allreduce
+
+
+def checked_allreduce(dist, device, group=None):
+    """torch_allreduce, after a known-answer run of the in-place path on every rank (a buffer of rank + 1 must come back
+    as world (world + 1) / 2 everywhere).  The in-place RCCL path aliases memory that torch did not allocate; if any rank
+    sees a wrong sum or an exception there, ALL ranks switch to the bounce-buffer variant together (the verdict itself
+    travels through an ordinary tensor).  Returns (allreduce, "in_place" | "bounce" | "staged")."""
+    import torch
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if dist.get_backend(group) != "nccl":
+        return torch_allreduce(dist, device, group), "staged"
+    ok = 1
+    try:
+        probe = torch.full((1024,), float(rank + 1), dtype=torch.float64, device=device)
+        torch.cuda.synchronize(device)
+        torch_allreduce(dist, device, group)(probe.data_ptr(), probe.numel())
+        if not bool(torch.all(probe == world * (world + 1) / 2).item()):
+            ok = 0
+    except Exception:   # noqa: BLE001 — any failure here means "do not trust the in-place path"
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) == 1:
+        return torch_allreduce(dist, device, group), "in_place"
+    return torch_allreduce(dist, device, group, bounce=True), "bounce"

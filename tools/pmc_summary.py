@@ -17,6 +17,19 @@ import subprocess
 import sys
 
 
+def csrc_digest(root="."):
+    """sha1 over the device + host sources of libgsx: bench.py reports `traffic` only while it matches the tree it runs from."""
+    import hashlib
+    import os
+    h = hashlib.sha1()
+    d = os.path.join(root, "gtsam_petercdev_amd", "csrc")
+    for n in sorted(os.listdir(d)):
+        if n.endswith((".hip", ".cpp", ".h")):
+            h.update(n.encode())
+            h.update(open(os.path.join(d, n), "rb").read())
+    return h.hexdigest()
+
+
 def kernel_name(full):
     """'void gsx::(anonymous namespace)::big_diag_kernel<12, 7>(gsx::BigDesc const*, ...)' -> 'big_diag_kernel'"""
     n = full.replace("(anonymous namespace)::", "")
@@ -44,7 +57,7 @@ def main():
     except OSError:
         sha = ""
     res = {"unit": "bytes per launch (average over the run; template instances of a kernel pooled)",
-           "fetch_calibration": "raw (8 B/lane accesses: uncalibrated)", "code": sha, "kernels": {}}
+           "fetch_calibration": "raw (8 B/lane accesses: uncalibrated)", "code": sha, "csrc_sha1": csrc_digest(), "kernels": {}}
     for k in sorted(set(f) | set(w)):
         fl, fv = f.get(k, [0, 0.0])
         wl, wv = w.get(k, [0, 0.0])
