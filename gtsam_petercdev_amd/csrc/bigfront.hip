@@ -304,7 +304,9 @@ __global__ void __launch_bounds__(NW * 64) big_diag_kernel(const BigDesc* descs,
   BST_ADD(8)
   if (tid == 0) {
     int bad = sfail;
-    if (c0 + fw == F) {  // conditioning test on the last two pivots (cholesky.cpp:145-158)
+    // conditioning test on the last two pivots (cholesky.cpp:145-158): here only for the dense entry (one clique, parent ==
+    // kStandaloneFront); the fronts of a tree are tested per reference clique by cond_check_kernel
+    if (d.parent == kStandaloneFront && c0 + fw == F) {
       int e1, e2;
       (void)frexp(ldiag[fw - 1], &e1);
       if (F >= 2) {

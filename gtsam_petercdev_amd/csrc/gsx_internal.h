@@ -81,6 +81,10 @@ struct Symbolic {
   std::vector<int> gm_task, gm_slot, gm_nslots;   // multi-segment task -> first slot, number of slots
   std::vector<int> gm_lvl_ptr;                    // level -> multi-task range
   int g_max_slots = 0;                            // scratch slots needed (x 128 doubles), reused per level
+  // choleskyPartial's conditioning test per REFERENCE clique: arena offsets of the last / second-to-last (-1: single pivot)
+  // diagonal entries of L, and the front that holds them (only the fronts this rank factors)
+  std::vector<int64_t> cond_last, cond_prev;
+  std::vector<int> cond_front;
   // for partial re-elimination (gsx_relinearize_partial): variable -> factors CSR, gather task -> destination front
   std::vector<int> vf_ptr, vf;
   std::vector<int> gt_front;

@@ -97,8 +97,12 @@ enum { SC_LAMBDA = 0, SC_ERR = 1, SC_LIN0 = 2, SC_LIND = 3, SC_TRIAL_ERR = 4, SC
 
 struct BigDesc {   // one big front of a level
   i64 off, xoff;             // arena offsets of the n x n front and of its n x F L-panel area
-  int N, F, front, parent;   // parent front id (-1 root)
+  int N, F, front, parent;   // parent front id (-1 root; kStandaloneFront: the dense entry, not a front of a tree)
 };
+constexpr int kStandaloneFront = -3;
+// choleskyPartial's conditioning test per reference clique, after the factorization (kernels.hip)
+void launch_cond_check(int n, const i64* last, const i64* prev, const int* front, const double* arena, DevStatus* status,
+                       hipStream_t st);
 // a big front owns n x n doubles followed by its n x F L panel (rows below each diagonal tile)
 __host__ __device__ inline i64 big_panel_offset(int n) { return ((i64)n * n + 1) & ~(i64)1; }
 

@@ -1432,7 +1432,7 @@ __device__ unsigned long long g_stamp[8];
 #define STAMP_ADD(slot)
 #endif
 template <int PB>
-__device__ inline int lds_partial_cholesky_t(double* L, int n, int F) {
+__device__ inline int lds_partial_cholesky_t(double* L, int n, int F, bool gap_test) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
   int fail = 0;
@@ -1519,7 +1519,9 @@ __device__ inline int lds_partial_cholesky_t(double* L, int n, int F) {
     __syncthreads();
     STAMP_ADD(1)
   }
-  // conditioning test on the last two pivots — cholesky.cpp:145-158
+  // conditioning test on the last two pivots — cholesky.cpp:145-158 (the fronts of a tree are tested per REFERENCE
+  // clique by cond_check_kernel instead: a relaxed front holds several)
+  if (!gap_test) return fail;
   if (F >= 2) {
     int e2, e1;
     (void)frexp(L[(F - 2) + (F - 2) * n], &e2);
@@ -1556,7 +1558,7 @@ __device__ __forceinline__ double tile_readlane(double v, int src_lane) {  // sr
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
   return __hiloint2double(hi, lo);
 }
-__device__ inline int lds_partial_cholesky_mfma(double* Lm, int n, int F) {
+__device__ inline int lds_partial_cholesky_mfma(double* Lm, int n, int F, bool gap_test) {
   __shared__ double Eb[16 * 17];  // (L_pp^-1)[i][c] of the current panel at i * 17 + c
   __shared__ int failed;
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -1656,7 +1658,9 @@ __device__ inline int lds_partial_cholesky_mfma(double* Lm, int n, int F) {
     __syncthreads();
   }
   int fail = failed;
-  // conditioning test on the last two pivots — cholesky.cpp:145-158
+  // conditioning test on the last two pivots — cholesky.cpp:145-158 (the fronts of a tree are tested per REFERENCE
+  // clique by cond_check_kernel instead: a relaxed front holds several)
+  if (!gap_test) return fail;
   if (F >= 2) {
     int e2, e1;
     (void)frexp(Lm[(F - 2) + (F - 2) * n], &e2);
@@ -1671,11 +1675,11 @@ __device__ inline int lds_partial_cholesky_mfma(double* Lm, int n, int F) {
 }
 // panel width by frontal size: narrow panels keep the per-pivot register work small for the many cliques
 // with a handful of frontal scalars, wide panels halve the number of trailing sweeps of the larger ones
-__device__ inline int lds_partial_cholesky(double* L, int n, int F) {
+__device__ inline int lds_partial_cholesky(double* L, int n, int F, bool gap_test) {
 #ifdef GSX_OLD_LDS_CHOLESKY
-  return (F <= 24) ? lds_partial_cholesky_t<8>(L, n, F) : lds_partial_cholesky_t<16>(L, n, F);
+  return (F <= 24) ? lds_partial_cholesky_t<8>(L, n, F, gap_test) : lds_partial_cholesky_t<16>(L, n, F, gap_test);
 #else
-  return lds_partial_cholesky_mfma(L, n, F);
+  return lds_partial_cholesky_mfma(L, n, F, gap_test);
 #endif
 }
 
@@ -1829,7 +1833,7 @@ __global__ void __launch_bounds__(512) front_small_kernel(DevProblem P, DevSymbo
     __syncthreads();
   }
   FS_ADD(2)
-  const int fail = lds_partial_cholesky(L, n, F);
+  const int fail = lds_partial_cholesky(L, n, F, false);
   FS_ADD(3)
   if (fail && tid == 0) report_failure(status, f);
   // L panel
@@ -1939,16 +1943,7 @@ __global__ void front_leaf_kernel(DevProblem P, DevSymbolic S, const LeafRec* re
     }
     __syncthreads();
   }
-  if (F >= 2) {  // conditioning test on the last two pivots — cholesky.cpp:145-158
-    int e2, e1;
-    (void)frexp(Pn[(F - 2) + (F - 2) * n], &e2);
-    (void)frexp(Pn[(F - 1) + (F - 1) * n], &e1);
-    if (!(e2 - e1 < 12)) fail = 1;
-  } else {
-    int e1;
-    (void)frexp(Pn[0], &e1);
-    if (!(e1 > -12)) fail = 1;
-  }
+  // (choleskyPartial's conditioning test runs per reference clique after the factorization: cond_check_kernel)
   if (fail && tid == 0) report_failure(status, f);
   double* A = arena + rec.off;
   for (int c = wave; c < F; c += nw)
@@ -1987,6 +1982,30 @@ __global__ void front_leaf_kernel(DevProblem P, DevSymbolic S, const LeafRec* re
       }
     }
   }
+}
+
+// choleskyPartial's conditioning test (gtsam/base/cholesky.cpp:145-158) for every clique of the REFERENCE tree: a thread
+// per clique reads the last two diagonal entries of L of its frontal block wherever the (possibly relaxed) front that
+// holds them stored it.  Exponent gap >= 12 between them, or an exponent <= -12 of a lone pivot, is the reference's
+// "underconstrained" verdict; a failure is reported against the front, like a non-positive pivot.
+__global__ void __launch_bounds__(256) cond_check_kernel(int n, const i64* last, const i64* prev, const int* front,
+                                                         const double* arena, DevStatus* status) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  int e1, e2;
+  (void)frexp(arena[last[k]], &e1);
+  bool bad;
+  if (prev[k] >= 0) {
+    (void)frexp(arena[prev[k]], &e2);
+    bad = !(e2 - e1 < 12);
+  } else {
+    bad = !(e1 > -12);
+  }
+  if (bad) report_failure(status, front[k]);
+}
+void launch_cond_check(int n, const i64* last, const i64* prev, const int* front, const double* arena, DevStatus* status,
+                       hipStream_t st) {
+  if (n > 0) cond_check_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, last, prev, front, arena, status);
 }
 
 void launch_front_leaf(const DevProblem& P, const DevSymbolic& S, const LeafRec* recs, int count, int max_panel, int threads,
@@ -2428,7 +2447,7 @@ __global__ void dense_small_kernel(double* a, int n, int nf, DevStatus* status) 
   extern __shared__ double L[];
   for (int e = threadIdx.x; e < n * n; e += blockDim.x) L[e] = a[e];
   __syncthreads();
-  const int fail = lds_partial_cholesky(L, n, nf);
+  const int fail = lds_partial_cholesky(L, n, nf, true);   // the dense entry: one clique, tested here
   if (fail && threadIdx.x == 0) report_failure(status, 0);
   for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
     const int r = e % n, c = e / n;
@@ -2463,7 +2482,7 @@ void launch_dense_partial(double* a, int n, int nf, DevStatus* status, hipStream
   hipMemcpyAsync(work, a, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, st);
   double* const user = a;
   a = work;
-  BigDesc h{0, xoff, n, nf, 0, -1};
+  BigDesc h{0, xoff, n, nf, 0, kStandaloneFront};
   BigDesc* d = nullptr;
   hipMalloc(&d, sizeof(BigDesc));
   hipMemcpyAsync(d, &h, sizeof(BigDesc), hipMemcpyHostToDevice, st);

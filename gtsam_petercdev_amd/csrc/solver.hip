@@ -115,6 +115,8 @@ struct gsx_context {
   DevBuf<VarRec> d_var_recs;
   DevBuf<ChildRec> d_child_recs;
   DevBuf<FrontRec> d_front_recs;
+  DevBuf<i64> d_cond_last, d_cond_prev;   // conditioning test per reference clique (Symbolic::cond_*)
+  DevBuf<int> d_cond_front;
   DevBuf<VarRec> d_fvar_recs;
   DevBuf<LeafRec> d_leaf_recs;   // leaf-kernel cliques of level 0, in schedule order
   int leaf_base = 0;             // schedule position of d_leaf_recs[0]
@@ -447,6 +449,9 @@ gsx_status upload_symbolic(gsx_context* c) {
     HIPCHK(c, c->d_var_recs.upload(vrec, st));
     HIPCHK(c, c->d_child_recs.upload(crec, st));
     HIPCHK(c, c->d_front_recs.upload(frec, st));
+    HIPCHK(c, c->d_cond_last.upload(std::vector<i64>(S.cond_last.begin(), S.cond_last.end()), st));
+    HIPCHK(c, c->d_cond_prev.upload(std::vector<i64>(S.cond_prev.begin(), S.cond_prev.end()), st));
+    HIPCHK(c, c->d_cond_front.upload(S.cond_front, st));
     HIPCHK(c, c->d_fvar_recs.upload(fvrec, st));
     HIPCHK(c, hipStreamSynchronize(st));
   }
@@ -919,6 +924,9 @@ void dev_factorize(gsx_context* c, double lambda) {
       if (c->profiling > 0) timer_end(c, PH_FACTOR_BIG);
     }
   }
+  // choleskyPartial's conditioning test, per clique of the reference tree (cholesky.cpp:145-158)
+  launch_cond_check((int)S.cond_last.size(), c->d_cond_last.p, c->d_cond_prev.p, c->d_cond_front.p, c->d_arena.p,
+                    c->d_status.p, c->stream);
   timer_end(c, PH_FACTORIZE);
 }
 
@@ -1977,6 +1985,9 @@ gsx_status partial_factor(gsx_handle h, std::vector<int>& dfr) {
         dev_big_factor(h, ps.big.p + L.big_begin, L.big_count, L.big_plan, sm, false);
       }
     }
+    // (all cliques: the clean ones' pivots are resident and unchanged, the test is two loads a clique)
+    launch_cond_check((int)S.cond_last.size(), h->d_cond_last.p, h->d_cond_prev.p, h->d_cond_front.p, h->d_arena.p,
+                      h->d_status.p, sm);
     timer_end(h, PH_FACTORIZE);
   }
   h->solved = false;

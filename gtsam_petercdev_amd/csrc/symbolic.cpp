@@ -137,6 +137,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
   // ---- supernodes: the reference's merge rule ------------------------------------------------------
   // merged[j] = true when node j was merged into its etree parent's cluster.
   std::vector<char> merged(n, 0);
+  std::vector<char> ref_merged(n, 0);  // ... by the reference's rule alone (the reference's cliques inside a relaxed one)
   std::vector<int> nfront_of(n, 1);  // frontal variable count of the cluster topped by node j
   // relaxed amalgamation (relax > 0; off = the reference's Bayes tree exactly): a child cluster is also merged
   // when the explicit zeros this adds to its columns are at most relax x its own L panel and the merged
@@ -158,6 +159,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
       for (int c = ech_ptr[j]; c < ech_ptr[j + 1]; ++c) {
         const int ch = ech[c];
         bool take = myNrParents + refNrFrontals == st[ch].size();
+        ref_merged[ch] = take;
         if (take) refNrFrontals += ref_nfront_of[ch];
         if (!take && rx > 0) {
           const int64_t fc = fdim_of[ch], sc = sdim_of[ch];
@@ -632,6 +634,33 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
         S.cmap[cm++] = S.N[f] - 1;
       }
       for (int k = S.fvar_ptr[f]; k < S.fvar_ptr[f + 1]; ++k) loc[S.fvars[k]] = -1;
+    }
+  }
+  // ---- choleskyPartial's conditioning test, clique by clique of the REFERENCE tree (cholesky.cpp:145-158: exponent gap
+  //      < 12 between the last two pivots of a clique's frontal block; > -12 for a single pivot).  A relaxed front holds
+  //      several reference cliques; the pivots are the same numbers wherever a clique is eliminated, so the test is a
+  //      list of (second-to-last, last) diagonal entries of L per reference clique, read after the factorization.
+  {
+    std::vector<int> rtop(n), prev_in_clique(n, -1);
+    for (int j = n - 1; j >= 0; --j) rtop[j] = ref_merged[j] ? rtop[eparent[j]] : j;
+    for (int j = 0; j < n; ++j)  // ascending position: the last write is the largest position below the top
+      if (rtop[j] != j) prev_in_clique[rtop[j]] = j;
+    for (int t = 0; t < n; ++t) {
+      if (rtop[t] != t) continue;
+      const int v = order[t], f = S.front_of_var[v];
+      if (!S.scheduled.empty() && !S.scheduled[f]) continue;
+      const int d = P.dims[v];
+      const int64_t ld = S.N[f];
+      const int c1 = S.h_loc[v] + d - 1;
+      int c2 = -1;
+      if (d >= 2) c2 = c1 - 1;
+      else if (prev_in_clique[t] >= 0) {
+        const int u = order[prev_in_clique[t]];
+        c2 = S.h_loc[u] + P.dims[u] - 1;
+      }
+      S.cond_last.push_back(S.off[f] + c1 + c1 * ld);
+      S.cond_prev.push_back(c2 >= 0 ? S.off[f] + c2 + c2 * ld : -1);
+      S.cond_front.push_back(f);
     }
   }
   clk.mark("row maps");

@@ -375,6 +375,54 @@ def test_indeterminate_system(gpu):
     assert res["n_solve_failures"] >= 0 and np.isfinite(res["final_error"])
 
 
+def test_underconstrained_clique_inside_a_relaxed_front(gpu, oracle):
+    """choleskyPartial's conditioning test (cholesky.cpp:145-158) belongs to every clique of the REFERENCE tree.  Variable
+    p is a clique of its own there (separator {q}); its two pivots are 16 binary orders apart — the reference throws.  With
+    relaxed amalgamation p's clique is folded into q's front, where its pivots are no longer "the last two": the verdict
+    must not change (it is taken per reference clique after the factorization, not per front inside the kernels)."""
+    iso = noiseModel.Isotropic.Sigma(2, 1.0)
+    fg, v = NonlinearFactorGraph(), Values()
+    fg.add(PriorFactor(0, Point2(0, 0), noiseModel.Diagonal.Sigmas([1e-5, 1.0])))     # p: L_00 ~ 1e5, L_11 ~ 1
+    fg.add(BetweenFactor(0, 1, Point2(1, 0), iso))                                    # p - q
+    fg.add(BetweenFactor(1, 2, Point2(1, 0), iso))                                    # q - r
+    fg.add(BetweenFactor(1, 3, Point2(0, 1), iso))                                    # q - s
+    fg.add(BetweenFactor(2, 3, Point2(-1, 1), iso))                                   # r - s
+    fg.add(PriorFactor(2, Point2(2, 0), iso))
+    for k, xy in enumerate([(0, 0), (1, 0), (2, 0), (1, 1)]):
+        v.insert(k, Point2(*xy))
+    arr = fg.to_arrays(v)
+    ob = oracle.oracle_backend(arr)
+    ob.set_ordering([0, 1, 2, 3])
+    ob.linearize()
+    with pytest.raises(gt.IndeterminantLinearSystemException):
+        ob.solve(0.0)
+    for relax in (0.0, 50.0, A.AMALGAMATION_AUTO):
+        be = gpu.product_backend(arr)
+        be.set_amalgamation(relax, 128)
+        be.set_ordering([0, 1, 2, 3])
+        if relax == 0.0:
+            assert be.stats()["n_fronts"] >= 2       # p's clique is separate in the reference tree ...
+        if relax == 50.0:
+            assert be.stats()["n_fronts"] == 1       # ... and swallowed here
+        be.linearize()
+        with pytest.raises(gt.IndeterminantLinearSystemException):
+            be.solve(0.0)
+        be.close()
+    # the same graph with a sane prior on p solves in every mode, identically
+    fg.factors[0] = PriorFactor(0, Point2(0, 0), iso)
+    arr = fg.to_arrays(v)
+    ob = oracle.oracle_backend(arr)
+    ob.set_ordering([0, 1, 2, 3])
+    ob.linearize()
+    want = ob.solve(0.0)
+    for relax in (0.0, 50.0):
+        be = gpu.product_backend(arr)
+        be.set_amalgamation(relax, 128)
+        be.set_ordering([0, 1, 2, 3])
+        be.linearize()
+        assert relerr(be.solve(0.0), want) < 1e-9
+
+
 def test_cheirality_zeroes_factor(gpu, oracle):
     g, v = NonlinearFactorGraph(), Values()
     g.add(GeneralSFMFactor(Point2(3., 0.), noiseModel.Unit.Create(2), X(1), L(1)))
