@@ -365,7 +365,10 @@ gsx_status upload_problem(gsx_context* c) {
 }
 
 int small_threads_for(int n) {
-  static const int shift = std::getenv("GSX_SMALL_THREADS_SHIFT") ? std::atoi(std::getenv("GSX_SMALL_THREADS_SHIFT")) : 0;
+  // (twice the threads the row-per-thread panel needed: the assembly and the stores of a front are a handful of memory
+  //  round trips that more lanes shorten, and the tile phases of the factorization split over the waves; measured -2 %
+  //  on the 100 000-pose graphs, nothing beyond 2x; GSX_SMALL_THREADS_SHIFT overrides for experiments)
+  static const int shift = std::getenv("GSX_SMALL_THREADS_SHIFT") ? std::atoi(std::getenv("GSX_SMALL_THREADS_SHIFT")) : 1;
   int t = 512;
   if (n <= 48) t = 64;
   else if (n <= 72) t = 128;
