@@ -815,13 +815,109 @@ __global__ void __launch_bounds__(256) backsolve_small_kernel(DevSymbolic S, con
     if (!isfinite(yr)) atomicAdd(&status->n_nonfinite, 1);
   }
 }
+// The same for 32 < F <= 64 (the unamalgamated nested-dissection leaves of a pose graph run to ~60 frontal scalars): two
+// column blocks.  L21 is read in two passes of 32 columns, the chain solves block 1, takes its part out of block 0's
+// right-hand side through the 32 x 32 off-diagonal tile, and solves block 0.
+__global__ void __launch_bounds__(256) backsolve_small2_kernel(DevSymbolic S, const int* ids, const double* arena,
+                                                               double* delta, DevStatus* status) {
+  constexpr int B = kBsSmallF;
+  __shared__ double xs[kBsSmallSep];
+  __shared__ double t00[B][B + 1], t11[B][B + 1], t10[B][B + 1];   // t10[r][c] = L[32 + r][c]
+  __shared__ double part[2][2 * B];
+  const int f = ids[blockIdx.x];
+  const int n = S.fr_N[f], F = S.fr_F[f], nS = n - 1 - F;
+  const double* A = arena + S.fr_off[f];
+  const int* gi = S.gidx + S.gidx_ptr[f];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = tid < nS ? gi[F + tid] : -1;
+  const int gf = tid < F ? gi[tid] : -1;
+  double v00[4], v11[4], v10[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = tid + 256 * q, r = e & 31, c = e >> 5;
+    v00[q] = (r < F && c <= r) ? A[r + (i64)c * n] : (r == c ? 1.0 : 0.0);
+    v11[q] = (B + r < F && c <= r) ? A[(B + r) + (i64)(B + c) * n] : (r == c ? 1.0 : 0.0);
+    v10[q] = (B + r < F) ? A[(B + r) + (i64)c * n] : 0.0;
+  }
+  constexpr int kSteps = kBsSmallSep / 8;
+  const int cl = 16 * (wave & 1) + (lane & 15), h = wave >> 1, rq = lane >> 4;
+  double lv[2][kSteps];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int cg = B * p + cl;
+    const double* col = A + (i64)cg * n + F + rq;
+#pragma unroll
+    for (int k = 0; k < kSteps; ++k) {
+      const int r0 = 4 * (h + 2 * k);
+      lv[p][k] = (cg < F && r0 + rq < nS) ? col[r0] : 0.0;
+    }
+  }
+  const double dv = tid < F ? A[(n - 1) + (i64)tid * n] : 0.0;   // (F <= 64: wave 0, lane = column)
+  if (tid < kBsSmallSep) xs[tid] = g >= 0 ? delta[g] : 0.0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = tid + 256 * q;
+    t00[e & 31][e >> 5] = v00[q];
+    t11[e & 31][e >> 5] = v11[q];
+    t10[e & 31][e >> 5] = v10[q];
+  }
+  lds_bar();
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < kSteps; ++k) acc = fma(lv[p][k], xs[4 * (h + 2 * k) + rq], acc);
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
+    if (rq == 0) part[h][B * p + cl] = acc;
+  }
+  lds_bar();
+  if (wave != 0) return;
+  // lane c (< 64) holds the right-hand side of column c; the two 32-pivot chains run on the lanes of their block
+  const int l = lane & 31;
+  double y = lane < F ? dv - part[0][lane] - part[1][lane] : 0.0;
+  double lc[B];
+  {  // block 1: lanes 32..63
+#pragma unroll
+    for (int c = 0; c < B; ++c) lc[c] = t11[c][l];
+    const double dinv = 1.0 / t11[l][l];
+#pragma unroll
+    for (int c = B - 1; c >= 0; --c) {
+      const double xc = readlane_f64(y, B + c) * readlane_f64(dinv, c);
+      y = lane == B + c ? xc : ((lane >= B && lane < B + c) ? fma(-lc[c], xc, y) : y);
+    }
+  }
+  // y_0 -= L10' x_1: lane c < 32 sums over the 32 rows of the off-diagonal tile
+  {
+    double acc = 0.0;
+#pragma unroll
+    for (int r = 0; r < B; ++r) acc = fma(t10[r][l], readlane_f64(y, B + r), acc);
+    if (lane < B) y -= acc;
+  }
+  {  // block 0: lanes 0..31
+#pragma unroll
+    for (int c = 0; c < B; ++c) lc[c] = t00[c][l];
+    const double dinv = 1.0 / t00[l][l];
+#pragma unroll
+    for (int c = B - 1; c >= 0; --c) {
+      const double xc = readlane_f64(y, c) * readlane_f64(dinv, c);
+      y = lane == c ? xc : (lane < c ? fma(-lc[c], xc, y) : y);
+    }
+  }
+  if (lane < F) {
+    delta[gf] = y;
+    if (!isfinite(y)) atomicAdd(&status->n_nonfinite, 1);
+  }
+}
 }  // namespace
 
-bool backsolve_small_fits(int max_n, int max_F) { return max_F <= kBsSmallF && max_n <= kSmallMaxN && max_n - 2 <= kBsSmallSep; }
+bool backsolve_small_fits(int max_n, int max_F) { return max_F <= 2 * kBsSmallF && max_n <= kSmallMaxN && max_n - 2 <= kBsSmallSep; }
 
-void launch_backsolve_small(const DevSymbolic& S, const int* ids, int count, const double* arena, double* delta,
+void launch_backsolve_small(const DevSymbolic& S, const int* ids, int count, int max_F, const double* arena, double* delta,
                             DevStatus* status, hipStream_t st) {
-  if (count) backsolve_small_kernel<<<count, 256, 0, st>>>(S, ids, arena, delta, status);
+  if (!count) return;
+  if (max_F <= kBsSmallF) backsolve_small_kernel<<<count, 256, 0, st>>>(S, ids, arena, delta, status);
+  else backsolve_small2_kernel<<<count, 256, 0, st>>>(S, ids, arena, delta, status);
 }
 
 // LDS the kernel needs for a front with F frontal columns and n rows; 0 when it does not fit (the caller keeps the

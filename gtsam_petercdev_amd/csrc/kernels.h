@@ -177,9 +177,9 @@ void launch_backsolve(const DevSymbolic& S, const int* ids, int count, int threa
 size_t backsolve_big_lds(int max_n, int max_F, int max_sep_rows);
 void launch_backsolve_big(const DevSymbolic& S, const int* ids, int count, int max_n, int max_F, const double* arena,
                           double* delta, DevStatus* status, hipStream_t st);
-// LDS-class fronts with <= 32 frontal columns (bigfront.hip): all loads of a front in flight together
+// LDS-class fronts with <= 64 frontal columns (bigfront.hip): all loads of a front in flight together
 bool backsolve_small_fits(int max_n, int max_F);
-void launch_backsolve_small(const DevSymbolic& S, const int* ids, int count, const double* arena, double* delta,
+void launch_backsolve_small(const DevSymbolic& S, const int* ids, int count, int max_F, const double* arena, double* delta,
                             DevStatus* status, hipStream_t st);
 // leaf cliques of a level, a wave per clique
 void launch_backsolve_leaf(const DevSymbolic& S, const LeafRec* recs, int count, int max_F, const double* arena,

@@ -954,7 +954,7 @@ void dev_backsolve(gsx_context* c) {
                            c->d_status.p, c->stream);
       if (c->profiling > 0) timer_end(c, PH_K_BACKSOLVE);
     }
-    // the LDS-class fronts: their own kernel when every one of them has at most 32 frontal columns
+    // the LDS-class fronts: their own kernels when every one of them has at most 64 frontal columns
     const int n_small = se - le;
     int small_maxn = 0, small_maxF = 0;
     for (int k = le; k < se; ++k) {
@@ -964,7 +964,8 @@ void dev_backsolve(gsx_context* c) {
     const bool small_own = n_small > 0 && backsolve_small_fits(small_maxn, small_maxF);
     if (small_own) {
       if (c->profiling > 0) timer_begin(c, PH_K_BACKSOLVE);
-      launch_backsolve_small(c->DS, c->d_sched.p + le, n_small, c->d_arena.p, c->d_delta.p, c->d_status.p, c->stream);
+      launch_backsolve_small(c->DS, c->d_sched.p + le, n_small, small_maxF, c->d_arena.p, c->d_delta.p, c->d_status.p,
+                             c->stream);
       if (c->profiling > 0) timer_end(c, PH_K_BACKSOLVE);
     }
     const bool big_left = B.count > 0 && !big_own, small_left = n_small > 0 && !small_own;
