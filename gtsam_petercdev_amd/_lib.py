@@ -112,6 +112,17 @@ class ProductBackend(A.Backend):
                                                     sp, C.c_int64(ns), C.byref(st)), "relinearize_partial")
         return {k: getattr(st, k) for k, _ in PartialStats._fields_}
 
+    def backsubstitute_wildfire(self, threshold: float):
+        """gsx_backsubstitute_wildfire (include/gsx.h): ISAM2's partial back-substitution on the resident undamped
+        factorization.  Returns (delta, number of frontal variables back-substituted)."""
+        out = np.zeros(self.tangent_size)
+        cnt = C.c_int64()
+        bad = C.c_uint64()
+        self._check(self._fn("backsubstitute_wildfire")(self._h, C.c_double(threshold),
+                                                        out.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(out.size),
+                                                        C.byref(cnt), C.byref(bad)), "backsubstitute_wildfire")
+        return out, cnt.value
+
     def get_ordering(self) -> np.ndarray:
         """gsx_get_ordering: the keys in the handle's current elimination order."""
         out = np.zeros(self.arrays.n_vars, dtype=np.uint64)

@@ -70,6 +70,8 @@ struct DevSymbolic {
   const ChildRec* child_recs;
   const FrontRec* front_recs;   // per front
   const VarRec* fvar_recs;      // var_recs in the order of fvars (a front's frontal variables are contiguous)
+  // partial ("wildfire") back-substitution: when set, the back-substitution kernels leave front f alone if bs_skip[f]
+  const unsigned char* bs_skip;
 };
 
 // status words written by the factorization / back-substitution kernels
@@ -181,6 +183,22 @@ void launch_backsolve_big(const DevSymbolic& S, const int* ids, int count, int m
 bool backsolve_small_fits(int max_n, int max_F);
 void launch_backsolve_small(const DevSymbolic& S, const int* ids, int count, int max_F, const double* arena, double* delta,
                             DevStatus* status, hipStream_t st);
+// ISAM2's partial ("wildfire") back-substitution (gtsam/nonlinear/ISAM2Clique.cpp:68-90,175-290), level by level from
+// the root: `pre` decides which cliques of the level are dirty (reached through a dirty parent, and re-eliminated or
+// with a separator variable that changed) and tells the back-substitution kernels to skip the others; `post` compares
+// a dirty clique's new frontal solution with the old one — a change of at least `threshold` in the infinity norm (or a
+// re-eliminated clique) marks its frontal variables as changed, a smaller one is undone.
+struct WildfireArgs {
+  const unsigned char* replaced;  // per front: re-eliminated since the last complete back-substitution
+  unsigned char *dirty, *skip;    // per front
+  unsigned char* changed;         // per variable
+  const double* old_delta;        // the solution before the pass
+  unsigned long long* count;      // frontal variables back-substituted (lastBacksubVariableCount)
+  double threshold;
+};
+void launch_wildfire_pre(const DevSymbolic& S, const int* ids, int count, const WildfireArgs& W, hipStream_t st);
+void launch_wildfire_post(const DevSymbolic& S, const int* ids, int count, const WildfireArgs& W, double* delta,
+                          hipStream_t st);
 // leaf cliques of a level, a wave per clique
 void launch_backsolve_leaf(const DevSymbolic& S, const LeafRec* recs, int count, int max_F, const double* arena,
                            double* delta, DevStatus* status, hipStream_t st);

@@ -2246,6 +2246,7 @@ __global__ void backsolve_kernel(DevSymbolic S, const int* ids, const double* ar
   __shared__ double y[TB];
   __shared__ double dv[TB];
   const int f = ids[blockIdx.x];
+  if (S.bs_skip != nullptr && S.bs_skip[f]) return;  // wildfire: a clique no change reaches
   const int n = S.fr_N[f], F = S.fr_F[f];
   const double* A = arena + S.fr_off[f];
   const bool big = (S.fr_lean[f] & 2) != 0;  // blocked layout (n > kSmallMaxN, and every cap front of a sharded problem)
@@ -2355,6 +2356,7 @@ __global__ void __launch_bounds__(256) backsolve_leaf_kernel(DevSymbolic S, cons
   const int k = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
   if (k >= count) return;
   const LeafRec rec = recs[k];
+  if (S.bs_skip != nullptr && S.bs_skip[rec.front]) return;  // wildfire: a clique no change reaches
   const int n = rec.n, F = rec.F;
   const double* A = arena + rec.off;
   const int* gi = S.gidx + rec.gidx_ptr;
@@ -2426,6 +2428,57 @@ void launch_backsolve_leaf(const DevSymbolic& S, const LeafRec* recs, int count,
   if (max_F <= 4) backsolve_leaf_kernel<4><<<grid, 256, 0, st>>>(S, recs, count, arena, delta, status);
   else if (max_F <= 8) backsolve_leaf_kernel<8><<<grid, 256, 0, st>>>(S, recs, count, arena, delta, status);
   else backsolve_leaf_kernel<kLeafMaxF><<<grid, 256, 0, st>>>(S, recs, count, arena, delta, status);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ISAM2's partial ("wildfire") back-substitution, the two bookkeeping passes around a level's kernels
+// (gtsam/nonlinear/ISAM2Clique.cpp: isDirty :68-90, valuesChanged :175-183, optimizeWildfireNode :237-259,
+//  optimizeWildfireNonRecursive :261-287 — children are visited only through a dirty parent).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) wildfire_pre_kernel(DevSymbolic S, const int* ids, int count, WildfireArgs W) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  const int f = ids[k];
+  const int p = S.fr_parent[f];
+  bool dirty = (p < 0) || W.dirty[p];  // reached at all?
+  if (dirty && !W.replaced[f]) {
+    dirty = false;
+    for (int q = S.fr_fvar_ptr[f] + S.fr_nfv[f]; q < S.fr_fvar_ptr[f + 1]; ++q)
+      if (W.changed[S.fvars[q]]) {
+        dirty = true;
+        break;
+      }
+  }
+  W.dirty[f] = dirty ? 1 : 0;
+  W.skip[f] = dirty ? 0 : 1;
+}
+__global__ void __launch_bounds__(256) wildfire_post_kernel(DevSymbolic S, const int* ids, int count, WildfireArgs W,
+                                                            double* delta) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  const int f = ids[k];
+  if (!W.dirty[f]) return;
+  const int F = S.fr_F[f], nfv = S.fr_nfv[f];
+  const int* gi = S.gidx + S.gidx_ptr[f];
+  atomicAdd(W.count, (unsigned long long)nfv);
+  bool keep = W.replaced[f] != 0;
+  if (!keep) {
+    double m = 0.0;
+    for (int r = 0; r < F; ++r) m = fmax(m, fabs(W.old_delta[gi[r]] - delta[gi[r]]));
+    keep = m >= W.threshold;
+  }
+  if (keep) {
+    for (int q = 0; q < nfv; ++q) W.changed[S.fvars[S.fr_fvar_ptr[f] + q]] = 1;
+  } else {
+    for (int r = 0; r < F; ++r) delta[gi[r]] = W.old_delta[gi[r]];
+  }
+}
+void launch_wildfire_pre(const DevSymbolic& S, const int* ids, int count, const WildfireArgs& W, hipStream_t st) {
+  if (count > 0) wildfire_pre_kernel<<<(count + 255) / 256, 256, 0, st>>>(S, ids, count, W);
+}
+void launch_wildfire_post(const DevSymbolic& S, const int* ids, int count, const WildfireArgs& W, double* delta,
+                          hipStream_t st) {
+  if (count > 0) wildfire_post_kernel<<<(count + 255) / 256, 256, 0, st>>>(S, ids, count, W, delta);
 }
 
 void launch_backsolve(const DevSymbolic& S, const int* ids, int count, int threads, int max_n, const double* arena,

@@ -198,6 +198,12 @@ struct gsx_context {
   DevBuf<double> d_xscal;
   std::vector<double> jac_stage;   // host staging of gsx_set_block_jacobians
   bool sharded() const { return shard_world > 1; }
+  // partial ("wildfire") back-substitution (gsx_backsubstitute_wildfire)
+  std::vector<unsigned char> wf_replaced;   // per front: re-eliminated since the last complete back-substitution
+  bool wf_delta_valid = false;              // d_delta holds a complete undamped solution on the current tree
+  DevBuf<unsigned char> d_wf_replaced, d_wf_dirty, d_wf_skip, d_wf_changed;
+  DevBuf<double> d_wf_old;
+  DevBuf<unsigned long long> d_wf_count;
 };
 
 namespace {
@@ -750,6 +756,8 @@ gsx_status upload_symbolic(gsx_context* c) {
   c->h_ready = false;
   c->solved = false;
   c->fact_valid = c->fact_pending = false;
+  c->wf_replaced.assign(S.n_fronts, 1);
+  c->wf_delta_valid = false;
   c->damp_ready = c->hdiag_ready = false;   // (sharded: the damping weights carry the ownership mask)
   if (c->sharded()) c->linearized = false;  // the owned factor set changed with the partition
   return GSX_OK;
@@ -867,6 +875,7 @@ void dev_factorize(gsx_context* c, double lambda) {
   c->fact_valid = false;   // becomes true when the read-back shows no failed front (readback)
   c->fact_pending = true;
   c->fact_lambda = lambda;
+  std::fill(c->wf_replaced.begin(), c->wf_replaced.end(), (unsigned char)1);  // every clique re-eliminated
   c->sc_dirty |= kXFact;
   timer_begin(c, PH_FACTORIZE);
   launch_begin_factorization(c->d_scalars.p, lambda, c->d_status.p, c->stream);
@@ -933,10 +942,13 @@ void dev_factorize(gsx_context* c, double lambda) {
   timer_end(c, PH_FACTORIZE);
 }
 
-void dev_backsolve(gsx_context* c) {
+// wf: the two bookkeeping passes of ISAM2's partial back-substitution around every level (nullptr: all cliques)
+void dev_backsolve(gsx_context* c, const WildfireArgs* wf = nullptr) {
   const Symbolic& S = c->S;
   timer_begin(c, PH_BACKSOLVE);
+  c->wf_delta_valid = false;  // (set again by the callers that leave a complete undamped solution behind)
   for (int l = S.n_levels - 1; l >= 0; --l) {
+    if (wf) launch_wildfire_pre(c->DS, c->d_sched.p + S.lvl_ptr[l], S.lvl_ptr[l + 1] - S.lvl_ptr[l], *wf, c->stream);
     const BigLevel& B = c->big_level[l];
     const int se = S.lvl_small_end[l];
     const int le = S.lvl_leaf_end[l], n_rest = S.lvl_ptr[l + 1] - le;
@@ -998,6 +1010,9 @@ void dev_backsolve(gsx_context* c) {
     if (S.lvl_leaf_end[l] > S.lvl_ptr[l])
       launch_backsolve_leaf(c->DS, c->d_leaf_recs.p + (S.lvl_ptr[l] - c->leaf_base), S.lvl_leaf_end[l] - S.lvl_ptr[l],
                             c->leaf_max_F[l], c->d_arena.p, c->d_delta.p, c->d_status.p, c->stream);
+    if (wf)
+      launch_wildfire_post(c->DS, c->d_sched.p + S.lvl_ptr[l], S.lvl_ptr[l + 1] - S.lvl_ptr[l], *wf, c->d_delta.p,
+                           c->stream);
   }
   timer_end(c, PH_BACKSOLVE);
 }
@@ -1460,6 +1475,10 @@ gsx_status gsx_solve(gsx_handle h, double lambda, int32_t diagonal_damping, doub
     return GSX_E_INDETERMINATE;
   }
   h->solved = true;
+  if (lambda == 0.0 && !h->sharded()) {  // a complete undamped solution: what a later wildfire pass starts from
+    h->wf_delta_valid = true;
+    std::fill(h->wf_replaced.begin(), h->wf_replaced.end(), (unsigned char)0);
+  }
   if (delta_out && n > 0) {
     const double* src = h->d_delta.p;
     if (h->sharded()) {
@@ -1468,6 +1487,71 @@ gsx_status gsx_solve(gsx_handle h, double lambda, int32_t diagonal_damping, doub
       src = h->d_udelta.p;
     }
     HIPCHK(h, hipMemcpyAsync(delta_out, src, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  return GSX_OK;
+}
+
+// ISAM2's partial ("wildfire") back-substitution (include/gsx.h; gtsam/nonlinear/ISAM2-impl.cpp:48-77,
+// ISAM2Clique.cpp:203-287) on the resident undamped factorization.
+gsx_status gsx_backsubstitute_wildfire(gsx_handle h, double threshold, double* delta_out, int64_t n,
+                                       int64_t* n_vars_solved, uint64_t* bad_key) {
+  if (!h || (delta_out && n != h->P.tan_size)) return GSX_E_INVALID;
+  gsx_status st = ensure_ready(h, true, true);
+  if (st != GSX_OK) return st;
+  if (h->sharded()) {
+    h->err = "the partial back-substitution is not available on a sharded handle";
+    return GSX_E_STATE;
+  }
+  if (!h->linearized || !h->fact_valid || h->fact_lambda != 0.0) {
+    h->err = "gsx_backsubstitute_wildfire needs the resident undamped factorization of the current linearization "
+             "(gsx_solve with lambda = 0, or gsx_relinearize_partial after one, first)";
+    return GSX_E_STATE;
+  }
+  hipSetDevice(h->device);
+  const Symbolic& S = h->S;
+  launch_begin_factorization(h->d_scalars.p, 0.0, h->d_status.p, h->stream);  // status reset for the substitution
+  h->sc_dirty |= kXFact;
+  const bool full = !(threshold > 0.0) || !h->wf_delta_valid;  // (DeltaImpl::UpdateGaussNewtonDelta: threshold <= 0 = all)
+  unsigned long long count = (unsigned long long)h->P.n_vars;
+  if (full) {
+    dev_backsolve(h);
+  } else {
+    const size_t nf = (size_t)S.n_fronts, nv = (size_t)h->P.n_vars, nt = (size_t)h->P.tan_size;
+    if (h->d_wf_dirty.n < nf) {
+      HIPCHK(h, h->d_wf_replaced.alloc(nf));
+      HIPCHK(h, h->d_wf_dirty.alloc(nf));
+      HIPCHK(h, h->d_wf_skip.alloc(nf));
+    }
+    if (h->d_wf_changed.n < nv) HIPCHK(h, h->d_wf_changed.alloc(nv));
+    if (h->d_wf_old.n < nt) HIPCHK(h, h->d_wf_old.alloc(nt));
+    if (!h->d_wf_count.p) HIPCHK(h, h->d_wf_count.alloc(1));
+    HIPCHK(h, hipMemcpyAsync(h->d_wf_replaced.p, h->wf_replaced.data(), nf, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_wf_changed.p, 0, nv, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_wf_count.p, 0, sizeof(unsigned long long), h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_wf_old.p, h->d_delta.p, nt * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    const WildfireArgs W{h->d_wf_replaced.p, h->d_wf_dirty.p, h->d_wf_skip.p, h->d_wf_changed.p,
+                         h->d_wf_old.p, h->d_wf_count.p, threshold};
+    h->DS.bs_skip = h->d_wf_skip.p;
+    dev_backsolve(h, &W);
+    h->DS.bs_skip = nullptr;
+    HIPCHK(h, hipMemcpyAsync(&count, h->d_wf_count.p, sizeof(count), hipMemcpyDeviceToHost, h->stream));
+  }
+  st = readback(h);
+  if (st != GSX_OK) return st;
+  if (h->h_status->n_fail > 0 || h->h_status->n_nonfinite > 0) {
+    if (bad_key) *bad_key = failing_key(h);
+    h->solved = false;
+    h->fact_valid = false;
+    h->err = "indeterminate linear system";
+    return GSX_E_INDETERMINATE;
+  }
+  h->solved = true;
+  h->wf_delta_valid = true;
+  std::fill(h->wf_replaced.begin(), h->wf_replaced.end(), (unsigned char)0);
+  if (n_vars_solved) *n_vars_solved = (int64_t)count;
+  if (delta_out && n > 0) {
+    HIPCHK(h, hipMemcpyAsync(delta_out, h->d_delta.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
   }
   return GSX_OK;
@@ -1886,6 +1970,7 @@ gsx_status partial_assemble(gsx_handle h, std::vector<int>& dvar) {
 // 3. the listed cliques, level by level, in the order and with the launch shapes of the full schedule (a re-done clique is
 //    re-assembled from H and from ALL its children, whose Schur complements / L panels are resident in the arena)
 gsx_status partial_factor(gsx_handle h, std::vector<int>& dfr) {
+  for (int f : dfr) h->wf_replaced[f] = 1;
   const Symbolic& S = h->S;
   hipStream_t sm = h->stream;
   gsx_context::PartialScratch& ps = h->ps;

@@ -437,12 +437,31 @@ gsx_status gsx_joint_marginal_covariance(gsx_handle h, const uint64_t* keys, int
  * factorization at the same values.  Needs the resident undamped factorization of the current linearization
  * (GSX_E_STATE otherwise); follow with gsx_solve(h, 0, ...) — which then only back-substitutes — or the marginal queries.
  * When most of the tree is dirty anyway the call takes the full path (same bits; the stats then report everything).
- * Adding / removing factors and variables: gsx_update below.  Not here yet: the partial ("wildfire") back-substitution. */
+ * Adding / removing factors and variables: gsx_update below; the partial ("wildfire") back-substitution:
+ * gsx_backsubstitute_wildfire. */
 typedef struct gsx_partial_stats {
   int32_t n_factors_relinearized, n_panels_reassembled, n_fronts_reeliminated, n_fronts;
 } gsx_partial_stats;
 gsx_status gsx_relinearize_partial(gsx_handle h, const uint64_t* keys, int32_t n_keys, const double* states,
                                    int64_t n_states, gsx_partial_stats* out);
+/* ---- ISAM2's partial ("wildfire") back-substitution --------------------------------------------------------------------
+ * DeltaImpl::UpdateGaussNewtonDelta (gtsam/nonlinear/ISAM2-impl.cpp:48-77) -> optimizeWildfireNonRecursive
+ * (gtsam/nonlinear/ISAM2Clique.cpp:261-287) on the resident undamped factorization: starting at the roots, a clique is
+ * back-substituted when it was re-eliminated since the handle's last complete solution ("replaced": the cliques redone
+ * by gsx_relinearize_partial, or all of them after a full factorization) or when one of its separator variables changed
+ * (ISAM2Clique::isDirty, :68-90); its new frontal solution is kept — and its frontal variables count as changed — when
+ * the clique was replaced or the solution moved by at least `threshold` in the infinity norm, and is put back to the old
+ * values otherwise (valuesChanged / restoreFromOriginals, :175-201); children are visited only through a dirty parent.
+ * threshold <= 0, or no complete undamped solution resident yet (gsx_solve with lambda = 0 leaves one, and so does
+ * this call): every clique is back-substituted, as the reference does.  delta_out (tangent order of gsx_solve) may be
+ * NULL; n_vars_solved = the reference's lastBacksubVariableCount (frontal variables of the cliques back-substituted).
+ * A front of a relaxed tree (gsx_set_amalgamation) is visited or skipped as a whole, so the reference's clique-by-clique
+ * pattern is reproduced exactly at relax = 0.  Each level costs two small bookkeeping launches around its
+ * back-substitution kernels, whose workgroups return at once for the cliques no change reaches.  Needs the resident
+ * undamped factorization (GSX_E_STATE otherwise); not on a sharded handle. */
+gsx_status gsx_backsubstitute_wildfire(gsx_handle h, double threshold, double* delta_out, int64_t n,
+                                       int64_t* n_vars_solved, uint64_t* bad_key);
+
 /* ---- structural update of a live handle: ISAM2::update(newFactors, newTheta, removeFactorIndices) ------------------------
  * (gtsam/nonlinear/ISAM2.cpp:395-484; the reference then detaches the affected part of the Bayes tree, re-orders it with
  * constrained COLAMD and re-eliminates it, ISAM2.cpp:117-362.)
