@@ -112,14 +112,15 @@ class ProductBackend(A.Backend):
                                                     sp, C.c_int64(ns), C.byref(st)), "relinearize_partial")
         return {k: getattr(st, k) for k, _ in PartialStats._fields_}
 
-    def backsubstitute_wildfire(self, threshold: float):
+    def backsubstitute_wildfire(self, threshold: float, want_delta: bool = True):
         """gsx_backsubstitute_wildfire (include/gsx.h): ISAM2's partial back-substitution on the resident undamped
-        factorization.  Returns (delta, number of frontal variables back-substituted)."""
-        out = np.zeros(self.tangent_size)
+        factorization.  Returns (delta or None, number of frontal variables back-substituted)."""
+        out = np.zeros(self.tangent_size) if want_delta else None
         cnt = C.c_int64()
         bad = C.c_uint64()
-        self._check(self._fn("backsubstitute_wildfire")(self._h, C.c_double(threshold),
-                                                        out.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(out.size),
+        ptr = out.ctypes.data_as(C.POINTER(C.c_double)) if want_delta else None
+        self._check(self._fn("backsubstitute_wildfire")(self._h, C.c_double(threshold), ptr,
+                                                        C.c_int64(self.tangent_size if want_delta else 0),
                                                         C.byref(cnt), C.byref(bad)), "backsubstitute_wildfire")
         return out, cnt.value
 

@@ -618,7 +618,7 @@ __global__ void __launch_bounds__(kBsThreads) backsolve_big_kernel(DevSymbolic S
                                                                    double* delta, DevStatus* status) {
   extern __shared__ double sm[];
   const int f = ids[blockIdx.x];
-  if (S.bs_skip != nullptr && S.bs_skip[f]) return;  // wildfire: a clique no change reaches
+  if (wildfire_skip(S, f, threadIdx.x == 0)) return;  // a clique no change reaches
   const int n = S.fr_N[f], F = S.fr_F[f];
   const double* A = arena + S.fr_off[f];
   const double* X = A + big_panel_offset(n);
@@ -761,7 +761,7 @@ __global__ void __launch_bounds__(256) backsolve_small_kernel(DevSymbolic S, con
   __shared__ double tile[kBsSmallF][kBsSmallF + 1];
   __shared__ double part[2][kBsSmallF];
   const int f = ids[blockIdx.x];
-  if (S.bs_skip != nullptr && S.bs_skip[f]) return;  // wildfire: a clique no change reaches
+  if (wildfire_skip(S, f, threadIdx.x == 0)) return;  // a clique no change reaches
   const int n = S.fr_N[f], F = S.fr_F[f], nS = n - 1 - F;
   const double* A = arena + S.fr_off[f];
   const int* gi = S.gidx + S.gidx_ptr[f];
@@ -827,7 +827,7 @@ __global__ void __launch_bounds__(256) backsolve_small2_kernel(DevSymbolic S, co
   __shared__ double t00[B][B + 1], t11[B][B + 1], t10[B][B + 1];   // t10[r][c] = L[32 + r][c]
   __shared__ double part[2][2 * B];
   const int f = ids[blockIdx.x];
-  if (S.bs_skip != nullptr && S.bs_skip[f]) return;  // wildfire: a clique no change reaches
+  if (wildfire_skip(S, f, threadIdx.x == 0)) return;  // a clique no change reaches
   const int n = S.fr_N[f], F = S.fr_F[f], nS = n - 1 - F;
   const double* A = arena + S.fr_off[f];
   const int* gi = S.gidx + S.gidx_ptr[f];

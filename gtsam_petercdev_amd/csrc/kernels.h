@@ -70,9 +70,32 @@ struct DevSymbolic {
   const ChildRec* child_recs;
   const FrontRec* front_recs;   // per front
   const VarRec* fvar_recs;      // var_recs in the order of fvars (a front's frontal variables are contiguous)
-  // partial ("wildfire") back-substitution: when set, the back-substitution kernels leave front f alone if bs_skip[f]
-  const unsigned char* bs_skip;
+  // partial ("wildfire") back-substitution (gsx_backsubstitute_wildfire): when wf_dirty is set, a back-substitution
+  // kernel first decides whether its clique is dirty — reached through a dirty parent, and re-eliminated (wf_replaced,
+  // per front) or with a separator variable that changed (wf_changed, per variable) — records that in wf_dirty and
+  // leaves a clean clique alone (ISAM2Clique::isDirty, gtsam/nonlinear/ISAM2Clique.cpp:68-90; children are visited only
+  // through a dirty parent, :261-287)
+  unsigned char* wf_dirty;
+  const unsigned char *wf_replaced, *wf_changed;
 };
+#ifdef __HIPCC__
+// every thread of the clique's workgroup (or wave: `writer` = its first lane) evaluates the same rule on the same bytes
+__device__ __forceinline__ bool wildfire_skip(const DevSymbolic& S, int f, bool writer) {
+  if (S.wf_dirty == nullptr) return false;
+  const int p = S.fr_parent[f];
+  bool dirty = (p < 0) || S.wf_dirty[p];
+  if (dirty && !S.wf_replaced[f]) {
+    dirty = false;
+    for (int q = S.fr_fvar_ptr[f] + S.fr_nfv[f]; q < S.fr_fvar_ptr[f + 1]; ++q)
+      if (S.wf_changed[S.fvars[q]]) {
+        dirty = true;
+        break;
+      }
+  }
+  if (writer) S.wf_dirty[f] = dirty ? 1 : 0;
+  return !dirty;
+}
+#endif
 
 // status words written by the factorization / back-substitution kernels
 struct DevStatus {
@@ -80,6 +103,7 @@ struct DevStatus {
   int first_front;   // smallest failing front id (INT_MAX when none)
   int n_nonfinite;   // non-finite entries met in back-substitution
   int n_cheirality;  // SFM factors zeroed in the last linearize
+  int n_backsub;     // frontal variables back-substituted by the last wildfire pass (lastBacksubVariableCount)
 };
 
 // scalar slots in the device scalar buffer
@@ -183,22 +207,21 @@ void launch_backsolve_big(const DevSymbolic& S, const int* ids, int count, int m
 bool backsolve_small_fits(int max_n, int max_F);
 void launch_backsolve_small(const DevSymbolic& S, const int* ids, int count, int max_F, const double* arena, double* delta,
                             DevStatus* status, hipStream_t st);
-// ISAM2's partial ("wildfire") back-substitution (gtsam/nonlinear/ISAM2Clique.cpp:68-90,175-290), level by level from
-// the root: `pre` decides which cliques of the level are dirty (reached through a dirty parent, and re-eliminated or
-// with a separator variable that changed) and tells the back-substitution kernels to skip the others; `post` compares
-// a dirty clique's new frontal solution with the old one — a change of at least `threshold` in the infinity norm (or a
-// re-eliminated clique) marks its frontal variables as changed, a smaller one is undone.
+// ISAM2's partial ("wildfire") back-substitution, the pass after a level's kernels: a dirty clique's new frontal solution
+// is compared with the old one — a change of at least `threshold` in the infinity norm (or a re-eliminated clique) marks
+// its frontal variables as changed, a smaller one is undone (valuesChanged / restoreFromOriginals,
+// gtsam/nonlinear/ISAM2Clique.cpp:175-201).
 struct WildfireArgs {
-  const unsigned char* replaced;  // per front: re-eliminated since the last complete back-substitution
-  unsigned char *dirty, *skip;    // per front
-  unsigned char* changed;         // per variable
-  const double* old_delta;        // the solution before the pass
-  unsigned long long* count;      // frontal variables back-substituted (lastBacksubVariableCount)
+  const unsigned char *replaced, *dirty;  // per front
+  unsigned char* changed;                 // per variable
+  const double* old_delta;                // the solution before the pass
+  DevStatus* status;                      // n_backsub += frontal variables back-substituted
   double threshold;
 };
-void launch_wildfire_pre(const DevSymbolic& S, const int* ids, int count, const WildfireArgs& W, hipStream_t st);
-void launch_wildfire_post(const DevSymbolic& S, const int* ids, int count, const WildfireArgs& W, double* delta,
-                          hipStream_t st);
+// flags[ids[k]] = 1 (the cliques a partial re-elimination has just redone)
+void launch_mark_fronts(const int* ids, int count, unsigned char* flags, hipStream_t st);
+void launch_wildfire_post(const DevSymbolic& S, const int* ids, int count, bool wave_per_clique, const WildfireArgs& W,
+                          double* delta, hipStream_t st);
 // leaf cliques of a level, a wave per clique
 void launch_backsolve_leaf(const DevSymbolic& S, const LeafRec* recs, int count, int max_F, const double* arena,
                            double* delta, DevStatus* status, hipStream_t st);

@@ -1408,6 +1408,7 @@ __global__ void begin_factorization_kernel(double* scalars, double lambda, DevSt
   status->n_fail = 0;
   status->first_front = 0x7fffffff;
   status->n_nonfinite = 0;
+  status->n_backsub = 0;
 }
 void launch_begin_factorization(double* scalars, double lambda, DevStatus* status, hipStream_t st) {
   begin_factorization_kernel<<<1, 1, 0, st>>>(scalars, lambda, status);
@@ -2246,7 +2247,7 @@ __global__ void backsolve_kernel(DevSymbolic S, const int* ids, const double* ar
   __shared__ double y[TB];
   __shared__ double dv[TB];
   const int f = ids[blockIdx.x];
-  if (S.bs_skip != nullptr && S.bs_skip[f]) return;  // wildfire: a clique no change reaches
+  if (wildfire_skip(S, f, threadIdx.x == 0)) return;  // a clique no change reaches
   const int n = S.fr_N[f], F = S.fr_F[f];
   const double* A = arena + S.fr_off[f];
   const bool big = (S.fr_lean[f] & 2) != 0;  // blocked layout (n > kSmallMaxN, and every cap front of a sharded problem)
@@ -2356,7 +2357,7 @@ __global__ void __launch_bounds__(256) backsolve_leaf_kernel(DevSymbolic S, cons
   const int k = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
   if (k >= count) return;
   const LeafRec rec = recs[k];
-  if (S.bs_skip != nullptr && S.bs_skip[rec.front]) return;  // wildfire: a clique no change reaches
+  if (wildfire_skip(S, rec.front, lane == 0)) return;  // a clique no change reaches
   const int n = rec.n, F = rec.F;
   const double* A = arena + rec.off;
   const int* gi = S.gidx + rec.gidx_ptr;
@@ -2431,54 +2432,59 @@ void launch_backsolve_leaf(const DevSymbolic& S, const LeafRec* recs, int count,
 }
 
 // ---------------------------------------------------------------------------------------------
-// ISAM2's partial ("wildfire") back-substitution, the two bookkeeping passes around a level's kernels
-// (gtsam/nonlinear/ISAM2Clique.cpp: isDirty :68-90, valuesChanged :175-183, optimizeWildfireNode :237-259,
-//  optimizeWildfireNonRecursive :261-287 — children are visited only through a dirty parent).
+// ISAM2's partial ("wildfire") back-substitution: the pass after a level's kernels (kernels.h: WildfireArgs;
+// gtsam/nonlinear/ISAM2Clique.cpp valuesChanged :175-183, restoreFromOriginals :193-201, optimizeWildfireNode :237-259).
+// The dirty rule itself sits at the top of the back-substitution kernels (wildfire_skip).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) wildfire_pre_kernel(DevSymbolic S, const int* ids, int count, WildfireArgs W) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= count) return;
-  const int f = ids[k];
-  const int p = S.fr_parent[f];
-  bool dirty = (p < 0) || W.dirty[p];  // reached at all?
-  if (dirty && !W.replaced[f]) {
-    dirty = false;
-    for (int q = S.fr_fvar_ptr[f] + S.fr_nfv[f]; q < S.fr_fvar_ptr[f + 1]; ++q)
-      if (W.changed[S.fvars[q]]) {
-        dirty = true;
-        break;
-      }
-  }
-  W.dirty[f] = dirty ? 1 : 0;
-  W.skip[f] = dirty ? 0 : 1;
-}
+// WAVE: a wave per clique (a thread walking hundreds of frontal scalars behind dependent loads takes as long as the
+// level's back-substitution); !WAVE: a thread per clique, for the leaf cliques (F <= 16, up to 10^5 a level).  The count
+// goes through LDS: one global atomic a workgroup.
+template <bool WAVE>
 __global__ void __launch_bounds__(256) wildfire_post_kernel(DevSymbolic S, const int* ids, int count, WildfireArgs W,
                                                             double* delta) {
+  __shared__ int solved;
+  if (threadIdx.x == 0) solved = 0;
+  __syncthreads();
+  const int lane = WAVE ? (threadIdx.x & 63) : 0, step = WAVE ? 64 : 1;
+  const int k = WAVE ? blockIdx.x * 4 + (threadIdx.x >> 6) : blockIdx.x * 256 + threadIdx.x;
+  if (k < count && W.dirty[ids[k]]) {
+    const int f = ids[k];
+    const int F = S.fr_F[f], nfv = S.fr_nfv[f];
+    const int* gi = S.gidx + S.gidx_ptr[f];
+    if (lane == 0) atomicAdd(&solved, nfv);
+    bool keep = W.replaced[f] != 0;
+    if (!keep) {
+      double m = 0.0;
+      for (int r = lane; r < F; r += step) {
+        const int g = gi[r];
+        m = fmax(m, fabs(W.old_delta[g] - delta[g]));
+      }
+      keep = WAVE ? (bool)__any(m >= W.threshold) : (m >= W.threshold);
+    }
+    if (keep) {
+      for (int q = lane; q < nfv; q += step) W.changed[S.fvars[S.fr_fvar_ptr[f] + q]] = 1;
+    } else {
+      for (int r = lane; r < F; r += step) {
+        const int g = gi[r];
+        delta[g] = W.old_delta[g];
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && solved) atomicAdd(&W.status->n_backsub, solved);
+}
+void launch_wildfire_post(const DevSymbolic& S, const int* ids, int count, bool wave_per_clique, const WildfireArgs& W,
+                          double* delta, hipStream_t st) {
+  if (count <= 0) return;
+  if (wave_per_clique) wildfire_post_kernel<true><<<(count + 3) / 4, 256, 0, st>>>(S, ids, count, W, delta);
+  else wildfire_post_kernel<false><<<(count + 255) / 256, 256, 0, st>>>(S, ids, count, W, delta);
+}
+__global__ void __launch_bounds__(256) mark_fronts_kernel(const int* ids, int count, unsigned char* flags) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= count) return;
-  const int f = ids[k];
-  if (!W.dirty[f]) return;
-  const int F = S.fr_F[f], nfv = S.fr_nfv[f];
-  const int* gi = S.gidx + S.gidx_ptr[f];
-  atomicAdd(W.count, (unsigned long long)nfv);
-  bool keep = W.replaced[f] != 0;
-  if (!keep) {
-    double m = 0.0;
-    for (int r = 0; r < F; ++r) m = fmax(m, fabs(W.old_delta[gi[r]] - delta[gi[r]]));
-    keep = m >= W.threshold;
-  }
-  if (keep) {
-    for (int q = 0; q < nfv; ++q) W.changed[S.fvars[S.fr_fvar_ptr[f] + q]] = 1;
-  } else {
-    for (int r = 0; r < F; ++r) delta[gi[r]] = W.old_delta[gi[r]];
-  }
+  if (k < count) flags[ids[k]] = 1;
 }
-void launch_wildfire_pre(const DevSymbolic& S, const int* ids, int count, const WildfireArgs& W, hipStream_t st) {
-  if (count > 0) wildfire_pre_kernel<<<(count + 255) / 256, 256, 0, st>>>(S, ids, count, W);
-}
-void launch_wildfire_post(const DevSymbolic& S, const int* ids, int count, const WildfireArgs& W, double* delta,
-                          hipStream_t st) {
-  if (count > 0) wildfire_post_kernel<<<(count + 255) / 256, 256, 0, st>>>(S, ids, count, W, delta);
+void launch_mark_fronts(const int* ids, int count, unsigned char* flags, hipStream_t st) {
+  if (count > 0) mark_fronts_kernel<<<(count + 255) / 256, 256, 0, st>>>(ids, count, flags);
 }
 
 void launch_backsolve(const DevSymbolic& S, const int* ids, int count, int threads, int max_n, const double* arena,

@@ -199,11 +199,28 @@ struct gsx_context {
   std::vector<double> jac_stage;   // host staging of gsx_set_block_jacobians
   bool sharded() const { return shard_world > 1; }
   // partial ("wildfire") back-substitution (gsx_backsubstitute_wildfire)
-  std::vector<unsigned char> wf_replaced;   // per front: re-eliminated since the last complete back-substitution
+  // "replaced" = re-eliminated since the last complete undamped solution: all cliques (host flag: a full factorization
+  // costs nothing here), or the ones gsx_relinearize_partial marked in the device flags; the flags are cleared lazily
+  bool wf_all_replaced = true, wf_clear_pending = true;
   bool wf_delta_valid = false;              // d_delta holds a complete undamped solution on the current tree
-  DevBuf<unsigned char> d_wf_replaced, d_wf_dirty, d_wf_skip, d_wf_changed;
+  DevBuf<unsigned char> d_wf_replaced, d_wf_dirty, d_wf_changed;
   DevBuf<double> d_wf_old;
-  DevBuf<unsigned long long> d_wf_count;
+  DevBuf<int> d_wf_ids;
+  // (device flags per front, allocated on first use for the current tree, zeroed when a clear is pending)
+  hipError_t wf_flags_ready(hipStream_t st) {
+    const size_t nf = (size_t)std::max(S.n_fronts, 1);
+    if (d_wf_replaced.n != nf) {
+      hipError_t e = d_wf_replaced.alloc(nf);
+      if (e != hipSuccess) return e;
+      wf_clear_pending = true;
+    }
+    if (wf_clear_pending) {
+      hipError_t e = hipMemsetAsync(d_wf_replaced.p, 0, nf, st);
+      if (e != hipSuccess) return e;
+      wf_clear_pending = false;
+    }
+    return hipSuccess;
+  }
 };
 
 namespace {
@@ -756,7 +773,7 @@ gsx_status upload_symbolic(gsx_context* c) {
   c->h_ready = false;
   c->solved = false;
   c->fact_valid = c->fact_pending = false;
-  c->wf_replaced.assign(S.n_fronts, 1);
+  c->wf_all_replaced = true;
   c->wf_delta_valid = false;
   c->damp_ready = c->hdiag_ready = false;   // (sharded: the damping weights carry the ownership mask)
   if (c->sharded()) c->linearized = false;  // the owned factor set changed with the partition
@@ -875,7 +892,7 @@ void dev_factorize(gsx_context* c, double lambda) {
   c->fact_valid = false;   // becomes true when the read-back shows no failed front (readback)
   c->fact_pending = true;
   c->fact_lambda = lambda;
-  std::fill(c->wf_replaced.begin(), c->wf_replaced.end(), (unsigned char)1);  // every clique re-eliminated
+  c->wf_all_replaced = true;  // every clique re-eliminated
   c->sc_dirty |= kXFact;
   timer_begin(c, PH_FACTORIZE);
   launch_begin_factorization(c->d_scalars.p, lambda, c->d_status.p, c->stream);
@@ -942,13 +959,13 @@ void dev_factorize(gsx_context* c, double lambda) {
   timer_end(c, PH_FACTORIZE);
 }
 
-// wf: the two bookkeeping passes of ISAM2's partial back-substitution around every level (nullptr: all cliques)
+// wf: ISAM2's partial back-substitution — the kernels skip the cliques no change reaches (DS.wf_*), and a bookkeeping pass
+// follows every level (nullptr: all cliques)
 void dev_backsolve(gsx_context* c, const WildfireArgs* wf = nullptr) {
   const Symbolic& S = c->S;
   timer_begin(c, PH_BACKSOLVE);
   c->wf_delta_valid = false;  // (set again by the callers that leave a complete undamped solution behind)
   for (int l = S.n_levels - 1; l >= 0; --l) {
-    if (wf) launch_wildfire_pre(c->DS, c->d_sched.p + S.lvl_ptr[l], S.lvl_ptr[l + 1] - S.lvl_ptr[l], *wf, c->stream);
     const BigLevel& B = c->big_level[l];
     const int se = S.lvl_small_end[l];
     const int le = S.lvl_leaf_end[l], n_rest = S.lvl_ptr[l + 1] - le;
@@ -1010,9 +1027,10 @@ void dev_backsolve(gsx_context* c, const WildfireArgs* wf = nullptr) {
     if (S.lvl_leaf_end[l] > S.lvl_ptr[l])
       launch_backsolve_leaf(c->DS, c->d_leaf_recs.p + (S.lvl_ptr[l] - c->leaf_base), S.lvl_leaf_end[l] - S.lvl_ptr[l],
                             c->leaf_max_F[l], c->d_arena.p, c->d_delta.p, c->d_status.p, c->stream);
-    if (wf)
-      launch_wildfire_post(c->DS, c->d_sched.p + S.lvl_ptr[l], S.lvl_ptr[l + 1] - S.lvl_ptr[l], *wf, c->d_delta.p,
-                           c->stream);
+    if (wf) {  // the leaf cliques (F <= 16) a thread each, the others a wave each
+      launch_wildfire_post(c->DS, c->d_sched.p + S.lvl_ptr[l], le - S.lvl_ptr[l], false, *wf, c->d_delta.p, c->stream);
+      launch_wildfire_post(c->DS, c->d_sched.p + le, n_rest, true, *wf, c->d_delta.p, c->stream);
+    }
   }
   timer_end(c, PH_BACKSOLVE);
 }
@@ -1477,7 +1495,8 @@ gsx_status gsx_solve(gsx_handle h, double lambda, int32_t diagonal_damping, doub
   h->solved = true;
   if (lambda == 0.0 && !h->sharded()) {  // a complete undamped solution: what a later wildfire pass starts from
     h->wf_delta_valid = true;
-    std::fill(h->wf_replaced.begin(), h->wf_replaced.end(), (unsigned char)0);
+    h->wf_all_replaced = false;
+    h->wf_clear_pending = true;
   }
   if (delta_out && n > 0) {
     const double* src = h->d_delta.p;
@@ -1512,30 +1531,24 @@ gsx_status gsx_backsubstitute_wildfire(gsx_handle h, double threshold, double* d
   const Symbolic& S = h->S;
   launch_begin_factorization(h->d_scalars.p, 0.0, h->d_status.p, h->stream);  // status reset for the substitution
   h->sc_dirty |= kXFact;
-  const bool full = !(threshold > 0.0) || !h->wf_delta_valid;  // (DeltaImpl::UpdateGaussNewtonDelta: threshold <= 0 = all)
-  unsigned long long count = (unsigned long long)h->P.n_vars;
+  // (DeltaImpl::UpdateGaussNewtonDelta: threshold <= 0 = all cliques; so is a pass with every clique replaced)
+  const bool full = !(threshold > 0.0) || !h->wf_delta_valid || h->wf_all_replaced;
   if (full) {
     dev_backsolve(h);
   } else {
-    const size_t nf = (size_t)S.n_fronts, nv = (size_t)h->P.n_vars, nt = (size_t)h->P.tan_size;
-    if (h->d_wf_dirty.n < nf) {
-      HIPCHK(h, h->d_wf_replaced.alloc(nf));
-      HIPCHK(h, h->d_wf_dirty.alloc(nf));
-      HIPCHK(h, h->d_wf_skip.alloc(nf));
-    }
+    const size_t nf = (size_t)std::max(S.n_fronts, 1), nv = (size_t)std::max(h->P.n_vars, 1), nt = (size_t)h->P.tan_size;
+    HIPCHK(h, h->wf_flags_ready(h->stream));
+    if (h->d_wf_dirty.n < nf) HIPCHK(h, h->d_wf_dirty.alloc(nf));
     if (h->d_wf_changed.n < nv) HIPCHK(h, h->d_wf_changed.alloc(nv));
-    if (h->d_wf_old.n < nt) HIPCHK(h, h->d_wf_old.alloc(nt));
-    if (!h->d_wf_count.p) HIPCHK(h, h->d_wf_count.alloc(1));
-    HIPCHK(h, hipMemcpyAsync(h->d_wf_replaced.p, h->wf_replaced.data(), nf, hipMemcpyHostToDevice, h->stream));
+    if (h->d_wf_old.n < nt) HIPCHK(h, h->d_wf_old.alloc(std::max<size_t>(nt, 1)));
     HIPCHK(h, hipMemsetAsync(h->d_wf_changed.p, 0, nv, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->d_wf_count.p, 0, sizeof(unsigned long long), h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_wf_old.p, h->d_delta.p, nt * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    const WildfireArgs W{h->d_wf_replaced.p, h->d_wf_dirty.p, h->d_wf_skip.p, h->d_wf_changed.p,
-                         h->d_wf_old.p, h->d_wf_count.p, threshold};
-    h->DS.bs_skip = h->d_wf_skip.p;
+    const WildfireArgs W{h->d_wf_replaced.p, h->d_wf_dirty.p, h->d_wf_changed.p, h->d_wf_old.p, h->d_status.p, threshold};
+    h->DS.wf_dirty = h->d_wf_dirty.p;
+    h->DS.wf_replaced = h->d_wf_replaced.p;
+    h->DS.wf_changed = h->d_wf_changed.p;
     dev_backsolve(h, &W);
-    h->DS.bs_skip = nullptr;
-    HIPCHK(h, hipMemcpyAsync(&count, h->d_wf_count.p, sizeof(count), hipMemcpyDeviceToHost, h->stream));
+    h->DS.wf_dirty = nullptr;
   }
   st = readback(h);
   if (st != GSX_OK) return st;
@@ -1548,8 +1561,9 @@ gsx_status gsx_backsubstitute_wildfire(gsx_handle h, double threshold, double* d
   }
   h->solved = true;
   h->wf_delta_valid = true;
-  std::fill(h->wf_replaced.begin(), h->wf_replaced.end(), (unsigned char)0);
-  if (n_vars_solved) *n_vars_solved = (int64_t)count;
+  h->wf_all_replaced = false;
+  h->wf_clear_pending = true;
+  if (n_vars_solved) *n_vars_solved = full ? (int64_t)h->P.n_vars : (int64_t)h->h_status->n_backsub;
   if (delta_out && n > 0) {
     HIPCHK(h, hipMemcpyAsync(delta_out, h->d_delta.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1970,7 +1984,11 @@ gsx_status partial_assemble(gsx_handle h, std::vector<int>& dvar) {
 // 3. the listed cliques, level by level, in the order and with the launch shapes of the full schedule (a re-done clique is
 //    re-assembled from H and from ALL its children, whose Schur complements / L panels are resident in the arena)
 gsx_status partial_factor(gsx_handle h, std::vector<int>& dfr) {
-  for (int f : dfr) h->wf_replaced[f] = 1;
+  if (!h->wf_all_replaced) {  // these cliques are "replaced" for the next wildfire pass
+    HIPCHK(h, h->wf_flags_ready(h->stream));
+    HIPCHK(h, h->d_wf_ids.stage(dfr, h->stream));
+    launch_mark_fronts(h->d_wf_ids.p, (int)dfr.size(), h->d_wf_replaced.p, h->stream);
+  }
   const Symbolic& S = h->S;
   hipStream_t sm = h->stream;
   gsx_context::PartialScratch& ps = h->ps;

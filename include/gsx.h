@@ -456,8 +456,8 @@ gsx_status gsx_relinearize_partial(gsx_handle h, const uint64_t* keys, int32_t n
  * this call): every clique is back-substituted, as the reference does.  delta_out (tangent order of gsx_solve) may be
  * NULL; n_vars_solved = the reference's lastBacksubVariableCount (frontal variables of the cliques back-substituted).
  * A front of a relaxed tree (gsx_set_amalgamation) is visited or skipped as a whole, so the reference's clique-by-clique
- * pattern is reproduced exactly at relax = 0.  Each level costs two small bookkeeping launches around its
- * back-substitution kernels, whose workgroups return at once for the cliques no change reaches.  Needs the resident
+ * pattern is reproduced exactly at relax = 0.  The dirty rule is evaluated at the top of the back-substitution kernels
+ * (a clean clique's workgroup returns at once); one small bookkeeping launch follows every level.  Needs the resident
  * undamped factorization (GSX_E_STATE otherwise); not on a sharded handle. */
 gsx_status gsx_backsubstitute_wildfire(gsx_handle h, double threshold, double* delta_out, int64_t n,
                                        int64_t* n_vars_solved, uint64_t* bad_key);

@@ -1,5 +1,6 @@
 """Time gsx_relinearize_partial + back-substitution against a full relinearize + factorize + back-substitution on the bench
-workloads, for a few sizes of the moved set (the most recent poses / a random sample).  python tools/partial_probe.py"""
+workloads, for a few sizes of the moved set (the most recent poses / a random sample), with the full and with ISAM2's
+partial ("wildfire") back-substitution.  python tools/partial_probe.py"""
 import json
 import os
 import sys
@@ -18,8 +19,6 @@ def main():
         arr, order = bench.make_problem(name, 42)
         kind = {"schur_nd": A.ORDER_SCHUR_ND, "nd": A.ORDER_ND}[order]
         be = _lib.ProductBackend(arr, device=0)
-        relax, mf = bench.AMALGAMATION[name]
-        be.set_amalgamation(relax, mf)
         be.set_ordering(be.compute_ordering(kind))
         off = np.concatenate([[0], np.cumsum(arr.state_dims())])
 
@@ -59,7 +58,20 @@ def main():
             st = be.stats()
             be.set_profiling(-1)
             dev_ms = st["ms_linearize"] + st["ms_assemble_hessian"] + st["ms_factorize"]
+            # the same update followed by ISAM2's partial back-substitution (default wildfireThreshold 1e-3); the moved
+            # states are nudged so that the solution does change and the change has to be chased down the tree
+            nudged = states + 1e-4 * rng.standard_normal(states.size)
+            be.relinearize_partial(keys, nudged)
+            _, n_wf = be.backsubstitute_wildfire(1e-3, want_delta=False)
+            be.synchronize()
+            t0 = time.perf_counter()
+            for k in range(10):
+                be.relinearize_partial(keys, nudged if k % 2 else states)
+                be.backsubstitute_wildfire(1e-3, want_delta=False)
+            be.synchronize()
+            t_wf = (time.perf_counter() - t0) / 10
             rows.append(dict(workload=name, moved=f"{pick} {n} poses", full_ms=1e3 * t_full, partial_ms=1e3 * t_part,
+                             partial_wildfire_ms=1e3 * t_wf, wildfire_vars_solved=n_wf, n_vars=int(arr.n_vars),
                              partial_device_ms_without_backsolve=dev_ms, **stats))
             print(json.dumps(rows[-1]), flush=True)
         be.close()
