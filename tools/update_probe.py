@@ -51,11 +51,48 @@ pb.linearize()
 pb.solve(0.0, False, want_delta=False)     # the same with every factor re-linearized
 pb.synchronize()
 t_full = time.perf_counter() - t0
+# ---- the relinearization step of an iSAM2 update on the same handle (config 5's "iSAM2 relinearize + partial Bayes-tree
+#      re-elimination"): the R most recent keyframes move, their factors are re-linearized, the cliques that hold them and
+#      their ancestors re-eliminated (gsx_relinearize_partial), then ISAM2's partial back-substitution (wildfire, 1e-3)
+partial = []
+so2 = a2.state_offsets()
+pose_idx = np.nonzero(a2.var_types == A.VAR_POSE3)[0]
+rng = np.random.default_rng(5)
+for R in (1, 10, 100):
+    idx = pose_idx[-R:]
+    keys = a2.var_keys[idx]
+    cur = pb.get_values()
+    base = np.concatenate([cur[so2[i]:so2[i + 1]] for i in idx])
+    nudged = base.copy()
+    for k in range(R):                      # translations only (the rotation block stays orthonormal)
+        nudged[12 * k + 9:12 * k + 12] += 1e-3 * rng.standard_normal(3)
+    pb.relinearize_partial(keys, nudged)    # warm the scratch tables
+    pb.backsubstitute_wildfire(1e-3, want_delta=False)
+    pb.synchronize()
+    t_p, t_w, n_wf, stp = 0.0, 0.0, 0, None
+    reps = 6
+    for k in range(reps):
+        t0 = time.perf_counter()
+        stp = pb.relinearize_partial(keys, base if k % 2 == 0 else nudged)
+        pb.synchronize()
+        t1 = time.perf_counter()
+        _, n_wf = pb.backsubstitute_wildfire(1e-3, want_delta=False)
+        pb.synchronize()
+        t2 = time.perf_counter()
+        t_p += t1 - t0
+        t_w += t2 - t1
+    t0 = time.perf_counter()
+    pb.solve(0.0, False, want_delta=False)  # the plain back-substitution of the same factorization, for comparison
+    pb.synchronize()
+    t_bs = time.perf_counter() - t0
+    partial.append(dict(moved_keyframes=R, relinearize_partial_ms=1e3 * t_p / reps, wildfire_backsub_ms=1e3 * t_w / reps,
+                        wildfire_vars_solved=n_wf, plain_backsub_ms=1e3 * t_bs, **stp))
 s = pb.stats()
 print(json.dumps({
     "probe": "gsx_update", "keyframes": K, "landmarks": int(a2.meta["n_landmarks"]), "projection_factors": int(a2.meta["n_obs"]),
     "variables": a2.n_vars, "factors": a2.n_factors, "initial_ordering_and_symbolic_s": t_sym0,
     "error_before_after_3_lm_iterations": [r0["initial_error"], r0["final_error"]],
     "update": dict(st, wall_s=t_update), "solve_after_update_ms": 1e3 * t_solve, "relinearize_all_and_solve_ms": 1e3 * t_full,
+    "isam2_relinearization_step": partial,
     "tree": {k: s[k] for k in ("n_fronts", "n_levels", "max_front_dim", "factor_flops")},
     "generate_s": t_gen}))
