@@ -2033,19 +2033,27 @@ constexpr int kLG = 4;  // sources per group
 struct LeanGroup {
   double x[kLG], y[kLG];
 };
+// SAME: a diagonal destination block — both operands are the same rows of the panel (d2 = 0, dB = dA): one load a source
+// instead of two (a third of a landmark's blocks are diagonal ones, and the kernel is bound by the texture-address path:
+// profiles/r02_bal1723_gather_pmc.json)
+template <bool SAME>
 __device__ __forceinline__ void lean_group_load(LeanGroup& g, const double* arena, i64 rec_off, int rec_d2, int rec_ldF,
                                                 int first, int cnt, int li, int lk, bool rowB, bool colA) {
 #pragma unroll
   for (int i = 0; i < kLG; ++i) {
     const int src = first + i;  // wave-uniform
     const i64 off = readlane_i64(rec_off, src & 63);
-    const int d2 = __builtin_amdgcn_readlane(rec_d2, src & 63);
     const int ldF = __builtin_amdgcn_readlane(rec_ldF, src & 63);
     const double* pb = arena + off;
     const unsigned o = (unsigned)li + (unsigned)lk * (unsigned)(ldF & 0xFFFFFF);
     const bool in = i < cnt && lk < (ldF >> 24);
     g.x[i] = (rowB && in) ? pb[o] : 0.0;
-    g.y[i] = (colA && in) ? pb[(i64)d2 + o] : 0.0;
+    if (SAME) {
+      g.y[i] = g.x[i];
+    } else {
+      const int d2 = __builtin_amdgcn_readlane(rec_d2, src & 63);
+      g.y[i] = (colA && in) ? pb[(i64)d2 + o] : 0.0;
+    }
   }
 }
 __device__ __forceinline__ void lean_group_mfma(const LeanGroup& g, v4d& acc) {
@@ -2097,7 +2105,8 @@ __global__ void __launch_bounds__(256) big_gather_seg_kernel(GatherArgs G, int s
       const unsigned long long want = (valid >> s) & ((1ull << kLG) - 1ull);
       if (((fast >> s) & want) == want) {
         LeanGroup ga;
-        lean_group_load(ga, arena, rec.off, rec.d2, rec.ldF, s, n - s, li, lk, rowB, colA);
+        if (diag && dB == dA) lean_group_load<true>(ga, arena, rec.off, rec.d2, rec.ldF, s, n - s, li, lk, rowB, colA);
+        else lean_group_load<false>(ga, arena, rec.off, rec.d2, rec.ldF, s, n - s, li, lk, rowB, colA);
         lean_group_mfma(ga, acc);
         s += kLG;
         continue;
