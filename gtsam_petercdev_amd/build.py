@@ -30,7 +30,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
                "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value", "-c", os.path.join(CSRC, s), "-o", o]
         if os.environ.get("GSX_STAMP") and s.endswith(".hip"):
             cmd.insert(1, "-DGSX_STAMP")
-        if os.environ.get("GSX_EXTRA_DEFINES") and s.endswith(".hip"):
+        if os.environ.get("GSX_EXTRA_DEFINES"):   # (experiment builds: tools_exp.sh)
             for d in os.environ["GSX_EXTRA_DEFINES"].split():
                 cmd.insert(1, "-D" + d)
         if s.endswith(".cpp"):
