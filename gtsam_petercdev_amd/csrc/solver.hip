@@ -617,17 +617,25 @@ gsx_status upload_symbolic(gsx_context* c) {
   for (int l = 0; l < S.n_levels; ++l) {
     int i = S.lvl_ptr[l];
     for (int k = i; k < S.lvl_leaf_end[l]; ++k) c->leaf_max_F[l] = std::max(c->leaf_max_F[l], S.F[S.sched[k]]);
-    // leaf-kernel fronts: sorted by (F, N); a launch = same F, panel size within 1.5x
+    // leaf-kernel fronts: sorted by (F, N); a launch = same F, panel size within 1.5x (or any size: below)
     const int le = S.lvl_leaf_end[l];
     while (i < le) {
       const int F0 = S.F[S.sched[i]], n0 = std::max(S.N[S.sched[i]], 8);
       int j = i, maxp = 0, maxn = 0;
-      while (j < le && S.F[S.sched[j]] == F0 && S.N[S.sched[j]] * 2 <= n0 * 3) {
+      // (lean narrow leaves — the landmarks under a blocked camera front: panel only, no Schur complement to form — of any
+      //  height go in ONE launch of one-wave workgroups: four launches by panel height took 178 us on BAL-1723, one takes
+      //  155; the others keep the 1.5x rule and their thread classes — the outer product of a stored complement wants a
+      //  thread per row, and the Pose2 leaves got slower in one launch)
+      const bool narrow = F0 <= 4 && S.lean[S.sched[i]];
+      while (j < le && S.F[S.sched[j]] == F0 &&
+             (narrow ? (bool)S.lean[S.sched[j]] : (S.N[S.sched[j]] * 2 <= n0 * 3 && !(F0 <= 4 && S.lean[S.sched[j]])))) {
         maxp = std::max(maxp, S.N[S.sched[j]] * S.F[S.sched[j]]);
         maxn = std::max(maxn, S.N[S.sched[j]]);
         ++j;
       }
-      c->leaf_launch[l].push_back({i, j - i, maxn, maxn <= 72 ? 64 : (maxn <= 110 ? 128 : 256), maxp});
+      // (the outer product of a stored complement runs a thread per trailing row: never fewer threads than n - F)
+      const int rows_below = maxn - F0;
+      c->leaf_launch[l].push_back({i, j - i, maxn, narrow ? 64 : (maxn <= 72 && rows_below <= 64 ? 64 : (maxn <= 110 ? 128 : 256)), maxp});
       i = j;
     }
     const int se = S.lvl_small_end[l];

@@ -942,6 +942,42 @@ def test_assembly_kernel_corner_shapes(gpu, oracle):
             assert relerr(gb.solve(lam, diag), ob.solve(lam, diag)) < 1e-8
 
 
+@pytest.mark.parametrize("m", [20, 21, 22, 23])
+def test_leaf_clique_with_many_trailing_rows(gpu, oracle, m):
+    """A childless one-variable clique whose separator has m Pose2 neighbours: 3 m + 1 trailing rows under 3 frontal
+    columns.  Its Schur complement is an outer product with a thread per trailing row, so the launch needs at least
+    that many threads: 22 neighbours = 67 rows sits just above one wave (a 64-thread launch left rows 64.. unwritten)."""
+    g, v = NonlinearFactorGraph(), Values()
+    rng = np.random.default_rng(m)
+    noise = noiseModel.Diagonal.Sigmas(np.array([0.2, 0.2, 0.1]))
+    v.insert(0, Pose2(0.1, -0.1, 0.05))
+    for k in range(1, m + 1):
+        a = 2 * np.pi * k / m
+        v.insert(k, Pose2(2 * np.cos(a) + rng.normal(0, 0.05), 2 * np.sin(a) + rng.normal(0, 0.05), a + rng.normal(0, 0.02)))
+        g.add(BetweenFactor(0, k, Pose2(2 * np.cos(a), 2 * np.sin(a), a), noise))
+        g.addPrior(k, Pose2(2 * np.cos(a), 2 * np.sin(a), a), noiseModel.Isotropic.Sigma(3, 0.5))
+        if k > 1:
+            g.add(BetweenFactor(k - 1, k, Pose2(0.3, 0.2, 2 * np.pi / m), noiseModel.Isotropic.Sigma(3, 0.3)))
+    # one more pose behind pose 1, eliminated last: the neighbours' clique then holds a variable the hub does not see, so
+    # the reference's merge rule (child separator == all of the parent) leaves the hub's clique alone
+    v.insert(m + 1, Pose2(3.0, 0.5, 0.3))
+    g.add(BetweenFactor(1, m + 1, Pose2(1.0, 0.3, 0.2), noise))
+    g.addPrior(m + 1, Pose2(3.0, 0.5, 0.3), noiseModel.Isotropic.Sigma(3, 0.5))
+    arr = g.to_arrays(v)
+    gb, ob = gpu.product_backend(arr), oracle.oracle_backend(arr)
+    order = list(range(m + 2))            # the hub first: its clique is a leaf with all m neighbours in the separator
+    for be in (gb, ob):
+        be.set_amalgamation(0.0, 128) if be is gb else None
+        be.set_ordering(order)
+        be.linearize()
+    parent, fronts = gb.get_tree()
+    hub = [c for c, (f, s) in enumerate(fronts) if f == [0]]
+    assert hub and len(fronts[hub[0]][1]) == m
+    for lam in (0.0, 1e-3):
+        assert relerr(gb.solve(lam, False), ob.solve(lam, False)) < 1e-9, (m, lam)
+    assert relerr(gb.marginal_covariance(1), ob.marginal_covariance(1)) < 1e-8
+
+
 # ---- a resident factorization never outlives the tree / linearization it was computed for ----------------------------------
 @pytest.mark.parametrize("name", ["bal_small", "pose3"])
 def test_reordering_a_live_handle_drops_the_resident_factorization(gpu, oracle, name):
