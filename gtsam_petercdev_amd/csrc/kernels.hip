@@ -1956,8 +1956,9 @@ __global__ void front_leaf_kernel(DevProblem P, DevSymbolic S, const LeafRec* re
   const int s1 = n - F;
   {
     const int G = max(1, nt / s1);
-    const int r = tid % s1, g = tid / s1;
-    if (g < G) {
+    // (a launch with fewer threads than trailing rows — the host never chooses one — still covers every row)
+    for (int rr = tid; rr < s1 * G; rr += nt) {
+      const int r = rr % s1, g = rr / s1;
       double rv[kLeafMaxF];
 #pragma unroll
       for (int k = 0; k < kLeafMaxF; ++k) rv[k] = (k < F) ? Pn[F + r + k * n] : 0.0;

@@ -2511,7 +2511,11 @@ gsx_status gsx_marginal_covariance(gsx_handle h, uint64_t key, double* out, int6
     return GSX_E_INVALID;
   }
   const int dA = h->P.dims[v];
-  if (n_out != (int64_t)dA * dA || dA > 16) return GSX_E_INVALID;
+  if (n_out != (int64_t)dA * dA) return GSX_E_INVALID;
+  if (dA > 16) {
+    h->err = "marginal: variables of more than 16 dimensions are not supported by the path kernel";
+    return GSX_E_INVALID;
+  }
   gsx_status st = marginals_prepare(h);
   if (st != GSX_OK) return st;
   const Symbolic& S = h->S;

@@ -978,6 +978,56 @@ def test_leaf_clique_with_many_trailing_rows(gpu, oracle, m):
     assert relerr(gb.marginal_covariance(1), ob.marginal_covariance(1)) < 1e-8
 
 
+@pytest.mark.parametrize("seed,dense", [(1, False), (2, True)])
+def test_linear_graph_with_wide_variables(gpu, oracle, seed, dense):
+    """Vector variables of 1 to 40 dimensions (blocks wider than one 16 x 16 matrix-core tile: the gather's wide path, H
+    panels and fronts with ragged blocks) in a linear-Gaussian graph — the NonlinearOptimizer::solve seam hands over
+    whatever dimensions the caller's variables have.  dense=True adds a cluster that makes blocked (n > 140) fronts with
+    wide children below them."""
+    rng = np.random.default_rng(seed)
+    dims = [int(d) for d in rng.choice([1, 2, 5, 9, 17, 24, 33, 40], size=36)]
+    fg = GaussianFactorGraph()
+    def block(m, d):
+        return rng.normal(0, 0.3, (m, d))
+    for k, d in enumerate(dims):
+        fg.add(JacobianFactor(k, np.eye(d) + 0.1 * rng.normal(size=(d, d)), rng.normal(size=d),
+                              noiseModel.Isotropic.Sigma(d, 1.0 + 0.1 * k)))
+    pairs = [(k, k + 1) for k in range(len(dims) - 1)] + [(int(a), int(b)) for a, b in rng.integers(0, len(dims), (30, 2)) if a != b]
+    if dense:
+        pairs += [(a, b) for a in range(8, 16) for b in range(a + 1, 16)]
+    for a, b in pairs:
+        m = max(1, min(dims[a], dims[b], 6))
+        fg.add(JacobianFactor(a, block(m, dims[a]), b, block(m, dims[b]), rng.normal(size=m),
+                              noiseModel.Diagonal.Sigmas(0.5 + rng.random(m))))
+    arr = fg.to_arrays(None)
+    arr.values = np.zeros(int(arr.var_dims.sum()))
+    assert int(arr.var_dims.max()) > 16
+    gb, ob = gpu.product_backend(arr), oracle.oracle_backend(arr)
+    for kind, relax in ((A.ORDER_MINDEGREE, 0.0), (A.ORDER_ND, 0.0), (A.ORDER_NATURAL, None)):
+        ordering = gb.compute_ordering(kind)
+        if relax is not None:
+            gb.set_amalgamation(relax, 128)
+        else:
+            gb.set_amalgamation(0.5, 64)
+        gb.set_ordering(ordering)
+        ob.set_ordering(ordering)
+        gb.linearize()
+        ob.linearize()
+        assert relerr(gb.hessian_diagonal(), ob.hessian_diagonal()) < 1e-12
+        for lam, diag in ((0.0, False), (1e-2, True)):
+            assert relerr(gb.solve(lam, diag), ob.solve(lam, diag)) < 1e-9, (kind, lam)
+        gb.solve(0.0, False)
+        ob.solve(0.0, False)
+        # (the marginal path kernel takes variables of up to 16 dimensions — through fronts with wider neighbours here)
+        kw = int(arr.var_keys[int(np.argmax(np.where(arr.var_dims <= 16, arr.var_dims, 0)))])
+        assert relerr(gb.marginal_covariance(kw), ob.marginal_covariance(kw)) < 1e-8
+        with pytest.raises(A.GsxError):
+            gb.marginal_covariance(int(arr.var_keys[int(np.argmax(arr.var_dims))]))
+    st = gb.stats()
+    if dense:
+        assert st["n_big_fronts"] > 0
+
+
 # ---- a resident factorization never outlives the tree / linearization it was computed for ----------------------------------
 @pytest.mark.parametrize("name", ["bal_small", "pose3"])
 def test_reordering_a_live_handle_drops_the_resident_factorization(gpu, oracle, name):
