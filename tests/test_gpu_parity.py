@@ -1028,6 +1028,111 @@ def test_linear_graph_with_wide_variables(gpu, oracle, seed, dense):
         assert st["n_big_fronts"] > 0
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_random_linear_graphs(gpu, oracle, seed):
+    """Structure fuzz: random linear-Gaussian graphs — chains with random chords, hubs with many neighbours (leaf cliques
+    with tall separators), dense clusters (blocked fronts), variables of 1-9 dimensions — under every ordering and three
+    amalgamation settings, against the oracle.  Aimed at the boundaries between the kernels' size classes."""
+    rng = np.random.default_rng(1000 + seed)
+    nv = int(rng.choice([4, 9, 30, 70, 140, 260]))
+    dim_sets = ([3], [6], [1, 2, 3], [2, 6, 9], [9, 3])
+    ds = dim_sets[seed % len(dim_sets)]
+    dims = [int(d) for d in rng.choice(ds, size=nv)]
+    fg = GaussianFactorGraph()
+    for k, d in enumerate(dims):
+        fg.add(JacobianFactor(k, np.eye(d) * (0.5 + rng.random()), rng.normal(size=d), noiseModel.Isotropic.Sigma(d, 2.0)))
+    pairs = {(k, k + 1) for k in range(nv - 1)}
+    for a, b in rng.integers(0, nv, (int(nv * rng.choice([0.2, 1.0, 2.5])), 2)):
+        if a != b:
+            pairs.add((int(min(a, b)), int(max(a, b))))
+    for hub in rng.integers(0, nv, 2):                       # hubs: one variable with up to 40 neighbours
+        for b in rng.choice(nv, size=min(nv - 1, int(rng.choice([5, 22, 40]))), replace=False):
+            if int(b) != int(hub):
+                pairs.add((int(min(hub, b)), int(max(hub, b))))
+    if nv >= 30 and seed % 3 == 0:                           # a dense cluster
+        c0 = int(rng.integers(0, nv - 20))
+        pairs |= {(a, b) for a in range(c0, c0 + 18) for b in range(a + 1, c0 + 18)}
+    for a, b in sorted(pairs):
+        m = int(rng.integers(1, 1 + min(dims[a] + dims[b], 6)))
+        fg.add(JacobianFactor(a, rng.normal(0, 0.4, (m, dims[a])), b, rng.normal(0, 0.4, (m, dims[b])), rng.normal(size=m),
+                              noiseModel.Diagonal.Sigmas(0.5 + rng.random(m))))
+    arr = fg.to_arrays(None)
+    arr.values = np.zeros(int(arr.var_dims.sum()))
+    gb, ob = gpu.product_backend(arr), oracle.oracle_backend(arr)
+    kinds = [A.ORDER_NATURAL, A.ORDER_MINDEGREE, A.ORDER_ND]
+    for kind, amalg in zip(kinds, ((0.0, 128), None, (1.0, 48))):
+        ordering = gb.compute_ordering(kind)
+        if kind == A.ORDER_NATURAL and seed % 2:
+            ordering = ordering[::-1].copy()
+        if amalg is not None:
+            gb.set_amalgamation(*amalg)
+        gb.set_ordering(ordering)
+        ob.set_ordering(ordering)
+        gb.linearize()
+        ob.linearize()
+        for lam, diag in ((0.0, False), (1e-2, True)):
+            assert relerr(gb.solve(lam, diag), ob.solve(lam, diag)) < 1e-8, (seed, nv, kind, lam)
+        e_g, e_o = gb.linear_error(), ob.linear_error()
+        assert abs(e_g[1] - e_o[1]) <= 1e-9 * max(abs(e_o[1]), 1e-12)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_partial_reelimination_on_random_structures(gpu, seed):
+    """Structure fuzz of the filtered launch plans: random Pose2 graphs with chords, hubs and a dense cluster; random sets
+    of moved variables; gsx_relinearize_partial + back-substitution must stay bit for bit the full path, and the
+    wildfire pass at threshold 0 likewise."""
+    rng = np.random.default_rng(500 + seed)
+    nv = int(rng.choice([12, 60, 150, 400]))
+    g, v = NonlinearFactorGraph(), Values()
+    pos = np.cumsum(rng.normal(0.5, 0.2, (nv, 2)), axis=0)
+    th = np.cumsum(rng.normal(0, 0.1, nv))
+    for k in range(nv):
+        v.insert(k, Pose2(pos[k, 0], pos[k, 1], th[k]))
+    g.addPrior(0, Pose2(pos[0, 0], pos[0, 1], th[0]), noiseModel.Isotropic.Sigma(3, 0.1))
+    pairs = {(k, k + 1) for k in range(nv - 1)}
+    for a, b in rng.integers(0, nv, (int(nv * rng.choice([0.3, 1.5])), 2)):
+        if a != b:
+            pairs.add((int(min(a, b)), int(max(a, b))))
+    hub = int(rng.integers(0, nv))
+    for b in rng.choice(nv, size=min(nv - 1, int(rng.choice([8, 22, 30]))), replace=False):
+        if int(b) != hub:
+            pairs.add((min(hub, int(b)), max(hub, int(b))))
+    if nv >= 60 and seed % 2 == 0:
+        c0 = int(rng.integers(0, nv - 50))
+        pairs |= {(a, b) for a in range(c0, c0 + 48) for b in range(a + 1, c0 + 48) if rng.random() < 0.6}
+    for a, b in sorted(pairs):
+        c, s_ = math.cos(th[a]), math.sin(th[a])      # pa^-1 pb
+        dx, dy = pos[b, 0] - pos[a, 0], pos[b, 1] - pos[a, 1]
+        zx, zy, zt = c * dx + s_ * dy, -s_ * dx + c * dy, th[b] - th[a]
+        g.add(BetweenFactor(a, b, Pose2(zx + rng.normal(0, 0.05), zy + rng.normal(0, 0.05), zt + rng.normal(0, 0.02)),
+                            noiseModel.Diagonal.Sigmas(np.array([0.2, 0.2, 0.1]))))
+    arr = g.to_arrays(v)
+    P, F = gpu.product_backend(arr), gpu.product_backend(arr)
+    kind = [A.ORDER_ND, A.ORDER_MINDEGREE][seed % 2]
+    ordering = P.compute_ordering(kind)
+    for be in (P, F):
+        if seed % 3 == 0:
+            be.set_amalgamation(0.0, 128)
+        be.set_ordering(ordering)
+    P.linearize()
+    P.solve(0.0, False)
+    off = np.concatenate([[0], np.cumsum(arr.state_dims())])
+    current = arr.values.copy()
+    for round_ in range(3):
+        idx = np.sort(rng.choice(nv, size=max(1, int(nv * rng.choice([0.02, 0.1]))), replace=False))
+        states = []
+        for i in idx:
+            current[off[i]:off[i + 1]] += rng.normal(0, 0.02, 3)
+            states.append(current[off[i]:off[i + 1]])
+        P.relinearize_partial(arr.var_keys[idx], np.concatenate(states))
+        dp = P.solve(0.0, False) if round_ % 2 == 0 else P.backsubstitute_wildfire(0.0)[0]
+        F.set_values(current)
+        F.linearize()
+        df = F.solve(0.0, False)
+        assert np.array_equal(P.jacobians(), F.jacobians()), (seed, round_)
+        assert np.array_equal(dp, df), (seed, round_, float(np.max(np.abs(dp - df))))
+
+
 # ---- a resident factorization never outlives the tree / linearization it was computed for ----------------------------------
 @pytest.mark.parametrize("name", ["bal_small", "pose3"])
 def test_reordering_a_live_handle_drops_the_resident_factorization(gpu, oracle, name):
