@@ -1074,6 +1074,14 @@ def test_random_linear_graphs(gpu, oracle, seed):
             assert relerr(gb.solve(lam, diag), ob.solve(lam, diag)) < 1e-8, (seed, nv, kind, lam)
         e_g, e_o = gb.linear_error(), ob.linear_error()
         assert abs(e_g[1] - e_o[1]) <= 1e-9 * max(abs(e_o[1]), 1e-12)
+        # marginals from the undamped factorization: a variable deep in the tree, one near the root, a joint of three
+        gb.solve(0.0, False)
+        ob.solve(0.0, False)
+        ks = [int(ordering[0]), int(ordering[-1]), int(ordering[len(ordering) // 2])]
+        for k in ks[:2]:
+            assert relerr(gb.marginal_covariance(k), ob.marginal_covariance(k)) < 1e-7, (seed, kind, k)
+        if len(set(ks)) == 3:
+            assert relerr(gb.joint_marginal_covariance(sorted(ks)), ob.joint_marginal_covariance(sorted(ks))) < 1e-7
 
 
 @pytest.mark.parametrize("seed", range(10))
