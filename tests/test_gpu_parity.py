@@ -1084,18 +1084,13 @@ def test_random_linear_graphs(gpu, oracle, seed):
             assert relerr(gb.joint_marginal_covariance(sorted(ks)), ob.joint_marginal_covariance(sorted(ks))) < 1e-7
 
 
-@pytest.mark.parametrize("seed", range(10))
-def test_partial_reelimination_on_random_structures(gpu, seed):
-    """Structure fuzz of the filtered launch plans: random Pose2 graphs with chords, hubs and a dense cluster; random sets
-    of moved variables; gsx_relinearize_partial + back-substitution must stay bit for bit the full path, and the
-    wildfire pass at threshold 0 likewise."""
-    rng = np.random.default_rng(500 + seed)
-    nv = int(rng.choice([12, 60, 150, 400]))
+def _random_pose2_graph(rng, nv, cluster):
+    """Random Pose2 graph: a noisy chain with chords, one hub with up to 30 neighbours, optionally a dense cluster."""
     g, v = NonlinearFactorGraph(), Values()
     pos = np.cumsum(rng.normal(0.5, 0.2, (nv, 2)), axis=0)
     th = np.cumsum(rng.normal(0, 0.1, nv))
     for k in range(nv):
-        v.insert(k, Pose2(pos[k, 0], pos[k, 1], th[k]))
+        v.insert(k, Pose2(pos[k, 0] + rng.normal(0, 0.03), pos[k, 1] + rng.normal(0, 0.03), th[k] + rng.normal(0, 0.01)))
     g.addPrior(0, Pose2(pos[0, 0], pos[0, 1], th[0]), noiseModel.Isotropic.Sigma(3, 0.1))
     pairs = {(k, k + 1) for k in range(nv - 1)}
     for a, b in rng.integers(0, nv, (int(nv * rng.choice([0.3, 1.5])), 2)):
@@ -1105,7 +1100,7 @@ def test_partial_reelimination_on_random_structures(gpu, seed):
     for b in rng.choice(nv, size=min(nv - 1, int(rng.choice([8, 22, 30]))), replace=False):
         if int(b) != hub:
             pairs.add((min(hub, int(b)), max(hub, int(b))))
-    if nv >= 60 and seed % 2 == 0:
+    if nv >= 60 and cluster:
         c0 = int(rng.integers(0, nv - 50))
         pairs |= {(a, b) for a in range(c0, c0 + 48) for b in range(a + 1, c0 + 48) if rng.random() < 0.6}
     for a, b in sorted(pairs):
@@ -1114,6 +1109,48 @@ def test_partial_reelimination_on_random_structures(gpu, seed):
         zx, zy, zt = c * dx + s_ * dy, -s_ * dx + c * dy, th[b] - th[a]
         g.add(BetweenFactor(a, b, Pose2(zx + rng.normal(0, 0.05), zy + rng.normal(0, 0.05), zt + rng.normal(0, 0.02)),
                             noiseModel.Diagonal.Sigmas(np.array([0.2, 0.2, 0.1]))))
+    return g, v
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_optimizers_on_random_structures(gpu, oracle, seed):
+    """LM (legacy and Ceres policies), Gauss-Newton and Dogleg on random Pose2 structures: the oracle's accept/reject
+    trace, lambda / trust-region schedule and errors."""
+    rng = np.random.default_rng(900 + seed)
+    nv = int(rng.choice([15, 80, 200]))
+    g, v = _random_pose2_graph(rng, nv, seed % 2 == 0)
+    arr = g.to_arrays(v)
+    kind = [A.ORDER_ND, A.ORDER_MINDEGREE][seed % 2]
+    for which in ("legacy", "ceres", "gn", "dogleg"):
+        gb, ob = gpu.product_backend(arr), oracle.oracle_backend(arr)
+        ordering = gb.compute_ordering(kind)
+        gb.set_ordering(ordering)
+        ob.set_ordering(ordering)
+        if which in ("legacy", "ceres"):
+            p = A.lm_params_legacy() if which == "legacy" else A.lm_params_ceres()
+            p.max_iterations = 12
+            rg, ro = gb.lm_optimize(p), ob.lm_optimize(p)
+            assert np.array_equal(rg["trace_accepted"], ro["trace_accepted"]), (seed, which)
+            assert np.allclose(rg["trace_lambda"], ro["trace_lambda"], rtol=1e-8), (seed, which)
+        elif which == "gn":
+            rg, ro = gb.gn_optimize(8), ob.gn_optimize(8)
+        else:
+            rg, ro = gb.dogleg_optimize(1.0, 10), ob.dogleg_optimize(1.0, 10)
+        assert rg["iterations"] == ro["iterations"], (seed, which)
+        assert abs(rg["final_error"] - ro["final_error"]) <= 1e-6 * max(ro["final_error"], 1e-12), (seed, which)
+        assert relerr(gb.get_values(), ob.get_values()) < 1e-7, (seed, which)
+        gb.close()
+        ob.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_partial_reelimination_on_random_structures(gpu, seed):
+    """Structure fuzz of the filtered launch plans: random Pose2 graphs with chords, hubs and a dense cluster; random sets
+    of moved variables; gsx_relinearize_partial + back-substitution must stay bit for bit the full path, and the
+    wildfire pass at threshold 0 likewise."""
+    rng = np.random.default_rng(500 + seed)
+    nv = int(rng.choice([12, 60, 150, 400]))
+    g, v = _random_pose2_graph(rng, nv, seed % 2 == 0)
     arr = g.to_arrays(v)
     P, F = gpu.product_backend(arr), gpu.product_backend(arr)
     kind = [A.ORDER_ND, A.ORDER_MINDEGREE][seed % 2]
