@@ -174,3 +174,80 @@ def test_update_argument_checks(gpu):
         gb.update(arr2, bad, _new_states(arr2, arr.var_keys))
     gb.update(arr2, origin, _new_states(arr2, arr.var_keys))   # the handle is still usable
     assert gb.error() > 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_update_on_random_growth(gpu, seed):
+    """Structure fuzz: a random Pose2 graph (chain, chords, a hub) revealed a few variables at a time, with random factors
+    removed and put back on the way; after every gsx_update the handle equals a fresh handle on the same graph, values and
+    ordering (Jacobians to 1e-12, Gauss-Newton step to 1e-9), also after a partial relinearization on top of it."""
+    from gtsam_petercdev_amd.graph import Pose2
+    rng = np.random.default_rng(700 + seed)
+    nv = int(rng.choice([20, 60, 120]))
+    pos = np.cumsum(rng.normal(0.5, 0.2, (nv, 2)), axis=0)
+    th = np.cumsum(rng.normal(0, 0.1, nv))
+    init = {k: Pose2(pos[k, 0] + rng.normal(0, 0.03), pos[k, 1] + rng.normal(0, 0.03), th[k] + rng.normal(0, 0.01))
+            for k in range(nv)}
+    pairs = {(k, k + 1) for k in range(nv - 1)}
+    for a, b in rng.integers(0, nv, (nv, 2)):
+        if a != b:
+            pairs.add((int(min(a, b)), int(max(a, b))))
+    hub = int(rng.integers(0, nv // 2))
+    for b in rng.choice(nv, size=min(nv - 1, 25), replace=False):
+        if int(b) != hub:
+            pairs.add((min(hub, int(b)), max(hub, int(b))))
+    sig = noiseModel.Diagonal.Sigmas(np.array([0.2, 0.2, 0.1]))
+    all_factors = [PriorFactor(0, Pose2(pos[0, 0], pos[0, 1], th[0]), noiseModel.Isotropic.Sigma(3, 0.1))]
+    for a, b in sorted(pairs, key=lambda ab: ab[1]):
+        c, s_ = math.cos(th[a]), math.sin(th[a])
+        dx, dy = pos[b, 0] - pos[a, 0], pos[b, 1] - pos[a, 1]
+        all_factors.append(BetweenFactor(a, b, Pose2(c * dx + s_ * dy + rng.normal(0, 0.05), -s_ * dx + c * dy + rng.normal(0, 0.05),
+                                                     th[b] - th[a] + rng.normal(0, 0.02)), sig))
+    def active(n_known, removed):
+        return [f for f in all_factors if max(f.keys_) < n_known and id(f) not in removed]
+    n_known = max(4, nv // 5)
+    removed = set()
+    cur = active(n_known, removed)
+    arr = _arrays(cur, {k: init[k] for k in range(n_known)})
+    gb = gpu.product_backend(arr)
+    amalg = (0.0, 128) if seed % 2 else (0.5, 64)   # (explicit on both sides: the library's own choice is made per graph)
+    gb.set_amalgamation(*amalg)
+    gb.set_ordering(gb.compute_ordering([A.ORDER_ND, A.ORDER_MINDEGREE][seed % 2]))
+    gb.linearize()
+    gb.solve(0.0, False)
+    step = 0
+    while n_known < nv:
+        step += 1
+        n_known = min(nv, n_known + int(rng.integers(1, 8)))
+        if step % 3 == 1 and len(cur) > 10:        # drop two between factors that are not chain links
+            cand = [f for f in cur if f.ftype != A.F_PRIOR and abs(f.keys_[0] - f.keys_[1]) > 1]
+            for f in list(rng.choice(cand, size=min(2, len(cand)), replace=False)) if cand else []:
+                removed.add(id(f))
+        elif step % 3 == 0:
+            removed.clear()                            # ... and put everything back
+        new = active(n_known, removed)
+        origin = [next((i for i, g in enumerate(cur) if g is f), -1) for f in new]
+        arr2 = _arrays(new, {k: init[k] for k in range(n_known)})
+        st = gb.update(arr2, origin, _new_states(arr2, arr.var_keys))
+        assert st["n_vars_added"] == arr2.n_vars - arr.n_vars
+        fresh = _arrays(new, {k: init[k] for k in range(n_known)})
+        fresh.values = gb.get_values()
+        fb = gpu.product_backend(fresh)
+        fb.set_amalgamation(*amalg)
+        fb.set_ordering(gb.get_ordering())
+        fb.linearize()
+        assert np.max(np.abs(gb.jacobians() - fb.jacobians())) <= 1e-12 * np.max(np.abs(fb.jacobians())), (seed, step)
+        assert relerr(gb.solve(0.0, False), fb.solve(0.0, False)) < 1e-9, (seed, step)
+        # an iSAM2 relinearization step on top of the updated handle
+        idx = np.arange(max(0, n_known - 3), n_known)
+        so = arr2.state_offsets()
+        vals = gb.get_values()
+        states = np.concatenate([vals[so[i]:so[i + 1]] + rng.normal(0, 0.01, 3) for i in idx])
+        gb.relinearize_partial(arr2.var_keys[idx], states)
+        dp, _ = gb.backsubstitute_wildfire(0.0)
+        fb.set_values(gb.get_values())
+        fb.linearize()
+        assert np.array_equal(dp, fb.solve(0.0, False)), (seed, step)
+        fb.close()
+        cur, arr = new, arr2
+    assert step >= 3
