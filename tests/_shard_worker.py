@@ -14,7 +14,39 @@ import torch  # noqa: E402
 from gtsam_petercdev_amd import _abi as A, _lib, datasets, distributed as D  # noqa: E402
 
 
+def _hub_graph(nv, seed):
+    """A Pose2 chain with random chords, two hubs with 22 / 40 neighbours and a dense cluster (leaf cliques with tall
+    separators, blocked fronts): the irregular structures the seeded Manhattan worlds do not have."""
+    import math
+    from gtsam_petercdev_amd.graph import NonlinearFactorGraph, Values, Pose2, BetweenFactor, noiseModel
+    rng = np.random.default_rng(seed)
+    g, v = NonlinearFactorGraph(), Values()
+    pos = np.cumsum(rng.normal(0.5, 0.2, (nv, 2)), axis=0)
+    th = np.cumsum(rng.normal(0, 0.1, nv))
+    for k in range(nv):
+        v.insert(k, Pose2(pos[k, 0] + rng.normal(0, 0.03), pos[k, 1] + rng.normal(0, 0.03), th[k] + rng.normal(0, 0.01)))
+    g.addPrior(0, Pose2(pos[0, 0], pos[0, 1], th[0]), noiseModel.Isotropic.Sigma(3, 0.1))
+    pairs = {(k, k + 1) for k in range(nv - 1)}
+    for a, b in rng.integers(0, nv, (nv, 2)):
+        if a != b:
+            pairs.add((int(min(a, b)), int(max(a, b))))
+    for hub, deg in ((nv // 7, 22), (nv // 2, 40)):
+        for b in rng.choice(nv, size=deg, replace=False):
+            if int(b) != hub:
+                pairs.add((min(hub, int(b)), max(hub, int(b))))
+    c0 = 2 * nv // 3
+    pairs |= {(a, b) for a in range(c0, c0 + 48) for b in range(a + 1, c0 + 48) if rng.random() < 0.6}
+    sig = noiseModel.Diagonal.Sigmas(np.array([0.2, 0.2, 0.1]))
+    for a, b in sorted(pairs):
+        c, s_ = math.cos(th[a]), math.sin(th[a])
+        dx, dy = pos[b, 0] - pos[a, 0], pos[b, 1] - pos[a, 1]
+        g.add(BetweenFactor(a, b, Pose2(c * dx + s_ * dy + rng.normal(0, 0.05), -s_ * dx + c * dy + rng.normal(0, 0.05),
+                                        th[b] - th[a] + rng.normal(0, 0.02)), sig))
+    return g.to_arrays(v)
+
+
 def problems():
+    yield "pose2_hubs", _hub_graph(900, 8), A.ORDER_ND, 0.0
     yield "pose2", datasets.synth_manhattan_pose2(3000, seed=3), A.ORDER_ND, 0.0
     yield "pose3_relaxed", datasets.synth_manhattan_pose3(4000, seed=4), A.ORDER_ND, 0.5
     yield "bal", datasets.synth_bal_arrays(60, 4000, 18000, seed=5, long_range=0.3), A.ORDER_SCHUR_ND, 0.25
