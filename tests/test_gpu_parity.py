@@ -1084,6 +1084,50 @@ def test_random_linear_graphs(gpu, oracle, seed):
             assert relerr(gb.joint_marginal_covariance(sorted(ks)), ob.joint_marginal_covariance(sorted(ks))) < 1e-7
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_random_bal_structures(gpu, oracle, seed):
+    """Structure fuzz of the bundle-adjustment kernels: small to medium camera systems (landmark leaves with stored or
+    product-form complements), one landmark seen by every camera, one camera that sees a landmark it also sees through a
+    second (duplicate) observation, under the Schur orderings, plain and relaxed trees: H diagonal, damped steps, three LM
+    iterations against the oracle."""
+    rng = np.random.default_rng(300 + seed)
+    nc = int(rng.choice([3, 7, 12, 17, 30, 55]))
+    npts = int(rng.choice([40, 150, 600]))
+    nobs = int(npts * min(rng.choice([2.5, 4.0, 7.0]), 0.8 * nc))
+    arr = datasets.synth_bal_arrays(nc, npts, max(nobs, 2 * npts), seed=300 + seed, long_range=float(rng.choice([0.0, 0.3, 1.0])),
+                                    priors=True)
+    n_sfm = int((arr.f_type == A.F_SFM).sum())
+    cams = arr.f_vars[0:2 * n_sfm:2]
+    pts = arr.f_vars[1:2 * n_sfm:2]
+    lm0 = int(pts[0])
+    z = arr.meas[arr.f_meas_ptr[0]:arr.f_meas_ptr[1]]
+    nz = arr.noise[arr.f_noise_ptr[0]:arr.f_noise_ptr[1]]
+    for c in sorted(set(range(nc)) - set(cams[pts == lm0].tolist())):      # lm0: seen by every camera
+        arr = arr.with_factor(A.F_SFM, [c, lm0], 2, z + rng.normal(0, 2.0, 2), int(arr.f_noise_kind[0]), nz)
+    if seed % 2:                                                            # a duplicate observation
+        arr = arr.with_factor(A.F_SFM, [int(cams[3]), int(pts[3])], 2, arr.meas[arr.f_meas_ptr[3]:arr.f_meas_ptr[4]] + 0.3,
+                              int(arr.f_noise_kind[3]), nz)
+    gb, ob = gpu.product_backend(arr), oracle.oracle_backend(arr)
+    for kind, amalg in ((A.ORDER_SCHUR, (0.0, 128)), (A.ORDER_SCHUR_ND, (0.5, 64)), (A.ORDER_MINDEGREE, None)):
+        ordering = gb.compute_ordering(kind)
+        if amalg is not None:
+            gb.set_amalgamation(*amalg)
+        gb.set_ordering(ordering)
+        ob.set_ordering(ordering)
+        gb.set_values(arr.values)
+        ob.set_values(arr.values)
+        gb.linearize()
+        ob.linearize()
+        assert relerr(gb.hessian_diagonal(), ob.hessian_diagonal()) < 1e-12
+        for lam, diag in ((1e-3, False), (1.0, True)):
+            assert relerr(gb.solve(lam, diag), ob.solve(lam, diag)) < 1e-8, (seed, kind, lam)
+        p = A.lm_params_legacy()
+        p.max_iterations = 3
+        rg, ro = gb.lm_optimize(p), ob.lm_optimize(p)
+        assert np.array_equal(rg["trace_accepted"], ro["trace_accepted"]), (seed, kind)
+        assert abs(rg["final_error"] - ro["final_error"]) <= 1e-6 * ro["final_error"], (seed, kind)
+
+
 def _random_pose2_graph(rng, nv, cluster):
     """Random Pose2 graph: a noisy chain with chords, one hub with up to 30 neighbours, optionally a dense cluster."""
     g, v = NonlinearFactorGraph(), Values()
