@@ -1084,6 +1084,62 @@ def test_random_linear_graphs(gpu, oracle, seed):
             assert relerr(gb.joint_marginal_covariance(sorted(ks)), ob.joint_marginal_covariance(sorted(ks))) < 1e-7
 
 
+def _split_dims(total, rng):
+    out = []
+    while total > 0:
+        d = int(min(total, rng.integers(1, 9)))
+        out.append(d)
+        total -= d
+    return out
+
+
+@pytest.mark.parametrize("dim_b", [12, 60, 131])
+@pytest.mark.parametrize("dim_a", [1, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 191, 192, 193, 230])
+def test_two_clique_size_classes(gpu, oracle, dim_a, dim_b):
+    """A Bayes tree of two cliques, (A | B) under (B, c), with the frontal width of the child swept over the boundaries
+    of the kernels' size classes (leaf kernel up to 16 frontal scalars; back-substitution kernels at 32 / 64; one chunk of
+    the blocked factorization at 192) and its height over the LDS / blocked boundary (140 rows)."""
+    rng = np.random.default_rng(dim_a * 1000 + dim_b)
+    da, db = _split_dims(dim_a, rng), _split_dims(dim_b, rng)
+    dims = da + db + [3]
+    nv = len(dims)
+    fg = GaussianFactorGraph()
+    for k, d in enumerate(dims):
+        fg.add(JacobianFactor(k, np.eye(d) * (0.7 + rng.random()), rng.normal(size=d), noiseModel.Isotropic.Sigma(d, 1.5)))
+    nab = len(da) + len(db)                # A and B mutually adjacent: a two-row factor on every pair
+    for a in range(nab):
+        for b in range(a + 1, nab):
+            fg.add(JacobianFactor(a, rng.normal(0, 0.3, (2, dims[a])), b, rng.normal(0, 0.3, (2, dims[b])), rng.normal(size=2),
+                                  noiseModel.Isotropic.Sigma(2, 1.0)))
+    kb, kc = len(da), nv - 1               # the last variable hangs on B only: (A | B) keeps its own clique
+    fg.add(JacobianFactor(kb, rng.normal(0, 0.4, (3, dims[kb])), kc, rng.normal(0, 0.4, (3, 3)), rng.normal(size=3),
+                          noiseModel.Isotropic.Sigma(3, 0.5)))
+    arr = fg.to_arrays(None)
+    arr.values = np.zeros(int(arr.var_dims.sum()))
+    gb, ob = gpu.product_backend(arr), oracle.oracle_backend(arr)
+    gb.set_amalgamation(0.0, 128)
+    order = list(range(nv))
+    gb.set_ordering(order)
+    ob.set_ordering(order)
+    parent, fronts = gb.get_tree()
+    assert len(fronts) == 2 and sorted(len(f) for f, _ in fronts) == sorted([len(da), len(db) + 1])
+    gb.linearize()
+    ob.linearize()
+    for lam, diag in ((0.0, False), (0.1, True)):
+        assert relerr(gb.solve(lam, diag), ob.solve(lam, diag)) < 1e-9, (dim_a, dim_b, lam)
+    gb.solve(0.0, False)
+    ob.solve(0.0, False)
+    for k in (0, kb, kc):
+        assert relerr(gb.marginal_covariance(k), ob.marginal_covariance(k)) < 1e-8, (dim_a, dim_b, k)
+    # the conditional of the child clique, entry by entry
+    child = [c for c, (f, _) in enumerate(fronts) if f[0] == 0][0]
+    po, fo = ob.get_tree()
+    co = [c for c, (f, _) in enumerate(fo) if f[0] == 0][0]
+    Rg, Ro = gb.conditional(child), ob.conditional(co)
+    assert Rg.shape == Ro.shape and fo[co][1] == fronts[child][1]
+    assert np.abs(Rg - Ro).max() <= 1e-9 * np.abs(Ro).max()
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_random_bal_structures(gpu, oracle, seed):
     """Structure fuzz of the bundle-adjustment kernels: small to medium camera systems (landmark leaves with stored or
