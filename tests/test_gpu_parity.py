@@ -1099,6 +1099,19 @@ def test_two_clique_size_classes(gpu, oracle, dim_a, dim_b):
     """A Bayes tree of two cliques, (A | B) under (B, c), with the frontal width of the child swept over the boundaries
     of the kernels' size classes (leaf kernel up to 16 frontal scalars; back-substitution kernels at 32 / 64; one chunk of
     the blocked factorization at 192) and its height over the LDS / blocked boundary (140 rows)."""
+    _two_clique_case(gpu, oracle, dim_a, dim_b)
+
+
+@pytest.mark.parametrize("dim_a", [1, 3, 6, 16])
+def test_leaf_clique_heights(gpu, oracle, dim_a):
+    """The same tree with a leaf-kernel child and the height of its separator swept row by row through the thread classes
+    of the leaf launch (64 / 128 / 256 threads; a thread per trailing row of the stored complement) and over the point
+    where the parent becomes a blocked front and the leaf keeps only its panel."""
+    for dim_b in list(range(58, 76)) + list(range(104, 114)) + [127, 128, 129, 135, 136, 137, 138, 139, 140]:
+        _two_clique_case(gpu, oracle, dim_a, dim_b, light=True)
+
+
+def _two_clique_case(gpu, oracle, dim_a, dim_b, light=False):
     rng = np.random.default_rng(dim_a * 1000 + dim_b)
     da, db = _split_dims(dim_a, rng), _split_dims(dim_b, rng)
     dims = da + db + [3]
@@ -1131,6 +1144,10 @@ def test_two_clique_size_classes(gpu, oracle, dim_a, dim_b):
     ob.solve(0.0, False)
     for k in (0, kb, kc):
         assert relerr(gb.marginal_covariance(k), ob.marginal_covariance(k)) < 1e-8, (dim_a, dim_b, k)
+    if light:
+        gb.close()
+        ob.close()
+        return
     # the conditional of the child clique, entry by entry
     child = [c for c, (f, _) in enumerate(fronts) if f[0] == 0][0]
     po, fo = ob.get_tree()
