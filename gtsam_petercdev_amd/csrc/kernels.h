@@ -146,6 +146,9 @@ void launch_assemble_h_group(const DevProblem& P, const DevSymbolic& S, const in
 // star variables in bundles (first position in vars, count) of one shape and <= 64 factors: a wave per bundle
 void launch_assemble_h_star_bundles(const DevProblem& P, const DevSymbolic& S, const int* vars, const int2* bundles,
                                     int count, const double* jac, double* H, hipStream_t st);
+// the diagonal-panel variables and the star bundles in one launch (they write different panels)
+void launch_assemble_h_diag_star(const DevProblem& P, const DevSymbolic& S, const int* dvars, int dcount, const int* svars,
+                                 const int2* bundles, int scount, const double* jac, double* H, hipStream_t st);
 void launch_hessian_diag(const DevProblem& P, const DevSymbolic& S, const double* H, double* diag, hipStream_t st);
 void launch_make_damping(int n, const double* hdiag, int diagonal, double mind, double maxd, double* damp,
                          hipStream_t st);

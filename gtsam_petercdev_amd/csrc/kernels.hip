@@ -222,9 +222,18 @@ __device__ inline void local_coords(int type, int dim, const double* x, const do
 // linearize: one thread per factor (register-resident [A b], whitening fused)
 // ---------------------------------------------------------------------------------------------
 // GeneralSFMFactor::linearize — gtsam/slam/GeneralSFMFactor.h:141-177
+// (defined below) priors and other rare factors ride in the first blocks of the launch of a main factor family
+// (launch_linearize): a launch of their own is pure latency — 22 us for the 1 723 camera priors of BAL-1723
+__device__ __forceinline__ void linearize_generic_body(const DevProblem& P, const int* list, int n, const double* values,
+                                                       double* jac, int bid);
 __global__ void __launch_bounds__(256) linearize_sfm_kernel(DevProblem P, const int* list, int n, const double* values,
-                                                            double* jac, DevStatus* status) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+                                                            double* jac, DevStatus* status, const int* glist, int gn) {
+  const int gb = (gn + 255) >> 8;
+  if ((int)blockIdx.x < gb) {
+    linearize_generic_body(P, glist, gn, values, jac, blockIdx.x);
+    return;
+  }
+  const int i = ((int)blockIdx.x - gb) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int f = list[i];
   const int kp = P.f_key_ptr[f];
@@ -323,8 +332,14 @@ __global__ void __launch_bounds__(256) linearize_projection_kernel(DevProblem P,
 
 // BetweenFactor<Pose2> via NoiseModelFactor::linearize — gtsam/nonlinear/NonlinearFactor.cpp:152-184
 __global__ void __launch_bounds__(256) linearize_between_pose2_kernel(DevProblem P, const int* list, int n,
-                                                                      const double* values, double* jac) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+                                                                      const double* values, double* jac, const int* glist,
+                                                                      int gn) {
+  const int gb = (gn + 255) >> 8;
+  if ((int)blockIdx.x < gb) {
+    linearize_generic_body(P, glist, gn, values, jac, blockIdx.x);
+    return;
+  }
+  const int i = ((int)blockIdx.x - gb) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int f = list[i];
   const int kp = P.f_key_ptr[f];
@@ -346,8 +361,14 @@ __global__ void __launch_bounds__(256) linearize_between_pose2_kernel(DevProblem
 }
 
 __global__ void __launch_bounds__(256) linearize_between_pose3_kernel(DevProblem P, const int* list, int n,
-                                                                      const double* values, double* jac) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+                                                                      const double* values, double* jac, const int* glist,
+                                                                      int gn) {
+  const int gb = (gn + 255) >> 8;
+  if ((int)blockIdx.x < gb) {
+    linearize_generic_body(P, glist, gn, values, jac, blockIdx.x);
+    return;
+  }
+  const int i = ((int)blockIdx.x - gb) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int f = list[i];
   const int kp = P.f_key_ptr[f];
@@ -371,8 +392,9 @@ __global__ void __launch_bounds__(256) linearize_between_pose3_kernel(DevProblem
 }
 
 // priors of every type and BetweenFactor on vector spaces: rare, runtime dims, built in place
-__global__ void linearize_generic_kernel(DevProblem P, const int* list, int n, const double* values, double* jac) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void linearize_generic_body(const DevProblem& P, const int* list, int n, const double* values,
+                                                       double* jac, int bid) {
+  const int i = bid * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int f = list[i];
   const int kp = P.f_key_ptr[f];
@@ -400,18 +422,34 @@ __global__ void linearize_generic_kernel(DevProblem P, const int* list, int n, c
     whiten_inplace(J, m, 2 * m + 1, P.f_noise_kind[f], P.noise + P.f_noise_off[f]);
   }
 }
+__global__ void linearize_generic_kernel(DevProblem P, const int* list, int n, const double* values, double* jac) {
+  linearize_generic_body(P, list, n, values, jac, blockIdx.x);
+}
 
 void launch_linearize(const DevProblem& P, const int* const type_lists[6], const int type_counts[6],
                       const double* values, double* jac, DevStatus* status, hipStream_t st) {
   auto grid = [](int n) { return dim3((n + 255) / 256); };
-  if (type_counts[0])
-    linearize_sfm_kernel<<<grid(type_counts[0]), 256, 0, st>>>(P, type_lists[0], type_counts[0], values, jac, status);
-  if (type_counts[1])
-    linearize_between_pose2_kernel<<<grid(type_counts[1]), 256, 0, st>>>(P, type_lists[1], type_counts[1], values, jac);
-  if (type_counts[2])
-    linearize_between_pose3_kernel<<<grid(type_counts[2]), 256, 0, st>>>(P, type_lists[2], type_counts[2], values, jac);
-  if (type_counts[3])
-    linearize_generic_kernel<<<grid(type_counts[3]), 256, 0, st>>>(P, type_lists[3], type_counts[3], values, jac);
+  // the generic family (priors, vector-space factors: few) rides in the first blocks of the first main family's launch
+  const int* glist = type_lists[3];
+  int gn = type_counts[3];
+  auto take = [&](int n) {  // blocks of a main launch: its own + the generic ones, handed out once
+    const int g = gn;
+    gn = 0;
+    return std::make_pair(dim3((n + 255) / 256 + (g + 255) / 256), g);
+  };
+  if (type_counts[0]) {
+    const auto gg = take(type_counts[0]);
+    linearize_sfm_kernel<<<gg.first, 256, 0, st>>>(P, type_lists[0], type_counts[0], values, jac, status, glist, gg.second);
+  }
+  if (type_counts[1]) {
+    const auto gg = take(type_counts[1]);
+    linearize_between_pose2_kernel<<<gg.first, 256, 0, st>>>(P, type_lists[1], type_counts[1], values, jac, glist, gg.second);
+  }
+  if (type_counts[2]) {
+    const auto gg = take(type_counts[2]);
+    linearize_between_pose3_kernel<<<gg.first, 256, 0, st>>>(P, type_lists[2], type_counts[2], values, jac, glist, gg.second);
+  }
+  if (gn) linearize_generic_kernel<<<grid(gn), 256, 0, st>>>(P, glist, gn, values, jac);
   if (type_counts[4])
     linearize_projection_kernel<<<grid(type_counts[4]), 256, 0, st>>>(P, type_lists[4], type_counts[4], values, jac);
   if (type_counts[5])
@@ -839,10 +877,10 @@ __global__ void assemble_h_global_kernel(DevProblem P, DevSymbolic S, const int*
 // factor row k being BOTH the A and the B operand of the instruction (A[i][k] and B[k][j] share the lane layout).  Loads
 // of kU steps are issued before their products.  The four partial 16 x 16 tiles are added in wave order: deterministic.
 // (Reference: JacobianFactor::updateHessian, gtsam/linear/JacobianFactor.cpp:586-624.)
-__global__ void __launch_bounds__(256) assemble_h_diag_kernel(DevProblem P, DevSymbolic S, const int* vars, const double* jac,
-                                                              double* H) {
+__device__ __forceinline__ void assemble_h_diag_body(const DevProblem& P, const DevSymbolic& S, const int* vars,
+                                                     const double* jac, double* H, int bid) {
   __shared__ double red[4][256];
-  const int v = vars[blockIdx.x];
+  const int v = vars[bid];
   const int d = P.var_dim[v], rows = d + 1;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int li = lane & 15, lk = lane >> 4;
@@ -918,6 +956,10 @@ __global__ void __launch_bounds__(256) assemble_h_diag_kernel(DevProblem P, DevS
     const int i = e >> 4, j = e & 15;  // entry (i, j) of X'X: i = row of the panel (d = the rhs row), j = column
     if (i <= d && j < d) out[i + j * rows] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
   }
+}
+__global__ void __launch_bounds__(256) assemble_h_diag_kernel(DevProblem P, DevSymbolic S, const int* vars, const double* jac,
+                                                              double* H) {
+  assemble_h_diag_body(P, S, vars, jac, H, blockIdx.x);
 }
 
 // "Star" variables: every factor of the variable is a binary factor with a LATER-eliminated partner and all factors
@@ -1010,11 +1052,11 @@ __global__ void __launch_bounds__(256) assemble_h_star_kernel(DevProblem P, DevS
 // all its partner-block entries flat over the lanes.  Entry for entry the arithmetic is that of the one-variable
 // kernel (which gsx_relinearize_partial keeps using on its filtered lists): same bits.
 constexpr int kStarVars = 5;  // kStarVars * (d*d + d) own entries must fit a wave (d = 3: 60 lanes)
-__global__ void __launch_bounds__(256) assemble_h_star_bundle_kernel(DevProblem P, DevSymbolic S, const int* vars,
-                                                                    const int2* bundles, int count, const double* jac,
-                                                                    double* H) {
+__device__ __forceinline__ void assemble_h_star_bundle_body(const DevProblem& P, const DevSymbolic& S, const int* vars,
+                                                            const int2* bundles, int count, const double* jac, double* H,
+                                                            int bid) {
   const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int w = __builtin_amdgcn_readfirstlane(bid * 4 + (threadIdx.x >> 6));
   if (w >= count) return;
   const int2 bd = bundles[w];  // first variable (position in vars), number of variables
   const int nv = bd.y;
@@ -1122,9 +1164,27 @@ __global__ void __launch_bounds__(256) assemble_h_star_bundle_kernel(DevProblem 
     if (on) H[hoff + odst] = own;
   }
 }
+__global__ void __launch_bounds__(256) assemble_h_star_bundle_kernel(DevProblem P, DevSymbolic S, const int* vars,
+                                                                    const int2* bundles, int count, const double* jac,
+                                                                    double* H) {
+  assemble_h_star_bundle_body(P, S, vars, bundles, count, jac, H, blockIdx.x);
+}
+// Both in ONE launch: the diagonal-panel variables (the cameras: a workgroup each, far fewer than the GPU holds) go
+// first and run beside the star bundles (the landmarks) instead of before them — the two kernels write different panels
+// and each is bound by its own chain of dependent loads, not by a resource the other needs.
+__global__ void __launch_bounds__(256) assemble_h_diag_star_kernel(DevProblem P, DevSymbolic S, const int* dvars, int dcount,
+                                                                  const int* svars, const int2* bundles, int scount,
+                                                                  const double* jac, double* H) {
+  if ((int)blockIdx.x < dcount) assemble_h_diag_body(P, S, dvars, jac, H, blockIdx.x);
+  else assemble_h_star_bundle_body(P, S, svars, bundles, scount, jac, H, (int)blockIdx.x - dcount);
+}
 void launch_assemble_h_star_bundles(const DevProblem& P, const DevSymbolic& S, const int* vars, const int2* bundles,
                                     int count, const double* jac, double* H, hipStream_t st) {
   if (count) assemble_h_star_bundle_kernel<<<(count + 3) / 4, 256, 0, st>>>(P, S, vars, bundles, count, jac, H);
+}
+void launch_assemble_h_diag_star(const DevProblem& P, const DevSymbolic& S, const int* dvars, int dcount, const int* svars,
+                                 const int2* bundles, int scount, const double* jac, double* H, hipStream_t st) {
+  assemble_h_diag_star_kernel<<<dcount + (scount + 3) / 4, 256, 0, st>>>(P, S, dvars, dcount, svars, bundles, scount, jac, H);
 }
 
 static int g_max_lds = -1;

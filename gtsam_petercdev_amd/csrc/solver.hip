@@ -842,7 +842,18 @@ void dev_linearize(gsx_context* c) {
 
 void dev_assemble_h(gsx_context* c) {
   timer_begin(c, PH_ASSEMBLE_H);
+  // the star bundles (landmarks) and the diagonal-panel variables (cameras) share one launch when both exist
+  const gsx_context::HGroup *gs = nullptr, *gd = nullptr;
   for (const auto& g : c->hgroups) {
+    if (g.threads == -1 && c->n_star_bundles) gs = &g;
+    if (g.threads == 0 && g.count > 0) gd = &g;
+  }
+  const bool fused = gs && gd;
+  if (fused)
+    launch_assemble_h_diag_star(c->DP, c->DS, c->d_hvars.p + gd->begin, gd->count, c->d_hvars.p + gs->begin,
+                                c->d_star_bundles.p, c->n_star_bundles, c->d_jac.p, c->d_H.p, c->stream);
+  for (const auto& g : c->hgroups) {
+    if (fused && (&g == gs || &g == gd)) continue;
     if (g.threads == -1 && c->n_star_bundles) {  // the whole star group, a wave per bundle of variables
       launch_assemble_h_star_bundles(c->DP, c->DS, c->d_hvars.p + g.begin, c->d_star_bundles.p, c->n_star_bundles,
                                      c->d_jac.p, c->d_H.p, c->stream);
