@@ -562,6 +562,15 @@ __global__ void __launch_bounds__(256) reduce_final_kernel(const double* partial
   if (threadIdx.x == 0) scalars[slot] = s;
 }
 
+// two interleaved partial sums (stride 2), a block each, into two consecutive scalar slots: the same additions in the
+// same order as two launches of the kernel above
+__global__ void __launch_bounds__(256) reduce_final_pair_kernel(const double* partials, int n, double* scalars, int slot0) {
+  double acc = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) acc += partials[(size_t)i * 2 + blockIdx.x];
+  const double s = block_sum(acc);
+  if (threadIdx.x == 0) scalars[slot0 + blockIdx.x] = s;
+}
+
 void launch_error(const DevProblem& P, const double* values, double* partials, int cap, double* scalars, int slot,
                   hipStream_t st) {
   int nb = (P.n_active + 255) / 256;
@@ -702,8 +711,8 @@ void launch_linear_error(const DevProblem& P, const double* jac, const double* d
     nb = nb < 1 ? 1 : (nb > cap / 2 ? cap / 2 : nb);
     linear_error_kernel<<<nb, 256, 0, st>>>(P, jac, delta, partials);
   }
-  reduce_final_kernel<<<1, 256, 0, st>>>(partials, nb, 2, scalars, SC_LIN0);
-  reduce_final_kernel<<<1, 256, 0, st>>>(partials + 1, nb, 2, scalars, SC_LIND);
+  static_assert(SC_LIND == SC_LIN0 + 1, "the two linearized errors are reduced by one launch, a block each");
+  reduce_final_pair_kernel<<<2, 256, 0, st>>>(partials, nb, scalars, SC_LIN0);
 }
 
 // ---------------------------------------------------------------------------------------------
