@@ -622,13 +622,13 @@ gsx_status upload_symbolic(gsx_context* c) {
     while (i < le) {
       const int F0 = S.F[S.sched[i]], n0 = std::max(S.N[S.sched[i]], 8);
       int j = i, maxp = 0, maxn = 0;
-      // (lean narrow leaves — the landmarks under a blocked camera front: panel only, no Schur complement to form — of any
-      //  height go in ONE launch of one-wave workgroups: four launches by panel height took 178 us on BAL-1723, one takes
-      //  155; the others keep the 1.5x rule and their thread classes — the outer product of a stored complement wants a
-      //  thread per row, and the Pose2 leaves got slower in one launch)
-      const bool narrow = F0 <= 4 && S.lean[S.sched[i]];
-      while (j < le && S.F[S.sched[j]] == F0 &&
-             (narrow ? (bool)S.lean[S.sched[j]] : (S.N[S.sched[j]] * 2 <= n0 * 3 && !(F0 <= 4 && S.lean[S.sched[j]])))) {
+      // (when every leaf of this width is lean and narrow — the landmarks under blocked camera fronts: panel only, no
+      //  Schur complement to form — they go in ONE launch of one-wave workgroups whatever their height: four launches by
+      //  panel height took 178 us on BAL-1723, one takes 155.  Otherwise the 1.5x rule and the thread classes: the outer
+      //  product of a stored complement wants a thread per row, and the Pose2 leaves got slower in one launch.)
+      bool narrow = F0 <= 4;
+      for (int k = i; narrow && k < le && S.F[S.sched[k]] == F0; ++k) narrow = S.lean[S.sched[k]] != 0;
+      while (j < le && S.F[S.sched[j]] == F0 && (narrow || S.N[S.sched[j]] * 2 <= n0 * 3)) {
         maxp = std::max(maxp, S.N[S.sched[j]] * S.F[S.sched[j]]);
         maxn = std::max(maxn, S.N[S.sched[j]]);
         ++j;
