@@ -617,7 +617,7 @@ gsx_status upload_symbolic(gsx_context* c) {
   for (int l = 0; l < S.n_levels; ++l) {
     int i = S.lvl_ptr[l];
     for (int k = i; k < S.lvl_leaf_end[l]; ++k) c->leaf_max_F[l] = std::max(c->leaf_max_F[l], S.F[S.sched[k]]);
-    // leaf-kernel fronts: sorted by (F, N); a launch = same F, panel size within 1.5x (or any size: below)
+    // leaf-kernel fronts: sorted by (F, N); a launch = same F, panel size within 1.5x — or more, see below
     const int le = S.lvl_leaf_end[l];
     while (i < le) {
       const int F0 = S.F[S.sched[i]], n0 = std::max(S.N[S.sched[i]], 8);
@@ -628,13 +628,18 @@ gsx_status upload_symbolic(gsx_context* c) {
       //  product of a stored complement wants a thread per row, and the Pose2 leaves got slower in one launch.)
       bool narrow = F0 <= 4;
       for (int k = i; narrow && k < le && S.F[S.sched[k]] == F0; ++k) narrow = S.lean[S.sched[k]] != 0;
-      while (j < le && S.F[S.sched[j]] == F0 && (narrow || S.N[S.sched[j]] * 2 <= n0 * 3)) {
+      // (few leaves — every level of a pose graph: ONE launch whatever their width and height, with the thread class of
+      //  the tallest; the launches by (F, height) were each bound by the latency of one leaf: pose2_100k 11 x 18 us ->
+      //  38 us, pose3_100k 4 x 21 -> 30)
+      const bool all = !narrow && (le - S.lvl_ptr[l]) <= 16384;
+      while (j < le && (all || (S.F[S.sched[j]] == F0 && (narrow || S.N[S.sched[j]] * 2 <= n0 * 3)))) {
         maxp = std::max(maxp, S.N[S.sched[j]] * S.F[S.sched[j]]);
         maxn = std::max(maxn, S.N[S.sched[j]]);
         ++j;
       }
       // (the outer product of a stored complement runs a thread per trailing row: never fewer threads than n - F)
-      const int rows_below = maxn - F0;
+      int rows_below = 0;
+      for (int k = i; k < j; ++k) rows_below = std::max(rows_below, S.N[S.sched[k]] - S.F[S.sched[k]]);
       c->leaf_launch[l].push_back({i, j - i, maxn, narrow ? 64 : (maxn <= 72 && rows_below <= 64 ? 64 : (maxn <= 110 ? 128 : 256)), maxp});
       i = j;
     }
