@@ -7,9 +7,11 @@ Cholesky -> back-substitution -> 2 linear errors -> retract -> nonlinear error. 
 committed, so every step does identical work on data already resident in HBM.
 
   N = 1   workload = BAL Ladybug-1723 shape (1 723 cameras / 156 502 points / 678 718 observations,
-          seeded synthetic: 70 % ring-local + 30 % half-lap revisit co-visibility), Schur ordering with
-          multilevel nested dissection of the camera graph (BASELINE config 3: "LM + METIS ordering").
-  N > 1   one process per GPU (torch.distributed, backend nccl = RCCL over xGMI): the ranks solve ONE
+          seeded synthetic: 70 % ring-local + 30 % half-lap revisit co-visibility); ordering: see `--ordering`
+          (BASELINE config 3: "LM + METIS ordering" — `--ordering metis` feeds the reference's own METIS result).
+          The line also carries `secondary`: pose3_100k ms/step on this one GPU — the N=1 anchor of the N>1 curve.
+  N > 1   `python bench.py --gpus N` starts its own N ranks (torch.distributed.run) when it was not started
+          under torchrun.  One process per GPU (torch.distributed, backend nccl = RCCL over xGMI): the ranks solve ONE
           100 000-pose Pose3 graph together ("100k-pose g2o @1/2/4/8", BASELINE's metric) — gsx_set_shard:
           subtrees of the Bayes tree dealt to the ranks, one all-reduce of the top ("cap") fronts per
           factorization; "scaling": "strong".  `--replicas` runs N independent seeded replicas of the N=1
@@ -43,7 +45,19 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=None, choices=["bal1723", "bal49", "pose3_100k", "pose2_100k"],
                     help="default: bal1723 on one GPU (and for --replicas), pose3_100k for the sharded N > 1 run")
-    ap.add_argument("--ordering", default=None, choices=[None, "schur", "schur_nd", "mindegree", "nd"])
+    ap.add_argument("--ordering", default=None, choices=[None, "schur", "schur_nd", "mindegree", "nd", "metis"],
+                    help="the library's own orderings, or 'metis' = the order the REFERENCE's METIS_NodeND returns for this "
+                         "seeded problem through Ordering::Metis (BASELINE config 3: 'LM + METIS ordering'), read from the "
+                         "committed fixture tests/golden/metis_perm_<workload>_seed42.npy and handed over through "
+                         "gsx_set_ordering exactly as GTSAM hands its params.ordering")
+    ap.add_argument("--ordering-file", default=None, metavar="NPY",
+                    help="elimination order from a file: int32 positions into the ascending-key variable table, or uint64 keys")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only the launch plumbing: rendezvous, barrier, MAX over ranks, rank 0's line — no GPU work "
+                         "(tests/test_distributed_gloo.py runs `bench.py --gpus 2 --backend gloo --launch-check` on CPU)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="N=1: skip the pose-graph anchor (pose3_100k ms/step, the N=1 point of the sharded curve) that is "
+                         "measured after the headline workload's timed region")
     ap.add_argument("--lam", type=float, default=1e-5)
     ap.add_argument("--amalgamation", default=None, metavar="RELAX,MAXF",
                     help="relaxed clique amalgamation (gsx_set_amalgamation); default: the library's own choice "
@@ -82,11 +96,49 @@ def make_problem(name, seed):
     return datasets.synth_manhattan_pose2(100000, seed=seed), "nd"
 
 
-def front_split(be, arrays, small_max_n=140, leaf_max_f=16, tile=32, leaf_max_panel=8192):
+def load_ordering(arrays, workload, path=None):
+    """Keys in elimination order from a fixture (int32 positions into the ascending-key variable table, or keys)."""
+    if path is None:
+        path = os.path.join(ROOT, "tests", "golden", f"metis_perm_{workload}_seed42.npy")
+    a = np.load(path)
+    if a.dtype == np.uint64:
+        return a
+    return arrays.var_keys[a.astype(np.int64)]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no torchrun environment: start the N ranks as a child job
+    (python -m torch.distributed.run, one rank per GPU) BEFORE anything in this process touches the GPU, relay rank 0's
+    JSON line, exit with the child's code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    line = None
+    for l in proc.stdout:
+        if l.startswith("{"):
+            line = l.strip()
+        else:
+            sys.stderr.write(l)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    sys.exit(rc if rc != 0 or line is not None else 1)
+
+
+def front_split(be, arrays, small_max_n=140, leaf_max_f=16, tile=32, leaf_max_panel=8192, mine=None, force_big=None):
     """Algorithmic bytes / flops of the factorization split by kernel class (the class rules mirror
     csrc/symbolic.cpp).  A materialised front moves 8 n^2 bytes; a LEAN leaf (childless, f <= 16, big parent) is the
     "fused landmark elimination" of §8(d): its Schur complement never exists, so it moves its H panel in and its L
-    panel out (16 n f bytes) and the parent's gather reads that L panel once more."""
+    panel out (16 n f bytes) and the parent's gather reads that L panel once more.
+    mine / force_big (bool per front): a sharded rank's share — only the fronts of its own subtrees and the cap
+    (which every rank factors, in the blocked class) are counted."""
     parent, fronts = be.get_tree()
     dims = arrays.var_dims
     nfr = len(fronts)
@@ -103,13 +155,18 @@ def front_split(be, arrays, small_max_n=140, leaf_max_f=16, tile=32, leaf_max_pa
     for k in ("leaf", "small", "big"):
         out.update({k + "_bytes": 0.0, k + "_flops": 0.0, "n_" + k: 0})
     lean = np.zeros(nfr, bool)
+    big = N > small_max_n
+    if force_big is not None:
+        big = big | force_big
     for i in range(nfr):
         f, s1, n = F[i], S1[i], N[i]
         p = parent[i]
-        lean[i] = (not has_child[i] and 0 < f <= leaf_max_f and p >= 0 and N[p] > small_max_n and n * f <= leaf_max_panel
-                   and sep_ok[i])
+        lean[i] = (not has_child[i] and 0 < f <= leaf_max_f and p >= 0 and big[p] and n * f <= leaf_max_panel
+                   and sep_ok[i] and not big[i])
+        if mine is not None and not mine[i]:
+            continue
         fl = f ** 3 / 3 + f * f * s1 + f * s1 * s1
-        k = "leaf" if lean[i] else ("big" if n > small_max_n else ("leaf" if (not has_child[i] and f <= leaf_max_f) else "small"))
+        k = "leaf" if lean[i] else ("big" if big[i] else ("leaf" if (not has_child[i] and f <= leaf_max_f) else "small"))
         out[k + "_bytes"] += 16.0 * n * f if lean[i] else 8.0 * n * n
         out[k + "_flops"] += fl
         out["n_" + k] += 1
@@ -128,7 +185,9 @@ def front_split(be, arrays, small_max_n=140, leaf_max_f=16, tile=32, leaf_max_pa
                 c0 += w
             out["gather_bytes"] += 2 * 8.0 * n * (n + 1) / 2          # destination lower triangle read + written once
     for i, p in enumerate(parent):
-        if p >= 0 and N[p] > small_max_n:  # what the big parent's gather reads of this child, once
+        if mine is not None and not mine[i]:
+            continue
+        if p >= 0 and big[p]:  # what the big parent's gather reads of this child, once
             out["gather_bytes"] += 8.0 * N[i] * F[i] if lean[i] else 8.0 * S1[i] * (S1[i] + 1) / 2
     return out
 
@@ -197,13 +256,103 @@ def run_shard_child(world, workload, backend, timeout_s):
             "phases_ms": d["phases_ms"], "wall_s": time.perf_counter() - t0}
 
 
+def cpu_baseline(arrays, ordering, lam, workload, threads, iters):
+    """The oracle ("port": a CPU restatement of the reference algorithm; GTSAM itself cannot be built here) on a bounded
+    sample of the same workload, on this box's host cores — with the two loops the reference runs on TBB threaded (factors
+    in linearize, independent subtrees in elimination / back-substitution), and single-threaded beside it.  A reported
+    baseline, not the target.  The ONLY place bench.py touches oracle/."""
+    from oracle import oracle as orc
+
+    def cpu_run(nthreads, n):
+        ob = orc.oracle_backend(arrays)
+        ob.set_threads(nthreads)
+        ob.set_ordering(ordering)
+        ob.linearize()                       # (first touch of the allocator's arenas: not timed)
+        ob.solve(lam, False, want_delta=False)
+        ob.reset_timing()
+        t_cpu = time.perf_counter()
+        for _ in range(n):
+            ob.linearize()
+            ob.solve(lam, False, want_delta=False)
+            ob.linear_error()
+            ob.retract(None, commit=False)
+        cpu_s = time.perf_counter() - t_cpu
+        tm, _ = ob.timing()
+        ob.close()
+        return {"value": n / cpu_s, "ms_per_step": 1e3 * cpu_s / n,
+                "ms_per_linear_solve": 1e3 * (tm["damp"] + tm["symbolic"] + tm["eliminate"] + tm["backsub"]) / n,
+                "phases_s": {k: v / n for k, v in tm.items()}}
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    cores = max(1, min(threads, os.cpu_count() or 1))
+    multi = cpu_run(cores, iters)
+    single = cpu_run(1, max(1, iters - 1))
+    return dict(
+        multi, unit="LM iterations/s", cores=cores, kind="port",
+        sample=f"{iters} identical LM inner iterations (linearize + damped multifrontal solve + 2 linear errors "
+               f"+ retract + error) of the same {workload} problem and ordering, after one untimed iteration; "
+               f"{cores} host threads on the loops the reference threads with TBB",
+        cpu_model=cpu_model, host_cpus=os.cpu_count(), single_thread=dict(single, cores=1))
+
+
+def anchor_ms_per_step(workload, ordering_name, device, lam, steps=20, warmup=3):
+    """ms per LM inner iteration of `workload` on ONE GPU (a fresh handle, same step as the headline): the N=1 point of
+    the sharded pose-graph curve, measured in the driver's own N=1 run."""
+    from gtsam_petercdev_amd import _abi as A, _lib
+    arrays, default_order = make_problem(workload, 42)
+    be = _lib.product_backend(arrays, device=device)
+    name = ordering_name or default_order
+    if name == "metis":
+        ordering = load_ordering(arrays, workload)
+    else:
+        ordering = be.compute_ordering({"schur": A.ORDER_SCHUR, "schur_nd": A.ORDER_SCHUR_ND,
+                                        "mindegree": A.ORDER_MINDEGREE, "nd": A.ORDER_ND}[name])
+    be.set_ordering(ordering)
+    be.set_profiling(-1)
+    for _ in range(warmup):
+        be.lm_trial(True, lam, False)
+    be.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        be.lm_trial(True, lam, False)
+    be.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    st = be.stats()
+    out = {"workload": workload, "ordering": name, "ms_per_step": ms, "lm_iterations_per_sec": 1e3 / ms, "steps": steps,
+           "n_fronts": st["n_fronts"], "n_levels": st["n_levels"], "factor_flops": st["factor_flops"],
+           "amalgamation": {"relax": st["amalgamation_relax"], "max_frontal_dim": int(st["amalgamation_max_frontal_dim"])}}
+    be.close()
+    return out
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)   # (does not return)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     from gtsam_petercdev_amd import _abi as A, _lib, distributed as D
+    if args.launch_check:
+        dist = D.init(args.backend, None)
+        t0 = time.perf_counter()
+        time.sleep(0.02 * (rank + 1))
+        if dist is not None:
+            dist.barrier()
+        value, ms_step = D.aggregate_throughput(dist, args.steps, time.perf_counter() - t0)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "gpus_arg": args.gpus, "value": value,
+                              "ms_per_step": ms_step, "steps": args.steps}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     dist = None
     ndev = max(torch.cuda.device_count(), 1)
     device = local_rank % ndev  # == local_rank on a node with one GPU per rank
@@ -235,10 +384,18 @@ def main():
             exchange["calls"] += 1
             exchange["doubles"] += count
         be.set_shard(shard_rank, shard_world, allreduce)
-    okind = {"schur": A.ORDER_SCHUR, "schur_nd": A.ORDER_SCHUR_ND, "mindegree": A.ORDER_MINDEGREE,
-             "nd": A.ORDER_ND}[args.ordering or default_order]
+    ordering_name = args.ordering or default_order
     t0 = time.time()
-    ordering = be.compute_ordering(okind)
+    if args.ordering_file is not None or ordering_name == "metis":
+        # an ordering computed by the caller and handed over through gsx_set_ordering — what GTSAM does with
+        # params.ordering; the committed METIS fixtures are for the seed-42 problems
+        ordering = load_ordering(arrays, args.workload, args.ordering_file)
+        ordering_name = "file:" + os.path.basename(args.ordering_file) if args.ordering_file else \
+            "metis (the reference's METIS_NodeND through Ordering::Metis, committed fixture)"
+    else:
+        okind = {"schur": A.ORDER_SCHUR, "schur_nd": A.ORDER_SCHUR_ND, "mindegree": A.ORDER_MINDEGREE,
+                 "nd": A.ORDER_ND}[ordering_name]
+        ordering = be.compute_ordering(okind)
     t_order = time.time() - t0
     if args.amalgamation is not None:   # (a new handle's default is the library's own choice)
         a, b = args.amalgamation.split(",")
@@ -310,7 +467,11 @@ def main():
     for _ in range(3):
         step()
     st_prof = be.stats()
-    split = front_split(be, arrays)
+    if sharded:   # this rank's share: its own subtrees + the cap (which every rank factors, in the blocked class)
+        _, f_owner, _ = be.shard_info()
+        split = front_split(be, arrays, mine=(f_owner == shard_rank) | (f_owner < 0), force_big=(f_owner < 0))
+    else:
+        split = front_split(be, arrays)
     nfac = max(st_prof["n_factorize"], 1)
     phases = {k: st_prof[k] / nfac for k in ("ms_linearize", "ms_assemble_hessian", "ms_factorize", "ms_backsolve",
                                              "ms_linear_error", "ms_retract", "ms_error")}
@@ -356,7 +517,7 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
         "scaling": "strong" if (sharded and world > 1) else "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": args.workload, "shape": arrays.meta, "ordering": args.ordering or default_order,
+        "config": {"workload": args.workload, "shape": arrays.meta, "ordering": ordering_name,
                    "amalgamation": {"relax": relax, "max_frontal_dim": relax_maxf,
                                     "chosen_by": "caller" if args.amalgamation is not None else "library"}, "lambda": lam,
                    "replicas": 1 if sharded else world,
@@ -378,55 +539,27 @@ def main():
                             exchange_mb_per_step=8e-6 * exchange_timed["doubles"] / args.steps,
                             exchange_ms_per_step=1e3 * exchange_timed["seconds"] / args.steps,
                             fronts_per_rank=[int((owner == r).sum()) for r in range(info["world"])])
-        # the per-kernel table above holds THIS rank's launches against whole-tree algorithmic amounts: not a roofline
-        out["roofline"] = None
+        # roofline / kernels / front_split above are RANK 0's: its launches against the algorithmic amounts of the
+        # fronts it processes (own subtrees + cap)
+        out["roofline"]["of"] = f"rank {shard_rank} of {shard_world}: own subtree fronts + cap fronts"
     out["config"]["shape"] = {k: (v if not hasattr(v, "tolist") else None) for k, v in arrays.meta.items()
                               if not hasattr(v, "shape")}
 
-    # ---- CPU baseline: the oracle ("port": a CPU restatement of the reference algorithm; GTSAM itself cannot be built
-    #      here) on a bounded sample of the same workload, on this box's host cores — with the two loops the reference
-    #      runs on TBB threaded (factors in linearize, independent subtrees in elimination / back-substitution), and
-    #      single-threaded beside it.  A reported baseline, not the target. ---------
-    if rank == 0 and world == 1 and not sharded and not args.no_cpu_baseline:
-        from oracle import oracle as orc
-
-        def cpu_run(threads, iters):
-            ob = orc.oracle_backend(arrays)
-            ob.set_threads(threads)
-            ob.set_ordering(ordering)
-            ob.linearize()                       # (first touch of the allocator's arenas: not timed)
-            ob.solve(lam, False, want_delta=False)
-            ob.reset_timing()
-            t_cpu = time.perf_counter()
-            for _ in range(iters):
-                ob.linearize()
-                ob.solve(lam, False, want_delta=False)
-                ob.linear_error()
-                ob.retract(None, commit=False)
-            cpu_s = time.perf_counter() - t_cpu
-            tm, _ = ob.timing()
-            return {"value": iters / cpu_s, "ms_per_step": 1e3 * cpu_s / iters,
-                    "ms_per_linear_solve": 1e3 * (tm["damp"] + tm["symbolic"] + tm["eliminate"] + tm["backsub"]) / iters,
-                    "phases_s": {k: v / iters for k, v in tm.items()}}
-        cpu_model = "unknown"
+    # ---- CPU baseline (rank 0; the other ranks of a sharded job wait at the barrier below) ---------
+    if rank == 0 and not args.no_cpu_baseline and args.shard_share <= 1 and (world == 1 or sharded):
+        out["cpu_baseline"] = cpu_baseline(arrays, ordering, lam, args.workload, args.cpu_threads, args.cpu_iters)
+        out["speedup_vs_cpu_port_threads"] = value / out["cpu_baseline"]["value"]
+        out["speedup_vs_cpu_port_1_thread"] = value / out["cpu_baseline"]["single_thread"]["value"]
+    # ---- N=1: the pose-graph anchor (the N=1 point of the curve `--gpus N` measures on pose3_100k) ---------
+    if rank == 0 and world == 1 and not sharded and not args.no_secondary and args.workload == "bal1723":
+        be.close()
         try:
-            for line in open("/proc/cpuinfo"):
-                if line.startswith("model name"):
-                    cpu_model = line.split(":", 1)[1].strip()
-                    break
-        except OSError:
-            pass
-        cores = max(1, min(args.cpu_threads, os.cpu_count() or 1))
-        multi = cpu_run(cores, args.cpu_iters)
-        single = cpu_run(1, max(1, args.cpu_iters - 1))
-        out["cpu_baseline"] = dict(
-            multi, unit="LM iterations/s", cores=cores, kind="port",
-            sample=f"{args.cpu_iters} identical LM inner iterations (linearize + damped multifrontal solve + 2 linear errors "
-                   f"+ retract + error) of the same {args.workload} problem and ordering, after one untimed iteration; "
-                   f"{cores} host threads on the loops the reference threads with TBB",
-            cpu_model=cpu_model, host_cpus=os.cpu_count(), single_thread=dict(single, cores=1))
-        out["speedup_vs_cpu_port_threads"] = value / multi["value"]      # vs the CPU port of the same algorithm on `cores` threads
-        out["speedup_vs_cpu_port_1_thread"] = value / single["value"]
+            out["secondary"] = [anchor_ms_per_step("pose3_100k", None, device, lam),
+                                anchor_ms_per_step("pose3_100k", "metis", device, lam)]
+        except Exception as e:   # noqa: BLE001 — the headline line must come out whatever happens here
+            out["secondary"] = {"error": repr(e)}
+    if dist is not None and sharded:
+        dist.barrier()
     if dist is not None and not sharded and args.shard_extra != "none":
         # the other ranks wait on the host (a key of the rendezvous store), their GPUs idle, while rank 0's child job runs
         from torch.distributed.distributed_c10d import _get_default_store

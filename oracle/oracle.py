@@ -126,3 +126,83 @@ def colamd_ordering(arrays: A.ProblemArrays, cmember=None) -> np.ndarray:
     if rv != 1:
         raise RuntimeError(f"ccolamd failed with return value {rv}")
     return arrays.var_keys[p[:nvars]]
+
+
+# ---- the reference's own METIS 5, compiled from its C sources (oracle/Makefile) ----------------
+REF_METIS_PATH = os.path.join(_HERE, "_ref", "libmetis_ref.so")
+
+
+def have_ref_metis() -> bool:
+    return os.path.exists(REF_METIS_PATH)
+
+
+def metis_index(arrays: A.ProblemArrays):
+    """MetisIndex::augment restated (gtsam/inference/MetisIndex-inl.h:27-82).
+
+    Returns (xadj, adj, int_to_var): vertices are numbered in FIRST-SEEN order while walking the
+    factors in graph order and each factor's keys in the factor's own order (the bimap of
+    :47-57); a vertex's neighbours are the other keys of its factors as a sorted set of those
+    integers (:60-70, std::set<int32_t>); xadj/adj are the CSR arrays METIS takes (:75-81).
+    Like the reference, only vertices that HAVE a neighbour get an xadj entry (the std::map of
+    :29 holds no entry for an isolated key); the reference's own callers never have isolated
+    keys next to others, and neither do ours — that case raises here instead of handing METIS a
+    short array."""
+    nvars = arrays.n_vars
+    fv = np.asarray(arrays.f_vars, dtype=np.int64)
+    ptr = np.asarray(arrays.f_key_ptr, dtype=np.int64)
+    # first-seen numbering
+    _, first_pos = np.unique(fv, return_index=True)          # per variable (ascending index) its first slot
+    seen_vars = fv[np.sort(first_pos)]                       # variables in first-seen order
+    var_to_int = np.full(nvars, -1, np.int64)
+    var_to_int[seen_vars] = np.arange(seen_vars.size)
+    n = int(seen_vars.size)
+    # all ordered pairs (k1, k2), k1 != k2, of every factor
+    sizes = np.diff(ptr)
+    rows, cols = [], []
+    for k in np.unique(sizes):
+        if k < 2:
+            continue
+        sel = np.nonzero(sizes == k)[0]
+        keys = var_to_int[fv[(ptr[sel, None] + np.arange(k)[None, :])]]  # (nsel, k)
+        a = np.repeat(keys, k, axis=1)
+        b = np.tile(keys, (1, k))
+        m = a != b
+        rows.append(a[m])
+        cols.append(b[m])
+    if rows:
+        r = np.concatenate(rows)
+        c = np.concatenate(cols)
+        pairs = np.unique(r * n + c)                          # set semantics, sorted by (vertex, neighbour)
+        r, c = pairs // n, pairs % n
+    else:
+        r = c = np.zeros(0, np.int64)
+    has = np.zeros(n, bool)
+    has[r] = True
+    if n > 1 and not has.all():
+        raise ValueError("MetisIndex: a key without neighbours next to other keys (the reference's CSR is short there)")
+    counts = np.bincount(r, minlength=n)[has] if n else np.zeros(0, np.int64)
+    xadj = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    return xadj, c.astype(np.int32), seen_vars.astype(np.int64)
+
+
+def metis_ordering(arrays: A.ProblemArrays) -> np.ndarray:
+    """Ordering::Metis restated (gtsam/inference/Ordering.cpp:211-251): METIS_NodeND on the
+    MetisIndex CSR with vwgt = options = NULL; result[j] = intToKey(perm[j]).  Calls the
+    reference's METIS from oracle/_ref/libmetis_ref.so.  Returns keys in elimination order."""
+    xadj, adj, int_to_var = metis_index(arrays)
+    n = int(int_to_var.size)
+    if n == 0:
+        return np.zeros(0, np.uint64)
+    if n == 1:
+        return arrays.var_keys[int_to_var[:1]].copy()
+    lib = C.CDLL(REF_METIS_PATH)
+    perm = np.zeros(n, np.int32)
+    iperm = np.zeros(n, np.int32)
+    nv = C.c_int32(n)
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    xadj = np.ascontiguousarray(xadj)
+    adj = np.ascontiguousarray(adj)
+    rv = lib.METIS_NodeND(C.byref(nv), ip(xadj), ip(adj), None, None, ip(perm), ip(iperm))
+    if rv != 1:  # METIS_OK
+        raise RuntimeError(f"METIS_NodeND failed with return value {rv}")
+    return arrays.var_keys[int_to_var[perm]]

@@ -159,3 +159,40 @@ def test_full_size_lm_run_matches_oracle(gpu, oracle, name):
     assert abs(rg["final_error"] - ro["final_error"]) <= 1e-6 * ro["final_error"]
     assert rg["final_error"] < rg["initial_error"]
     assert relerr(gb.get_values(), ob.get_values()) < 1e-6
+
+
+# ---- BASELINE config 3 as written: "LM + METIS ordering" ---------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["bal1723", "pose3_100k", "pose2_100k"])
+def test_reference_metis_ordering_through_the_hip_path(gpu, oracle, golden_dir, name):
+    """The elimination order the REFERENCE's METIS_NodeND returns for the whole graph (Ordering::Metis as
+    SFMExample_bal_COLAMD_METIS.cpp:83-117 / LevenbergMarquardtParams orderingType = METIS use it; the committed fixture
+    tests/golden/metis_perm_*_seed42.npy, made by tests/golden/make_metis_orderings.py with the reference's own METIS)
+    handed over through gsx_set_ordering: damped step within 1e-6 of the oracle, which eliminates the reference's Bayes
+    tree for the same ordering, and the LM run with identical accept/reject decisions and final chi^2 within 1e-6."""
+    import bench
+    arr, _ = bench.make_problem(name, 42)
+    ordering = bench.load_ordering(arr, name)
+    assert np.array_equal(np.sort(ordering), arr.var_keys)
+    gb = gpu.product_backend(arr)
+    ob = oracle.oracle_backend(arr)
+    gb.set_ordering(ordering)
+    ob.set_ordering(ordering)
+    assert np.array_equal(gb.get_ordering(), ordering)     # the order is taken as given (bit-identical by construction)
+    gb.linearize()
+    ob.linearize()
+    for lam, diag in ((1e-5, False), (1e-2, True)):
+        dg = gb.solve(lam, diag)
+        do = ob.solve(lam, diag)
+        assert relerr(dg, do) < 1e-6, (name, lam)
+        e0g, edg = gb.linear_error()
+        e0o, edo = ob.linear_error()
+        assert abs(e0g - e0o) <= 1e-10 * abs(e0o)
+        assert abs(edg - edo) <= 1e-6 * max(abs(edo), 1e-9 * abs(e0o))
+    p = A.lm_params_legacy()
+    p.max_iterations = 4
+    rg, ro = gb.lm_optimize(p), ob.lm_optimize(p)
+    assert rg["iterations"] == ro["iterations"] and rg["inner_iterations"] == ro["inner_iterations"]
+    assert np.array_equal(rg["trace_accepted"], ro["trace_accepted"])
+    assert np.allclose(rg["trace_lambda"], ro["trace_lambda"], rtol=1e-9)
+    assert abs(rg["final_error"] - ro["final_error"]) <= 1e-6 * ro["final_error"]
+    assert relerr(gb.get_values(), ob.get_values()) < 1e-6

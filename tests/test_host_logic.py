@@ -504,6 +504,36 @@ def test_nested_dissection_against_reference_colamd(lib, oracle, workload):
     assert flops <= max_flops and depth <= max_depth, line
 
 
+METIS_BOUNDS = {  # workload -> max ratio of ORDER_ND / ORDER_SCHUR_ND flops to the reference's METIS flops (reference cliques)
+    "pose3_100k": 1.45, "pose2_100k": 1.45, "bal1723": 1.1,
+}
+
+
+@pytest.mark.parametrize("workload", list(METIS_BOUNDS))
+def test_metis_fixture_and_nested_dissection_against_reference_metis(lib, oracle, golden_dir, workload):
+    """The committed METIS orderings (tests/golden/metis_perm_*_seed42.npy) ARE what the reference's own METIS returns
+    through Ordering::Metis for the seeded bench problems (regenerated here when oracle/_ref/libmetis_ref.so exists:
+    variable ordering bit-identical), and the library's nested dissection is printed and bounded against them: flops of
+    the reference's cliques and tree height."""
+    import bench
+    arr, kind = bench.make_problem(workload, 42)
+    keys = bench.load_ordering(arr, workload)
+    assert np.array_equal(np.sort(keys), arr.var_keys)
+    if oracle.have_ref_metis():
+        assert np.array_equal(oracle.metis_ordering(arr), keys), "fixture is not the reference METIS result any more"
+    costs = {}
+    for name in ("metis", kind):
+        be = _lib.ProductBackend(arr, host_only=True)
+        be.set_amalgamation(0.0, 128)
+        be.set_ordering(keys if name == "metis" else be.compute_ordering({"schur_nd": A.ORDER_SCHUR_ND, "nd": A.ORDER_ND}[kind]))
+        costs[name] = _tree_cost(be, arr.var_dims)
+        be.close()
+    line = (f"{workload}: ORDER_{kind.upper()} flops {costs[kind][0]:.4g} height {costs[kind][1]} | reference METIS flops "
+            f"{costs['metis'][0]:.4g} height {costs['metis'][1]} | ratio {costs[kind][0] / costs['metis'][0]:.2f}")
+    print(line)
+    assert costs[kind][0] <= METIS_BOUNDS[workload] * costs["metis"][0], line
+
+
 def test_nested_dissection_is_a_permutation_on_awkward_graphs(lib):
     """Disconnected graphs, stars (matching stalls), a clique (no separator), a path, single vertices."""
     rng = np.random.default_rng(5)

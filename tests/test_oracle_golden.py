@@ -425,6 +425,55 @@ def test_colamd_chain(orc):
     assert orc.colamd_ordering(arrays, cm).tolist() == [0, 1, 3, 2, 4, 5]
 
 
+# ---- gtsam/inference/tests/testOrdering.cpp:240-393 (the reference's own METIS 5, built from its C sources) ----
+def _symbolic(factors):
+    """A SymbolicFactorGraph as a linear graph of 1-dim variables: only the key lists matter."""
+    fg = GaussianFactorGraph()
+    for keys in factors:
+        args = []
+        for k in keys:
+            args += [k, np.eye(1)]
+        fg.add(JacobianFactor(*args, [0.0]))
+    return fg.to_arrays(None)
+
+
+def test_MetisIndex_csr_format_4(orc):
+    """:240-275 — CSR of the x1..x6 chain with a unary factor on x1, then a landmark seen from x1..x4."""
+    chain = [[X(1)], [X(1), X(2)], [X(2), X(3)], [X(3), X(4)], [X(4), X(5)], [X(5), X(6)]]
+    xadj, adj, _ = orc.metis_index(_symbolic(chain))
+    assert xadj.tolist() == [0, 1, 3, 5, 7, 9, 10]
+    assert adj.tolist() == [1, 0, 2, 1, 3, 2, 4, 3, 5, 4]
+    more = chain + [[L(1)], [X(1), L(1)], [X(2), L(1)], [X(3), L(1)], [X(4), L(1)]]
+    xadj, adj, i2v = orc.metis_index(_symbolic(more))
+    # the landmark is vertex 6 (first seen last) although its key sorts before the x's
+    assert xadj.tolist() == [0, 2, 5, 8, 11, 13, 14, 18]
+    assert adj[-4:].tolist() == [0, 1, 2, 3]
+    if orc.have_ref_metis():
+        assert sorted(orc.metis_ordering(_symbolic(more)).tolist()) == sorted([L(1)] + [X(i) for i in range(1, 7)])
+
+
+def test_MetisIndex_metis(orc):
+    """:278-297"""
+    xadj, adj, _ = orc.metis_index(_symbolic([[0], [0, 1], [1, 2]]))
+    assert xadj.tolist() == [0, 1, 3, 4]
+    assert adj.tolist() == [1, 0, 2, 1]
+
+
+def test_metis_chain_and_loop(orc):
+    """:300-336 (the Linux branch) and :375-383 — METIS_NodeND of the reference's own METIS."""
+    if not orc.have_ref_metis():
+        pytest.skip("oracle/_ref/libmetis_ref.so not built (reference tree absent)")
+    chain = [[i, i + 1] for i in range(5)]
+    assert orc.metis_ordering(_symbolic(chain)).tolist() == [5, 3, 4, 1, 0, 2]
+    assert orc.metis_ordering(_symbolic(chain + [[0, 5]])).tolist() == [3, 2, 5, 0, 4, 1]
+
+
+def test_metis_empty_and_single(orc):
+    """:339-360 — an empty graph gives an empty ordering, a single node itself (no METIS call)."""
+    assert orc.metis_ordering(_symbolic([[7]])).tolist() == [7]
+    assert orc.metis_ordering(GaussianFactorGraph().to_arrays(None)).size == 0
+
+
 # ---- tests/testDoglegOptimizer.cpp ---------------------------------------------------------------------
 def test_Dogleg_ComputeBlendEdgeCases(orc):
     """:76-92 (issue #1861) — a trust region equal to |n| returns n, equal to |u| returns u."""
