@@ -20,12 +20,18 @@ def _stale() -> bool:
 
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
+    # GSX_BUILD_DIR: an experiment build (GSX_STAMP / GSX_EXTRA_DEFINES) into a directory of its own, e.g. build/exp_stamp,
+    # leaving the product library alone (tools_exp.sh copies it over on the GPU box)
+    out_dir = os.environ.get("GSX_BUILD_DIR")
+    out = os.path.join(out_dir, "libgsx.so") if out_dir else OUT
+    if out_dir:
+        os.makedirs(out_dir, exist_ok=True)
+    elif not force and not _stale():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     for s in SOURCES:
-        o = os.path.join(CSRC, os.path.splitext(s)[0] + ".o")
+        o = os.path.join(out_dir or CSRC, os.path.splitext(s)[0] + ".o")
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
                "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value", "-c", os.path.join(CSRC, s), "-o", o]
         if os.environ.get("GSX_STAMP") and s.endswith(".hip"):
@@ -42,11 +48,11 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
         objs.append(o)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

@@ -755,13 +755,27 @@ __global__ void __launch_bounds__(kBsThreads) backsolve_big_kernel(DevSymbolic S
 // are a straight-line chain of lane reads with the reciprocals taken beforehand.
 namespace {
 constexpr int kBsSmallF = 32, kBsSmallSep = 144;
-__global__ void __launch_bounds__(256) backsolve_small_kernel(DevSymbolic S, const int* ids, const double* arena,
-                                                              double* delta, DevStatus* status) {
-  __shared__ double xs[kBsSmallSep];
-  __shared__ double tile[kBsSmallF][kBsSmallF + 1];
-  __shared__ double part[2][kBsSmallF];
-  const int f = ids[blockIdx.x];
-  if (wildfire_skip(S, f, threadIdx.x == 0)) return;  // a clique no change reaches
+// COH (the tree kernel below): the parents' solution is read, and this clique's is written, with agent-scope accesses —
+// the value may have been stored a moment ago by a workgroup on another CU / XCD inside the same launch
+template <bool COH>
+__device__ __forceinline__ double delta_load(const double* p) {
+  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void delta_store(double* p, double v) {
+  if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+// LDS pool of one clique (doubles): xs[kBsSmallSep] | part[2][64] | three 32 x 33 tiles
+constexpr int kBsTile = kBsSmallF * (kBsSmallF + 1);
+constexpr int kBsPool = kBsSmallSep + 4 * kBsSmallF + 3 * kBsTile;
+template <bool COH>
+__device__ __forceinline__ void backsolve_small_body(const DevSymbolic& S, const int f, const double* arena, double* delta,
+                                                     DevStatus* status, double* pool) {
+  double* xs = pool;
+  double(*part)[kBsSmallF] = (double(*)[kBsSmallF])(pool + kBsSmallSep);
+  double(*tile)[kBsSmallF + 1] = (double(*)[kBsSmallF + 1])(pool + kBsSmallSep + 4 * kBsSmallF);
   const int n = S.fr_N[f], F = S.fr_F[f], nS = n - 1 - F;
   const double* A = arena + S.fr_off[f];
   const int* gi = S.gidx + S.gidx_ptr[f];
@@ -786,7 +800,7 @@ __global__ void __launch_bounds__(256) backsolve_small_kernel(DevSymbolic S, con
     lv[k] = (cg < F && r0 + rq < nS) ? col[r0] : 0.0;
   }
   const double dv = tid < F ? A[(n - 1) + (i64)tid * n] : 0.0;
-  if (tid < kBsSmallSep) xs[tid] = g >= 0 ? delta[g] : 0.0;
+  if (tid < kBsSmallSep) xs[tid] = g >= 0 ? delta_load<COH>(delta + g) : 0.0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int e = tid + 256 * q;
@@ -813,21 +827,29 @@ __global__ void __launch_bounds__(256) backsolve_small_kernel(DevSymbolic S, con
     yr = lane == c ? xc : (lane < c ? fma(-lc[c], xc, yr) : yr);
   }
   if (lane < F) {
-    delta[gf] = yr;
+    delta_store<COH>(delta + gf, yr);
     if (!isfinite(yr)) atomicAdd(&status->n_nonfinite, 1);
   }
+}
+__global__ void __launch_bounds__(256) backsolve_small_kernel(DevSymbolic S, const int* ids, const double* arena,
+                                                              double* delta, DevStatus* status) {
+  __shared__ double pool[kBsSmallSep + 4 * kBsSmallF + kBsTile];
+  const int f = ids[blockIdx.x];
+  if (wildfire_skip(S, f, threadIdx.x == 0)) return;  // a clique no change reaches
+  backsolve_small_body<false>(S, f, arena, delta, status, pool);
 }
 // The same for 32 < F <= 64 (the unamalgamated nested-dissection leaves of a pose graph run to ~60 frontal scalars): two
 // column blocks.  L21 is read in two passes of 32 columns, the chain solves block 1, takes its part out of block 0's
 // right-hand side through the 32 x 32 off-diagonal tile, and solves block 0.
-__global__ void __launch_bounds__(256) backsolve_small2_kernel(DevSymbolic S, const int* ids, const double* arena,
-                                                               double* delta, DevStatus* status) {
+template <bool COH>
+__device__ __forceinline__ void backsolve_small2_body(const DevSymbolic& S, const int f, const double* arena, double* delta,
+                                                      DevStatus* status, double* pool) {
   constexpr int B = kBsSmallF;
-  __shared__ double xs[kBsSmallSep];
-  __shared__ double t00[B][B + 1], t11[B][B + 1], t10[B][B + 1];   // t10[r][c] = L[32 + r][c]
-  __shared__ double part[2][2 * B];
-  const int f = ids[blockIdx.x];
-  if (wildfire_skip(S, f, threadIdx.x == 0)) return;  // a clique no change reaches
+  double* xs = pool;
+  double(*part)[2 * B] = (double(*)[2 * B])(pool + kBsSmallSep);
+  double(*t00)[B + 1] = (double(*)[B + 1])(pool + kBsSmallSep + 4 * B);
+  double(*t11)[B + 1] = (double(*)[B + 1])(pool + kBsSmallSep + 4 * B + kBsTile);
+  double(*t10)[B + 1] = (double(*)[B + 1])(pool + kBsSmallSep + 4 * B + 2 * kBsTile);   // t10[r][c] = L[32 + r][c]
   const int n = S.fr_N[f], F = S.fr_F[f], nS = n - 1 - F;
   const double* A = arena + S.fr_off[f];
   const int* gi = S.gidx + S.gidx_ptr[f];
@@ -856,7 +878,7 @@ __global__ void __launch_bounds__(256) backsolve_small2_kernel(DevSymbolic S, co
     }
   }
   const double dv = tid < F ? A[(n - 1) + (i64)tid * n] : 0.0;   // (F <= 64: wave 0, lane = column)
-  if (tid < kBsSmallSep) xs[tid] = g >= 0 ? delta[g] : 0.0;
+  if (tid < kBsSmallSep) xs[tid] = g >= 0 ? delta_load<COH>(delta + g) : 0.0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int e = tid + 256 * q;
@@ -908,11 +930,165 @@ __global__ void __launch_bounds__(256) backsolve_small2_kernel(DevSymbolic S, co
     }
   }
   if (lane < F) {
-    delta[gf] = y;
+    delta_store<COH>(delta + gf, y);
     if (!isfinite(y)) atomicAdd(&status->n_nonfinite, 1);
   }
 }
+__global__ void __launch_bounds__(256) backsolve_small2_kernel(DevSymbolic S, const int* ids, const double* arena,
+                                                               double* delta, DevStatus* status) {
+  __shared__ double pool[kBsPool];
+  const int f = ids[blockIdx.x];
+  if (wildfire_skip(S, f, threadIdx.x == 0)) return;  // a clique no change reaches
+  backsolve_small2_body<false>(S, f, arena, delta, status, pool);
+}
+// Any LDS-class clique (F <= kSmallMaxN): the 32-column panel loop of backsolve_kernel (kernels.hip) on the same pool
+template <bool COH>
+__device__ __forceinline__ void backsolve_panels_body(const DevSymbolic& S, const int f, const double* arena, double* delta,
+                                                      DevStatus* status, double* pool) {
+  constexpr int B = kBsSmallF;
+  double* xs = pool;                                   // n - 1 <= kBsSmallSep entries: frontal + separator
+  double* y = pool + kBsSmallSep;                      // B
+  double(*tile)[B + 1] = (double(*)[B + 1])(pool + kBsSmallSep + 4 * B);
+  const int n = S.fr_N[f], F = S.fr_F[f];
+  const double* A = arena + S.fr_off[f];
+  const int* gi = S.gidx + S.gidx_ptr[f];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+  for (int r = F + tid; r < n - 1; r += nt) xs[r] = delta_load<COH>(delta + gi[r]);
+  lds_bar();
+  const int nblk = (F + B - 1) / B;
+  for (int kb = nblk - 1; kb >= 0; --kb) {
+    const int c0 = kb * B, w = min(B, F - c0);
+    double treg[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + q * 256, r = e & 31, c = e >> 5;
+      treg[q] = (r < w && c <= r) ? A[(c0 + r) + (i64)(c0 + c) * n] : (r == c ? 1.0 : 0.0);
+    }
+    for (int c = 2 * wave; c < w; c += 2 * nw) {  // two columns per wave: independent loads and reductions
+      const double* col0 = A + (i64)(c0 + c) * n;
+      const bool two = c + 1 < w;
+      const double* col1 = two ? col0 + n : col0;
+      double acc0 = 0, acc1 = 0;
+      for (int r = c0 + w + lane; r < n - 1; r += 64) {
+        const double x = xs[r];
+        acc0 += col0[r] * x;
+        acc1 += col1[r] * x;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        acc0 += __shfl_down(acc0, o, 64);
+        acc1 += __shfl_down(acc1, o, 64);
+      }
+      if (lane == 0) {
+        y[c] = col0[n - 1] - acc0;
+        if (two) y[c + 1] = col1[n - 1] - acc1;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + q * 256;
+      tile[e & 31][e >> 5] = treg[q];
+    }
+    lds_bar();
+    if (wave == 0) {  // solve tile' x = y backwards; lane r holds y_r
+      double yr = (lane < w) ? y[lane] : 0.0;
+      for (int c = w - 1; c >= 0; --c) {
+        const double xc = __shfl(yr, c, 64) / tile[c][c];
+        if (lane == c) yr = xc;
+        else if (lane < c) yr -= tile[c][lane] * xc;
+      }
+      if (lane < w) xs[c0 + lane] = yr;
+    }
+    lds_bar();
+  }
+  int bad = 0;
+  for (int r = tid; r < F; r += nt) {
+    const double x = xs[r];
+    delta_store<COH>(delta + gi[r], x);
+    if (!isfinite(x)) bad = 1;
+  }
+  if (bad) atomicAdd(&status->n_nonfinite, 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// backsolve_tree: the tree fronts (Symbolic::tree_*) of ALL levels in one launch, top-down (the pre-order of
+// gtsam/linear/linearAlgorithms-inst.h:49-117 without level barriers).  A clique may be solved as soon as its parent is:
+// the workgroup that has solved a clique goes on with its first tree child itself and publishes the others in a ready
+// list; a workgroup without work takes the next TICKET (in order: 0, 1, 2, ...), waits until the list entry of that
+// ticket exists, and solves it.  Tickets below n_roots are the cliques whose parent is not a tree front (solved by the
+// level launches before this kernel); the number of tickets = n_roots + the number of non-first children, known to the
+// host.  Why this cannot hang:
+// tickets are handed out in order to running workgroups only, so every published entry is claimed by a workgroup that is
+// running, and a workgroup that is solving never waits — if all running workgroups waited, every published clique would
+// be solved already and all its children published, i.e. the list would be complete.  (A bounded number of polls guards
+// against a corrupt list all the same: the kernel then gives up and reports a non-finite solution.)
+// Solutions cross workgroups inside the launch: agent-scope stores / loads of delta (COH above), entries and tickets
+// through agent-scope atomics.  An entry carries the launch's epoch, so the list needs no clearing between launches.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) backsolve_tree_kernel(DevSymbolic S, BacksolveTreeArgs Q, const double* arena,
+                                                             double* delta, DevStatus* status) {
+  __shared__ double pool[kBsPool];
+  __shared__ int s_f;
+  const int tid = threadIdx.x;
+  for (;;) {
+    if (tid == 0) {
+      const int t = atomicAdd(Q.head, 1);
+      int f = -1;
+      if (t < Q.n_roots) {
+        f = Q.roots[t];
+      } else if (t < Q.n_tickets) {
+        const unsigned long long want = (unsigned long long)Q.epoch << 32;
+        const unsigned long long* slot = Q.ready + (t - Q.n_roots);
+        int polls = 0;
+        for (;;) {
+          const unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((v >> 32 << 32) == want) {
+            f = (int)(v & 0xffffffffu);
+            break;
+          }
+          if (++polls > (1 << 20)) {  // (~a second: the list is corrupt — give up loudly)
+            atomicAdd(&status->n_nonfinite, 1);
+            f = -2;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(8);
+        }
+      }
+      s_f = f;
+    }
+    __syncthreads();
+    int f = s_f;
+    if (f < 0) return;   // (uniform: the list is exhausted)
+    while (f >= 0) {
+      const int F = S.fr_F[f];
+      if (F <= kBsSmallF) backsolve_small_body<true>(S, f, arena, delta, status, pool);
+      else if (F <= 2 * kBsSmallF) backsolve_small2_body<true>(S, f, arena, delta, status, pool);
+      else backsolve_panels_body<true>(S, f, arena, delta, status, pool);
+      __syncthreads();  // every store of the solution has drained (s_waitcnt vmcnt(0) before the barrier)
+      // the first tree child (the deepest subtree: the host sorted them) is solved by this workgroup right away, the
+      // others are published: one claim of a range of entries, then one entry per lane
+      const int c0 = Q.child_ptr[f], nc = Q.child_ptr[f + 1] - c0;
+      if (nc > 1 && tid < 64) {
+        int base = 0;
+        if (tid == 0) base = atomicAdd(Q.tail, nc - 1);
+        base = __shfl(base, 0, 64);
+        for (int k = 1 + tid; k < nc; k += 64)
+          __hip_atomic_store(Q.ready + base + k - 1, ((unsigned long long)Q.epoch << 32) | (unsigned)Q.children[c0 + k],
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      f = nc > 0 ? Q.children[c0] : -1;
+    }
+  }
+}
 }  // namespace
+
+void launch_backsolve_tree(const DevSymbolic& S, const BacksolveTreeArgs& Q, const double* arena, double* delta,
+                           DevStatus* status, hipStream_t st) {
+  if (Q.n_tickets <= 0) return;
+  const int grid = std::min(Q.n_tickets, 256 * 5);
+  backsolve_tree_kernel<<<grid, 256, 0, st>>>(S, Q, arena, delta, status);
+}
 
 bool backsolve_small_fits(int max_n, int max_F) { return max_F <= 2 * kBsSmallF && max_n <= kSmallMaxN && max_n - 2 <= kBsSmallSep; }
 

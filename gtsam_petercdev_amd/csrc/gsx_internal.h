@@ -66,6 +66,17 @@ struct Symbolic {
   std::vector<int> lvl_small_end;    // level -> end of the small (LDS) fronts inside the level range
   std::vector<int> lvl_leaf_end;     // level 0 only: end of the leaf-kernel fronts (no children, F <= kLeafMaxF)
   int n_levels = 0;
+  // Subtree-fused elimination of the LDS-class fronts (front_tree_kernel): a front is a TREE front when it is LDS-class and
+  // so is its whole subtree (leaf-kernel children aside).  Tree fronts are cut into tiers by the largest front of their
+  // subtree (= the LDS a workgroup needs to climb it); one launch per tier, inside which a workgroup that finishes a front
+  // takes the parent when it was the last child to arrive (ClusterTree-inst.h:219-318 post-order, without level barriers).
+  std::vector<int> tree_bounds;      // tier -> largest n of its fronts
+  std::vector<int> tree_threads;     // tier -> workgroup size (0: the host's default for that n)
+  std::vector<int> tree_tier;        // front -> tier, -1: not a tree front
+  std::vector<int> tree_up;          // front -> parent when that is a tree front of the same tier, else -1
+  std::vector<int> tree_npend;       // front -> children that are tree fronts of the same tier
+  std::vector<int> tree_start;       // per tier (tree_start_ptr): the fronts with tree_npend == 0, in schedule order
+  std::vector<int> tree_start_ptr;
   // deterministic extend-add into BIG parents: one task per destination block (parent var pair),
   // with the list of source blocks (child Schur-complement blocks) in child order
   std::vector<int64_t> gt_dst;       // task -> arena offset of the destination block (top-left entry)

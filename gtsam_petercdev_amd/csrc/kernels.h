@@ -157,6 +157,16 @@ void launch_make_damping(int n, const double* hdiag, int diagonal, double mind, 
 void launch_front_small(const DevProblem& P, const DevSymbolic& S, const int* ids, int count, int max_n,
                         int threads, const double* H, const double* damp, const double* scalars, double* arena,
                         DevStatus* status, hipStream_t st);
+// the LDS-class fronts of one tier, whole subtrees in one launch (kernels.hip: front_tree_kernel)
+struct TreeArgs {
+  const int* start;   // fronts without an unfinished child in the tier
+  int nstart;
+  int* cursor;        // start entries claimed so far (zeroed by launch_begin_factorization)
+  int* pending;       // per front: children of the tier still to arrive (restores itself to npend)
+  const int *up, *npend;
+};
+void launch_front_tree(const DevProblem& P, const DevSymbolic& S, const TreeArgs& T, int max_n, int threads, const double* H,
+                       const double* damp, const double* scalars, double* arena, DevStatus* status, hipStream_t st);
 void launch_big_init(const DevProblem& P, const DevSymbolic& S, const BigDesc* descs, int count, int max_n,
                      int max_nfv, const double* H, const double* damp, const double* scalars, double* arena,
                      hipStream_t st);
@@ -210,6 +220,17 @@ void launch_backsolve_big(const DevSymbolic& S, const int* ids, int count, int m
 bool backsolve_small_fits(int max_n, int max_F);
 void launch_backsolve_small(const DevSymbolic& S, const int* ids, int count, int max_F, const double* arena, double* delta,
                             DevStatus* status, hipStream_t st);
+// the tree fronts of all levels in one launch, top-down (bigfront.hip: backsolve_tree_kernel)
+struct BacksolveTreeArgs {
+  const int* roots;            // tree fronts whose parent is not a tree front
+  int n_roots, n_tickets;      // ... their number; n_tickets = n_roots + the tree fronts that are not a first child
+  const int *child_ptr, *children;   // per front: its tree children (CSR over all fronts), the deepest subtree first
+  unsigned long long* ready;   // n_tickets - n_roots entries: epoch << 32 | front
+  int *head, *tail;            // tickets handed out; entries published (zeroed by the host before the launch)
+  unsigned epoch;              // differs from launch to launch (never 0)
+};
+void launch_backsolve_tree(const DevSymbolic& S, const BacksolveTreeArgs& Q, const double* arena, double* delta,
+                           DevStatus* status, hipStream_t st);
 // ISAM2's partial ("wildfire") back-substitution, the pass after a level's kernels: a dirty clique's new frontal solution
 // is compared with the old one — a change of at least `threshold` in the infinity norm (or a re-eliminated clique) marks
 // its frontal variables as changed, a smaller one is undone (valuesChanged / restoreFromOriginals,
@@ -243,7 +264,8 @@ void launch_marginal_path(const DevSymbolic& S, const int* path, int npath, int 
                           double* out, double* Y, int64_t n_tan, hipStream_t st);
 void launch_joint_cross(const double* Ya, const double* Yb, int64_t n_tan, int dA, int dB, double* out, hipStream_t st);
 void launch_set_scalar(double* scalars, int slot, double v, hipStream_t st);
-void launch_begin_factorization(double* scalars, double lambda, DevStatus* status, hipStream_t st);
+constexpr int kTreeCursors = 8;  // cursors of the tree kernels' start lists, zeroed with the status words
+void launch_begin_factorization(double* scalars, double lambda, DevStatus* status, int* tree_cursors, hipStream_t st);
 // dense unit kernel for gsx_cholesky_partial: in-place lower partial Cholesky of an n x n
 // column-major matrix (lower triangle significant)
 void launch_dense_partial(double* a, int n, int nf, DevStatus* status, hipStream_t st);

@@ -1472,15 +1472,17 @@ void launch_set_scalar(double* scalars, int slot, double v, hipStream_t st) {
 }
 // start of a factorization: lambda + the status words of the factorization / back-substitution in ONE tiny launch
 // (three memset / memcpy nodes cost ~5 us each on the stream; the cheirality count of the last linearize is kept)
-__global__ void begin_factorization_kernel(double* scalars, double lambda, DevStatus* status) {
+__global__ void begin_factorization_kernel(double* scalars, double lambda, DevStatus* status, int* tree_cursors) {
+  if (tree_cursors)
+    for (int k = 0; k < kTreeCursors; ++k) tree_cursors[k] = 0;
   scalars[SC_LAMBDA] = lambda;
   status->n_fail = 0;
   status->first_front = 0x7fffffff;
   status->n_nonfinite = 0;
   status->n_backsub = 0;
 }
-void launch_begin_factorization(double* scalars, double lambda, DevStatus* status, hipStream_t st) {
-  begin_factorization_kernel<<<1, 1, 0, st>>>(scalars, lambda, status);
+void launch_begin_factorization(double* scalars, double lambda, DevStatus* status, int* tree_cursors, hipStream_t st) {
+  begin_factorization_kernel<<<1, 1, 0, st>>>(scalars, lambda, status, tree_cursors);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1774,27 +1776,29 @@ __device__ unsigned long long g_fs_stamp[12];
   {                                                                                   \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                       \
     unsigned long long t__ = wall_clock64();                                          \
-    if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) g_fs_stamp[slot] = t__ - fs0__; \
+    if (threadIdx.x == 0) atomicAdd(&g_fs_stamp[slot], t__ - fs0__);                   \
     fs0__ = t__;                                                                      \
   }
 #else
 #define FS_BEGIN
 #define FS_ADD(slot)
 #endif
-__global__ void __launch_bounds__(512) front_small_kernel(DevProblem P, DevSymbolic S, const int* ids, const double* H, const double* damp,
-                                   const double* scalars, double* arena, DevStatus* status) {
-  extern __shared__ double L[];
+// COH: the children's Schur complements are read, and this front's is written, with agent-scope accesses that go past
+// the (per-XCD, mutually non-coherent) L2s — what front_tree_kernel needs to hand a front from one workgroup to another
+// inside a launch without cache-wide write-back / invalidate fences.
+template <bool COH>
+__device__ __forceinline__ void front_small_body(const DevProblem& P, const DevSymbolic& S, const int f, const double* H,
+                                                 const double* damp, const double lambda, double* arena,
+                                                 DevStatus* status, double* L) {
   __shared__ VarRec vrec[kVarStage];
   __shared__ int vpre[kVarStage + 1];
   __shared__ ChildRec crec[kChildStage];
   FS_BEGIN
-  const int f = ids[blockIdx.x];
   const FrontRec fr = S.front_recs[f];
   const int n = fr.n, F = fr.F;
   const i64 off = fr.off;
   const int tid = threadIdx.x, nt = blockDim.x;
   const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
-  const double lambda = scalars[SC_LAMBDA];
   // A front this small is a chain of dependent memory round trips (more than a microsecond each), not bytes or flops:
   // the records of its variables and children are staged in LDS by one round trip, and every loop below puts all the
   // loads of a lane in flight before the first LDS store that needs one.
@@ -1886,7 +1890,8 @@ __global__ void __launch_bounds__(512) front_small_kernel(DevProblem P, DevSymbo
           if (c + 1 < s1 && (c + 1) * s1 - (c + 1) * c / 2 <= e) ++c;
           if (c * s1 - c * (c - 1) / 2 > e) --c;
           const int r = c + (e - (c * s1 - c * (c - 1) / 2));
-          v[u] = src0[(i64)c * cr.nc + r];
+          if constexpr (COH) v[u] = __hip_atomic_load(&src0[(i64)c * cr.nc + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else v[u] = src0[(i64)c * cr.nc + r];
           dst[u] = cm[r] + cm[c] * n;
         }
       }
@@ -1913,10 +1918,104 @@ __global__ void __launch_bounds__(512) front_small_kernel(DevProblem P, DevSymbo
   // Schur complement -> own arena square (a small parent pulls it, a big parent gathers it)
   const int s1 = n - F;
   for (int col = wave; col < s1; col += nw)
-    for (int r = col + lane; r < s1; r += 64) A[(F + r) + (i64)(F + col) * n] = L[(F + r) + (F + col) * n];
+    for (int r = col + lane; r < s1; r += 64) {
+      if constexpr (COH)
+        __hip_atomic_store(&A[(F + r) + (i64)(F + col) * n], L[(F + r) + (F + col) * n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else A[(F + r) + (i64)(F + col) * n] = L[(F + r) + (F + col) * n];
+    }
   FS_ADD(4)
 #ifdef GSX_STAMP
-  if (tid == 0 && blockIdx.x == gridDim.x / 2) { g_fs_stamp[5] = n; g_fs_stamp[6] = F; g_fs_stamp[7] = nchild; g_fs_stamp[8] = nfv; }
+  if (tid == 0) { atomicAdd(&g_fs_stamp[5], (unsigned long long)n); atomicAdd(&g_fs_stamp[6], (unsigned long long)F); atomicAdd(&g_fs_stamp[7], (unsigned long long)nchild); atomicAdd(&g_fs_stamp[8], (unsigned long long)nfv); atomicAdd(&g_fs_stamp[9], 1ull); }
+#endif
+}
+__global__ void __launch_bounds__(512) front_small_kernel(DevProblem P, DevSymbolic S, const int* ids, const double* H, const double* damp,
+                                   const double* scalars, double* arena, DevStatus* status) {
+  extern __shared__ double L[];
+  front_small_body<false>(P, S, ids[blockIdx.x], H, damp, scalars[SC_LAMBDA], arena, status, L);
+}
+
+// ---------------------------------------------------------------------------------------------
+// front_tree: the LDS-class fronts of one tier (Symbolic::tree_*), whole subtrees without a kernel boundary or a level
+// barrier.  A workgroup claims a start front (no unfinished child in the tier), eliminates it exactly as front_small does,
+// and then climbs: it tells the parent that one more child has arrived (one device-scope atomic), and when it was the
+// LAST to arrive it eliminates the parent itself — whose children's Schur complements are then all in the arena, written
+// by this or by other workgroups: the Schur complements travel with agent-scope stores and loads (past the per-XCD L2s),
+// ordered by the workgroup's own wait for its stores before the atomic — a release / acquire fence pair instead writes
+// back and invalidates a whole L2 per front, measured at 5x the level-by-level time.  Nobody ever waits: a
+// workgroup that is not the last arrival claims the next start front, and leaves when there is none.  The extend-add
+// stays a pull in child order, so the numbers do not depend on who arrives when (bitwise reproducible).
+// Post-order elimination of gtsam/inference/ClusterTree-inst.h:219-318.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512, 4) front_tree_kernel(DevProblem P, DevSymbolic S, TreeArgs T, const double* H,
+                                                         const double* damp, const double* scalars, double* arena,
+                                                         DevStatus* status) {
+  extern __shared__ double L[];
+  __shared__ int s_next;
+  const double lambda = scalars[SC_LAMBDA];
+  for (;;) {
+    if (threadIdx.x == 0) s_next = atomicAdd(T.cursor, 1);
+    __syncthreads();
+    const int k = s_next;
+    __syncthreads();
+    if (k >= T.nstart) return;
+    int f = T.start[k];
+    while (f >= 0) {
+      front_small_body<true>(P, S, f, H, damp, lambda, arena, status, L);
+#ifdef GSX_STAMP
+      unsigned long long hs0 = wall_clock64();
+#endif
+      __syncthreads();  // (drains every store of the workgroup: s_waitcnt vmcnt(0) before the barrier)
+      if (threadIdx.x == 0) {
+        int nxt = -1;
+        const int p = T.up[f];
+        if (p >= 0 && atomicSub(&T.pending[p], 1) == 1) {
+          T.pending[p] = T.npend[p];  // (every child has arrived: nobody touches the counter again in this launch)
+          nxt = p;
+        }
+        s_next = nxt;
+      }
+      __syncthreads();
+      f = s_next;
+      __syncthreads();
+#ifdef GSX_STAMP
+      if (threadIdx.x == 0) atomicAdd(&g_fs_stamp[10], wall_clock64() - hs0);
+#endif
+    }
+  }
+}
+#ifdef GSX_STAMP
+static void fs_stamp_zero() {
+  unsigned long long z[12] = {};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_fs_stamp), z, sizeof(z));
+}
+static void fs_stamp_print(const char* what, int count, int threads, int max_n, hipStream_t st) {
+  unsigned long long h[12];
+  hipStreamSynchronize(st);
+  hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fs_stamp), sizeof(h));
+  const double c = h[9] ? (double)h[9] : 1.0;
+  printf("[%s] count %6d thr %3d max_n %3d | fronts %llu mean n=%.0f F=%.0f ch=%.1f nfv=%.1f | mean us: head %.1f  H %.1f  children %.1f  chol %.1f  store %.1f  handoff %.1f\n",
+         what, count, threads, max_n, h[9], h[5] / c, h[6] / c, h[7] / c, h[8] / c, h[0] / c / 100, h[1] / c / 100, h[2] / c / 100,
+         h[3] / c / 100, h[4] / c / 100, h[10] / c / 100);
+}
+#endif
+void launch_front_tree(const DevProblem& P, const DevSymbolic& S, const TreeArgs& T, int max_n, int threads, const double* H,
+                       const double* damp, const double* scalars, double* arena, DevStatus* status, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)front_tree_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+    attr = true;
+  }
+  if (T.nstart <= 0) return;
+  const size_t lds = ((size_t)max_n * max_n + max_n) * sizeof(double);
+  // as many workgroups as can be resident (LDS, 2048 threads a CU); the rest would only find the start list empty
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>({(size_t)(156 * 1024) / (lds + 2048), (size_t)2048 / threads, 16}));
+  const int grid = std::min(T.nstart, 256 * per_cu);
+#ifdef GSX_STAMP
+  fs_stamp_zero();
+#endif
+  front_tree_kernel<<<grid, threads, lds, st>>>(P, S, T, H, damp, scalars, arena, status);
+#ifdef GSX_STAMP
+  fs_stamp_print("tree", grid, threads, max_n, st);
 #endif
 }
 
@@ -1928,17 +2027,14 @@ void launch_front_small(const DevProblem& P, const DevSymbolic& S, const int* id
     hipFuncSetAttribute((const void*)front_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
     attr = true;
   }
+#ifdef GSX_STAMP
+  fs_stamp_zero();
+#endif
   if (count)
     front_small_kernel<<<count, threads, ((size_t)max_n * max_n + max_n) * sizeof(double), st>>>(P, S, ids, H, damp, scalars,
                                                                                          arena, status);
 #ifdef GSX_STAMP
-  if (count) {
-    unsigned long long h[12];
-    hipStreamSynchronize(st);
-    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fs_stamp), sizeof(h));
-    printf("[fs] count %6d thr %3d max_n %3d | wg n=%3llu F=%3llu ch=%llu nfv=%llu | x10ns: head %llu  H %llu  children %llu  chol %llu  store %llu\n",
-           count, threads, max_n, h[5], h[6], h[7], h[8], h[0], h[1], h[2], h[3], h[4]);
-  }
+  if (count) fs_stamp_print("fs", count, threads, max_n, st);
 #endif
 }
 

@@ -68,6 +68,7 @@ struct DevBuf {
 struct SmallLaunch {
   int begin, count, max_n, threads;
   int max_panel = 0;  // leaf launches: largest n*F of the group (LDS doubles)
+  int max_F = 0;      // rest launches: largest frontal dimension
 };
 struct BigLevel {
   int begin = 0, count = 0;
@@ -129,6 +130,20 @@ struct gsx_context {
   std::vector<std::vector<SmallLaunch>> small_launch;  // per level
   std::vector<std::vector<SmallLaunch>> leaf_launch;   // per level (panel-only leaf kernel)
   std::vector<int> leaf_max_F;                         // per level: largest F among its leaf-kernel fronts
+  // the full factorization runs the tree fronts (Symbolic::tree_*) in one launch per tier and only the other LDS-class
+  // fronts level by level (rest_launch: ranges of d_rest_ids); small_launch keeps ALL of them for the filtered plans of
+  // gsx_relinearize_partial
+  std::vector<std::vector<SmallLaunch>> rest_launch;
+  DevBuf<int> d_rest_ids, d_tree_start, d_tree_up, d_tree_npend, d_tree_pending, d_tree_cursor;
+  // back-substitution of the tree fronts in one launch (bigfront.hip: backsolve_tree_kernel)
+  DevBuf<int> d_bst_roots, d_bst_child_ptr, d_bst_children, d_bst_counters;
+  DevBuf<unsigned long long> d_bst_ready;
+  int bst_roots = 0, bst_total = 0;
+  unsigned bst_epoch = 0;
+  struct TreeTier {
+    int start0, nstart, max_n, threads;
+  };
+  std::vector<TreeTier> tree_tiers;
   DevBuf<i64> d_gt_dst;  // gather tasks / segments for big parents
   DevBuf<GatherSeg> d_gsegs;
   DevBuf<GatherSrc> d_gsrcs;
@@ -614,6 +629,8 @@ gsx_status upload_symbolic(gsx_context* c) {
   c->big_max_n = c->big_max_nfv = 0;
   c->leaf_launch.assign(S.n_levels, {});
   c->leaf_max_F.assign(S.n_levels, 0);
+  c->rest_launch.assign(S.n_levels, {});
+  std::vector<int> rest_ids;
   for (int l = 0; l < S.n_levels; ++l) {
     int i = S.lvl_ptr[l];
     for (int k = i; k < S.lvl_leaf_end[l]; ++k) c->leaf_max_F[l] = std::max(c->leaf_max_F[l], S.F[S.sched[k]]);
@@ -694,6 +711,21 @@ gsx_status upload_symbolic(gsx_context* c) {
         G.assign(1, one);
       }
     }
+    {
+      // what the level loop of the full factorization still launches: the LDS-class fronts that are not tree fronts (they
+      // sit above a blocked front), one launch a level
+      SmallLaunch r{(int)rest_ids.size(), 0, 0, 0};
+      for (int k = S.lvl_leaf_end[l]; k < se; ++k) {
+        const int f = S.sched[k];
+        if (S.tree_tier[f] >= 0) continue;
+        rest_ids.push_back(f);
+        r.count++;
+        r.max_n = std::max(r.max_n, S.N[f]);
+        r.max_F = std::max(r.max_F, S.F[f]);
+      }
+      r.threads = small_threads_for(r.max_n);
+      if (r.count) c->rest_launch[l].push_back(r);
+    }
     BigLevel& B = c->big_level[l];
     B.begin = (int)c->big_descs.size();
     for (int k = se; k < S.lvl_ptr[l + 1]; ++k) {
@@ -705,6 +737,49 @@ gsx_status upload_symbolic(gsx_context* c) {
     }
     B.count = (int)c->big_descs.size() - B.begin;
     plan_big_group(c->big_descs.data() + B.begin, B.count, B.plan);
+  }
+  HIPCHK(c, c->d_rest_ids.upload(rest_ids, st));
+  {
+    c->tree_tiers.clear();
+    const int ntier = std::min<int>((int)S.tree_bounds.size(), kTreeCursors);
+    for (int t = 0; t < ntier; ++t) {
+      int maxn = 0;
+      for (int f = 0; f < S.n_fronts; ++f)
+        if (S.tree_tier[f] == t) maxn = std::max(maxn, S.N[f]);
+      c->tree_tiers.push_back({S.tree_start_ptr[t], S.tree_start_ptr[t + 1] - S.tree_start_ptr[t], maxn,
+                               S.tree_threads[t] > 0 ? S.tree_threads[t] : small_threads_for(maxn)});
+    }
+    HIPCHK(c, c->d_tree_start.upload(S.tree_start, st));
+    HIPCHK(c, c->d_tree_up.upload(S.tree_up, st));
+    HIPCHK(c, c->d_tree_npend.upload(S.tree_npend, st));
+    HIPCHK(c, c->d_tree_pending.upload(S.tree_npend, st));
+    HIPCHK(c, c->d_tree_cursor.upload(std::vector<int>(kTreeCursors, 0), st));
+    // top-down: roots = tree fronts whose parent is not a tree front; per front its tree children, the deepest subtree
+    // first (a workgroup goes on with that one itself); roots by depth as well: the long chains start first
+    std::vector<int> roots, cptr(S.n_fronts + 1, 0), cidx, height(S.n_fronts, 0);
+    for (int f = 0; f < S.n_fronts; ++f)   // children have smaller ids
+      if (S.tree_tier[f] >= 0 && S.parent[f] >= 0 && S.tree_tier[S.parent[f]] >= 0)
+        height[S.parent[f]] = std::max(height[S.parent[f]], height[f] + 1);
+    int total = 0;
+    for (int f = 0; f < S.n_fronts; ++f) {
+      const size_t b = cidx.size();
+      for (int k = S.child_ptr[f]; k < S.child_ptr[f + 1]; ++k)
+        if (S.tree_tier[f] >= 0 && S.tree_tier[S.children[k]] >= 0) cidx.push_back(S.children[k]);
+      std::stable_sort(cidx.begin() + b, cidx.end(), [&](int x, int y) { return height[x] > height[y]; });
+      cptr[f + 1] = (int)cidx.size();
+      if (S.tree_tier[f] < 0) continue;
+      total += (int)(cidx.size() - b) > 1 ? (int)(cidx.size() - b) - 1 : 0;   // published entries
+      if (S.parent[f] < 0 || S.tree_tier[S.parent[f]] < 0) roots.push_back(f);
+    }
+    std::stable_sort(roots.begin(), roots.end(), [&](int x, int y) { return height[x] > height[y]; });
+    total += (int)roots.size();   // = tickets
+    c->bst_roots = (int)roots.size();
+    c->bst_total = total;
+    HIPCHK(c, c->d_bst_roots.upload(roots, st));
+    HIPCHK(c, c->d_bst_child_ptr.upload(cptr, st));
+    HIPCHK(c, c->d_bst_children.upload(cidx, st));
+    HIPCHK(c, c->d_bst_counters.upload(std::vector<int>(2, 0), st));
+    HIPCHK(c, c->d_bst_ready.upload(std::vector<unsigned long long>((size_t)std::max(total - (int)roots.size(), 1), 0ull), st));
   }
   // front -> where it sits in the launch plan (for the filtered plans of gsx_relinearize_partial)
   c->fr_sched_pos.assign(S.n_fronts, -1);
@@ -919,7 +994,7 @@ void dev_factorize(gsx_context* c, double lambda) {
   c->wf_all_replaced = true;  // every clique re-eliminated
   c->sc_dirty |= kXFact;
   timer_begin(c, PH_FACTORIZE);
-  launch_begin_factorization(c->d_scalars.p, lambda, c->d_status.p, c->stream);
+  launch_begin_factorization(c->d_scalars.p, lambda, c->d_status.p, c->d_tree_cursor.p, c->stream);
   if (!c->big_descs.empty())
     launch_big_init(c->DP, c->DS, c->d_big.p, (int)c->big_descs.size(), c->big_max_n, c->big_max_nfv, c->d_H.p,
                     c->d_damp.p, c->d_scalars.p, c->d_arena.p, c->stream);
@@ -927,13 +1002,13 @@ void dev_factorize(gsx_context* c, double lambda) {
     // The leaf / small (LDS) launches of a level are independent of each other.  Few, GPU-filling ones (the landmark
     // cliques of a bundle adjustment) go one after the other; many partly-filled ones (the size groups of a pose
     // graph's lower levels, each bound by the latency of its slowest front) run side by side.
-    const size_t n_groups = c->leaf_launch[l].size() + c->small_launch[l].size();
+    const size_t n_groups = c->leaf_launch[l].size() + c->rest_launch[l].size();
     int max_count = 0;
     for (const SmallLaunch& sl : c->leaf_launch[l]) max_count = std::max(max_count, sl.count);
-    for (const SmallLaunch& sl : c->small_launch[l]) max_count = std::max(max_count, sl.count);
+    for (const SmallLaunch& sl : c->rest_launch[l]) max_count = std::max(max_count, sl.count);
     // (a fork + join costs ~85 us of cross-queue event latency, measured: only worth it for many groups)
     // the long ones are the LDS-front launches (40-150 us each); leaf launches are 10-30 us and do not justify a fork)
-    const bool side = c->profiling <= 0 && n_groups >= 4 && c->small_launch[l].size() >= 4 && max_count < 16384 && side_fork(c);
+    const bool side = c->profiling <= 0 && n_groups >= 4 && c->rest_launch[l].size() >= 4 && max_count < 16384 && side_fork(c);
     unsigned used = 0;
     int gi = 0;
     for (const SmallLaunch& sl : c->leaf_launch[l]) {
@@ -943,15 +1018,26 @@ void dev_factorize(gsx_context* c, double lambda) {
                         side ? side_stream(c, gi++, &used) : c->stream);
       if (c->profiling > 0) timer_end(c, PH_FACTOR_LEAF);
     }
-    // (largest fronts first: they are the longest launches and land on different hardware queues)
-    for (size_t k = c->small_launch[l].size(); k-- > 0;) {
-      const SmallLaunch& sl = c->small_launch[l][k];
+    for (const SmallLaunch& sl : c->rest_launch[l]) {
       if (c->profiling > 0) timer_begin(c, PH_FACTOR_SMALL);
-      launch_front_small(c->DP, c->DS, c->d_sched.p + sl.begin, sl.count, sl.max_n, sl.threads, c->d_H.p, c->d_damp.p,
+      launch_front_small(c->DP, c->DS, c->d_rest_ids.p + sl.begin, sl.count, sl.max_n, sl.threads, c->d_H.p, c->d_damp.p,
                          c->d_scalars.p, c->d_arena.p, c->d_status.p, side ? side_stream(c, gi++, &used) : c->stream);
       if (c->profiling > 0) timer_end(c, PH_FACTOR_SMALL);
     }
     if (side) side_join(c, used);
+    if (l == 0) {
+      // the tree fronts of every level: one launch per tier (their leaf-kernel children were the launches above)
+      for (size_t t = 0; t < c->tree_tiers.size(); ++t) {
+        const gsx_context::TreeTier& tt = c->tree_tiers[t];
+        if (!tt.nstart) continue;
+        if (c->profiling > 0) timer_begin(c, PH_FACTOR_SMALL);
+        launch_front_tree(c->DP, c->DS,
+                          TreeArgs{c->d_tree_start.p + tt.start0, tt.nstart, c->d_tree_cursor.p + t, c->d_tree_pending.p,
+                                   c->d_tree_up.p, c->d_tree_npend.p},
+                          tt.max_n, tt.threads, c->d_H.p, c->d_damp.p, c->d_scalars.p, c->d_arena.p, c->d_status.p, c->stream);
+        if (c->profiling > 0) timer_end(c, PH_FACTOR_SMALL);
+      }
+    }
     if (l == 0 && S.gseg_lvl_ptr[1] > S.gseg_lvl_ptr[0]) {
       // gather group 0: the product-form contributions of all lean leaves to all big fronts (symbolic.cpp)
       if (c->profiling > 0) timer_begin(c, PH_K_GATHER);
@@ -989,6 +1075,9 @@ void dev_backsolve(gsx_context* c, const WildfireArgs* wf = nullptr) {
   const Symbolic& S = c->S;
   timer_begin(c, PH_BACKSOLVE);
   c->wf_delta_valid = false;  // (set again by the callers that leave a complete undamped solution behind)
+  // (the wildfire pass keeps the level launches: its bookkeeping runs level by level)
+  static const bool bs_tree_off = std::getenv("GSX_BS_TREE_OFF") != nullptr;
+  const bool tree = wf == nullptr && c->bst_total > 0 && !bs_tree_off;
   for (int l = S.n_levels - 1; l >= 0; --l) {
     const BigLevel& B = c->big_level[l];
     const int se = S.lvl_small_end[l];
@@ -1007,22 +1096,34 @@ void dev_backsolve(gsx_context* c, const WildfireArgs* wf = nullptr) {
                            c->d_status.p, c->stream);
       if (c->profiling > 0) timer_end(c, PH_K_BACKSOLVE);
     }
-    // the LDS-class fronts: their own kernels when every one of them has at most 64 frontal columns
-    const int n_small = se - le;
+    // the LDS-class fronts: their own kernels when every one of them has at most 64 frontal columns.  With the tree
+    // kernel only the ones that are not tree fronts are solved here (rest_launch: they sit above a blocked front).
+    const int* small_ids = c->d_sched.p + le;
+    int n_small = se - le;
     int small_maxn = 0, small_maxF = 0;
-    for (int k = le; k < se; ++k) {
-      small_maxn = std::max(small_maxn, S.N[S.sched[k]]);
-      small_maxF = std::max(small_maxF, S.F[S.sched[k]]);
+    if (tree) {
+      n_small = 0;
+      for (const SmallLaunch& rl : c->rest_launch[l]) {   // (at most one range a level)
+        small_ids = c->d_rest_ids.p + rl.begin;
+        n_small = rl.count;
+        small_maxn = rl.max_n;
+        small_maxF = rl.max_F;
+      }
+    } else {
+      for (int k = le; k < se; ++k) {
+        small_maxn = std::max(small_maxn, S.N[S.sched[k]]);
+        small_maxF = std::max(small_maxF, S.F[S.sched[k]]);
+      }
     }
     const bool small_own = n_small > 0 && backsolve_small_fits(small_maxn, small_maxF);
     if (small_own) {
       if (c->profiling > 0) timer_begin(c, PH_K_BACKSOLVE);
-      launch_backsolve_small(c->DS, c->d_sched.p + le, n_small, small_maxF, c->d_arena.p, c->d_delta.p, c->d_status.p,
+      launch_backsolve_small(c->DS, small_ids, n_small, small_maxF, c->d_arena.p, c->d_delta.p, c->d_status.p,
                              c->stream);
       if (c->profiling > 0) timer_end(c, PH_K_BACKSOLVE);
     }
     const bool big_left = B.count > 0 && !big_own, small_left = n_small > 0 && !small_own;
-    if (big_left && small_left && n_rest <= 512 && n_rest > B.count) {
+    if (!tree && big_left && small_left && n_rest <= 512 && n_rest > B.count) {
       // few fronts: small and big ones of the level in ONE launch of the generic kernel
       int maxn = 0;
       for (int k = le; k < S.lvl_ptr[l + 1]; ++k) maxn = std::max(maxn, S.N[S.sched[k]]);
@@ -1042,10 +1143,22 @@ void dev_backsolve(gsx_context* c, const WildfireArgs* wf = nullptr) {
         // the size groups of the factorization (split by LDS footprint) mean nothing here — the generic kernel keeps
         // only n - 1 doubles per clique in LDS: all the level's LDS-class cliques go in ONE launch
         if (c->profiling > 0) timer_begin(c, PH_K_BACKSOLVE);
-        launch_backsolve(c->DS, c->d_sched.p + le, n_small, small_maxn <= 48 ? 64 : 256, small_maxn, c->d_arena.p,
+        launch_backsolve(c->DS, small_ids, n_small, small_maxn <= 48 ? 64 : 256, small_maxn, c->d_arena.p,
                          c->d_delta.p, c->d_status.p, c->stream);
         if (c->profiling > 0) timer_end(c, PH_K_BACKSOLVE);
       }
+    }
+    if (tree && l == 0) {
+      // every other front is solved: the tree fronts of all levels, one launch (their leaf-kernel children follow below)
+      hipMemsetAsync(c->d_bst_counters.p, 0, 2 * sizeof(int), c->stream);
+      if (++c->bst_epoch == 0) c->bst_epoch = 1;
+      if (c->profiling > 0) timer_begin(c, PH_K_BACKSOLVE);
+      launch_backsolve_tree(c->DS,
+                            BacksolveTreeArgs{c->d_bst_roots.p, c->bst_roots, c->bst_total, c->d_bst_child_ptr.p,
+                                              c->d_bst_children.p, c->d_bst_ready.p, c->d_bst_counters.p,
+                                              c->d_bst_counters.p + 1, c->bst_epoch},
+                            c->d_arena.p, c->d_delta.p, c->d_status.p, c->stream);
+      if (c->profiling > 0) timer_end(c, PH_K_BACKSOLVE);
     }
     // all leaf-kernel cliques of the level in one launch (a wave each)
     if (S.lvl_leaf_end[l] > S.lvl_ptr[l])
@@ -1503,7 +1616,7 @@ gsx_status gsx_solve(gsx_handle h, double lambda, int32_t diagonal_damping, doub
     dev_damping(h, diagonal_damping, min_diagonal, max_diagonal);
     dev_factorize(h, lambda);
   } else {
-    launch_begin_factorization(h->d_scalars.p, 0.0, h->d_status.p, h->stream);  // status reset for the substitution
+    launch_begin_factorization(h->d_scalars.p, 0.0, h->d_status.p, nullptr, h->stream);  // status reset for the substitution
     h->sc_dirty |= kXFact;
   }
   dev_backsolve(h);
@@ -1553,7 +1666,7 @@ gsx_status gsx_backsubstitute_wildfire(gsx_handle h, double threshold, double* d
   }
   hipSetDevice(h->device);
   const Symbolic& S = h->S;
-  launch_begin_factorization(h->d_scalars.p, 0.0, h->d_status.p, h->stream);  // status reset for the substitution
+  launch_begin_factorization(h->d_scalars.p, 0.0, h->d_status.p, nullptr, h->stream);  // status reset for the substitution
   h->sc_dirty |= kXFact;
   // (DeltaImpl::UpdateGaussNewtonDelta: threshold <= 0 = all cliques; so is a pass with every clique replaced)
   const bool full = !(threshold > 0.0) || !h->wf_delta_valid || h->wf_all_replaced;
@@ -2097,7 +2210,7 @@ gsx_status partial_factor(gsx_handle h, std::vector<int>& dfr) {
     GA.gm_nslots = ps.gm_nslots.p;
     h->sc_dirty |= kXFact;
     timer_begin(h, PH_FACTORIZE);
-    launch_begin_factorization(h->d_scalars.p, 0.0, h->d_status.p, sm);
+    launch_begin_factorization(h->d_scalars.p, 0.0, h->d_status.p, nullptr, sm);
     dev_damping(h, 0, 0, 0);
     if (!big.empty())
       launch_big_init(h->DP, h->DS, ps.big.p, (int)big.size(), big_max_n, big_max_nfv, h->d_H.p, h->d_damp.p,

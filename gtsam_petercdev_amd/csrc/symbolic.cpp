@@ -446,6 +446,65 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     if (S.cls[f] == 2) sz = ((sz + 1) & ~int64_t(1)) + (int64_t)S.N[f] * S.F[f];  // + L-panel area (kernels.h)
     fsize[f] = (sz + 1) & ~int64_t(1);  // 16-byte aligned fronts
   }
+  // ---- tree fronts (gsx_internal.h): LDS-class fronts whose whole subtree is LDS-class, tiers by the subtree's largest n
+  {
+    S.tree_bounds.clear();
+    S.tree_threads.clear();
+    if (const char* e = std::getenv("GSX_TREE_TIERS")) {  // experiments: "45:128,79:256,140:512"; "0" switches the tree kernels off
+      int v[2] = {0, 0}, k = 0;
+      bool any = false;
+      for (const char* q = e;; ++q) {
+        if (*q >= '0' && *q <= '9') {
+          v[k] = v[k] * 10 + (*q - '0');
+          any = true;
+        } else if (*q == ':') {
+          k = 1;
+        } else {
+          if (any && v[0] > 0) {
+            S.tree_bounds.push_back(std::min(v[0], kSmallMaxN));
+            S.tree_threads.push_back(std::max(0, std::min(512, (v[1] + 63) / 64 * 64)));   // (the kernel's launch bound)
+          }
+          v[0] = v[1] = k = 0;
+          any = false;
+          if (!*q) break;
+        }
+      }
+    } else {
+      // two tiers: fronts of at most 67 rows (four to a CU's 160 KB of LDS) and the rest.  Swept on the 100 000-pose
+      // graphs (tools/sweep_tree.sh): every further tier adds its own tail — the last few chains of a launch run alone
+      // on the chip — and costs more than the LDS it frees: 45/79/140 +16 %, 53/98/140 +13 %, one tier +67 %.
+      S.tree_bounds = {67, kSmallMaxN};
+      S.tree_threads = {256, 512};
+    }
+    S.tree_tier.assign(nfr, -1);
+    S.tree_up.assign(nfr, -1);
+    S.tree_npend.assign(nfr, 0);
+    const int nt = (int)S.tree_bounds.size();
+    std::vector<int> subn(nfr, 0);
+    for (int f = 0; f < nfr && nt > 0; ++f) {  // children have smaller ids
+      if (!S.scheduled[f] || S.cls[f] != 1) continue;
+      bool ok = true;
+      int mx = S.N[f];
+      for (int c = S.child_ptr[f]; c < S.child_ptr[f + 1] && ok; ++c) {
+        const int ch = S.children[c];
+        if (S.cls[ch] == 0 && !S.lean[ch]) continue;  // done by the leaf launch before the tree kernels
+        ok = S.tree_tier[ch] >= 0;
+        mx = std::max(mx, subn[ch]);
+      }
+      if (!ok || mx > S.tree_bounds.back()) continue;
+      subn[f] = mx;
+      int t = 0;
+      while (S.tree_bounds[t] < mx) ++t;
+      S.tree_tier[f] = t;
+    }
+    for (int f = 0; f < nfr; ++f) {
+      const int p = S.parent[f];
+      if (S.tree_tier[f] >= 0 && p >= 0 && S.tree_tier[p] == S.tree_tier[f]) {
+        S.tree_up[f] = p;
+        S.tree_npend[p]++;
+      }
+    }
+  }
   {
     // A level's LDS fronts cost one launch bound by the latency of its slowest front (60-100 us for a 100-140 row front:
     // a barrier per pivot) however few they are.  Where the level has blocked (big) fronts anyway and only a handful of
@@ -456,12 +515,12 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     for (int f = 0; f < nfr; ++f) nlev = std::max(nlev, S.level[f] + 1);
     std::vector<int> n_lds(nlev, 0), n_blk(nlev, 0);
     for (int f = 0; f < nfr; ++f) {
-      if (S.cls[f] == 1) n_lds[S.level[f]]++;
+      if (S.cls[f] == 1 && S.tree_tier[f] < 0) n_lds[S.level[f]]++;  // (tree fronts cost no launch of their level)
       else if (S.cls[f] == 2) n_blk[S.level[f]]++;
     }
     for (int f = 0; f < nfr; ++f) {
       const int l = S.level[f];
-      if (S.cls[f] != 1 || n_blk[l] == 0 || n_lds[l] > 1024) continue;
+      if (S.cls[f] != 1 || S.tree_tier[f] >= 0 || n_blk[l] == 0 || n_lds[l] > 1024) continue;
       S.cls[f] = 2;
       S.n_big++;
       S.n_small--;
@@ -687,6 +746,16 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     S.lvl_leaf_end[l] = e;
     while (e < S.lvl_ptr[l + 1] && cls(S.sched[e]) == 1) ++e;
     S.lvl_small_end[l] = e;
+  }
+  {
+    const int nt = (int)S.tree_bounds.size();
+    S.tree_start_ptr.assign(nt + 1, 0);
+    S.tree_start.clear();
+    for (int t = 0; t < nt; ++t) {
+      for (int f : S.sched)
+        if (S.tree_tier[f] == t && S.tree_npend[f] == 0) S.tree_start.push_back(f);
+      S.tree_start_ptr[t + 1] = (int)S.tree_start.size();
+    }
   }
   clk.mark("schedule");
   // ---- gather tasks for big parents ------------------------------------------------------------------------
