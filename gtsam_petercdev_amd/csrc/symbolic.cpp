@@ -182,54 +182,110 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     merge_pass(relax, relax_max_f);
   } else {
     // ---- the library's own choice (gsx_set_amalgamation(h, GSX_AMALGAMATION_AUTO, .)) ------------------------------
-    // The factorization is a level schedule: every level of the clique tree costs its kernel launches and the
-    // sequential pivot chain of its largest front, while the arithmetic itself runs far below the matrix cores' rate —
-    // so a tree is priced by its levels and chains first and by its (padded) flops last.  Constants in microseconds,
-    // measured on MI355X (profiles/r02_*, tools/bigfront_bench.hip): a level with blocked fronts = gather + three
-    // launches (~35) + 0.33 per pivot of its widest chunk chain + its flops at ~10 TFLOP/s; a level with LDS fronts
-    // ~25 + 1.0 per pivot of its largest front + flops at ~2 TFLOP/s; the back-substitution ~25 per level.
+    // A candidate tree is priced by how it will run (microseconds, measured on MI355X: profiles/r03_*):
+    //  * tree fronts (LDS-class with an all-LDS-class subtree; gsx_internal.h) run dependency-driven, one launch per
+    //    tier: a front takes t = 4 + 1.9 children + 0.3 F + 0.04 n; a tier costs the larger of its longest chain of
+    //    such fronts and its total front time over the workgroups resident at once (4 a CU up to 67 rows, 1 a CU beyond);
+    //    their back-substitution is one launch: 7 per front, chain or total over 1280 workgroups;
+    //  * everything else is a level schedule: a level with blocked fronts = gather + three launches (~55) + 0.33 per
+    //    pivot of its widest chunk chain + its flops at ~10 TFLOP/s, + ~22 for its back-substitution; LDS fronts
+    //    above blocked ones ~25 + 1.0 per pivot of the largest + flops at ~2 TFLOP/s.
     double best_cost = 0;
     double best_rx = 0;
     int best_mf = 128;
     bool first = true;
     std::vector<int> lvl(n), bigF, smallF;
     std::vector<double> bigFl, smallFl;
+    // per node: what its (non-merged) child clusters hand up — folded into the cluster's top node
+    std::vector<char> a_tree(n);        // all child clusters are tree fronts or leaf-kernel cliques
+    std::vector<int> a_nch(n), a_subn(n), a_depth(n);
+    std::vector<float> a_cp0(n), a_cp1(n);  // longest chain below, in tier 0 / tier 1
     const double cand_rx[] = {0.0, 0.125, 0.25, 0.5, 1.0, 2.0};
-    const int cand_mf[] = {32, 64, 96, 128, 160};
+    const int cand_mf[] = {16, 24, 32, 48, 64, 96, 128, 160};
     for (double rx : cand_rx)
       for (int mf : cand_mf) {
         if (rx == 0.0 && mf != cand_mf[0]) continue;
         merge_pass(rx, mf);
         bigF.clear(), smallF.clear(), bigFl.clear(), smallFl.clear();
         std::fill(lvl.begin(), lvl.end(), 0);
+        std::fill(a_tree.begin(), a_tree.end(), 1);
+        std::fill(a_nch.begin(), a_nch.end(), 0);
+        std::fill(a_subn.begin(), a_subn.end(), 0);
+        std::fill(a_depth.begin(), a_depth.end(), 0);
+        std::fill(a_cp0.begin(), a_cp0.end(), 0.f);
+        std::fill(a_cp1.begin(), a_cp1.end(), 0.f);
         int nl = 0;
-        for (int j = 0; j < n; ++j) {  // children before parents: lvl[j] of a cluster top is final when j is reached
-          if (merged[j]) {             // a merged node hands its children's levels to the cluster's top
-            if (eparent[j] >= 0) lvl[eparent[j]] = std::max(lvl[eparent[j]], lvl[j]);
+        double work[2] = {0, 0}, chain[2] = {0, 0}, n_tree = 0;
+        int bs_depth = 0;
+        for (int j = 0; j < n; ++j) {  // children before parents: everything of a cluster top is final when j is reached
+          const int ep = eparent[j];
+          if (merged[j]) {             // a merged node hands what its children gave it to the cluster's top
+            if (ep >= 0) {
+              lvl[ep] = std::max(lvl[ep], lvl[j]);
+              a_tree[ep] = a_tree[ep] && a_tree[j];
+              a_nch[ep] += a_nch[j];
+              a_subn[ep] = std::max(a_subn[ep], a_subn[j]);
+              a_depth[ep] = std::max(a_depth[ep], a_depth[j]);
+              a_cp0[ep] = std::max(a_cp0[ep], a_cp0[j]);
+              a_cp1[ep] = std::max(a_cp1[ep], a_cp1[j]);
+            }
             continue;
           }
           const int l = lvl[j];
-          if (l >= nl) {
-            nl = l + 1;
-            bigF.resize(nl, 0), smallF.resize(nl, 0), bigFl.resize(nl, 0.0), smallFl.resize(nl, 0.0);
-          }
           const double F = (double)fdim_of[j], s1 = (double)sdim_of[j] + 1.0;
+          const int nn = (int)(fdim_of[j] + sdim_of[j] + 1);
           const double fl = F * F * F / 3.0 + F * F * s1 + F * s1 * s1;
-          if (fdim_of[j] + sdim_of[j] + 1 > kSmallMaxN) {
-            bigF[l] = std::max(bigF[l], (int)fdim_of[j]);
-            bigFl[l] += fl;
-          } else if (ech_ptr[j + 1] > ech_ptr[j] || fdim_of[j] > kLeafMaxF) {  // (childless small cliques: the leaf kernel, one launch)
-            smallF[l] = std::max(smallF[l], (int)fdim_of[j]);
-            smallFl[l] += fl;
+          const bool blocked = nn > kSmallMaxN;
+          const bool leafk = !blocked && a_nch[j] == 0 && fdim_of[j] <= kLeafMaxF;   // the leaf kernel: one launch for all
+          const bool tree = !blocked && !leafk && a_tree[j] && std::max(nn, a_subn[j]) <= kSmallMaxN;
+          if (tree) {
+            const int subn = std::max(nn, a_subn[j]);
+            const int tier = subn <= 67 ? 0 : 1;
+            const double t = 4.0 + 1.9 * a_nch[j] + 0.3 * F + 0.04 * nn;
+            const double cp = t + (tier == 0 ? a_cp0[j] : a_cp1[j]);   // (a tier-1 front's tier-0 children ran in the launch before)
+            work[tier] += t;
+            chain[tier] = std::max(chain[tier], cp);
+            n_tree += 1;
+            const int depth = a_depth[j] + 1;
+            bs_depth = std::max(bs_depth, depth);
+            if (ep >= 0) {
+              a_subn[ep] = std::max(a_subn[ep], subn);
+              a_depth[ep] = std::max(a_depth[ep], depth);
+              if (tier == 0) a_cp0[ep] = std::max(a_cp0[ep], (float)cp);
+              else a_cp1[ep] = std::max(a_cp1[ep], (float)cp);
+            }
+          } else if (!leafk) {
+            if (l >= nl) {
+              nl = l + 1;
+              bigF.resize(nl, 0), smallF.resize(nl, 0), bigFl.resize(nl, 0.0), smallFl.resize(nl, 0.0);
+            }
+            if (blocked) {
+              bigF[l] = std::max(bigF[l], (int)fdim_of[j]);
+              bigFl[l] += fl;
+            } else {
+              smallF[l] = std::max(smallF[l], (int)fdim_of[j]);
+              smallFl[l] += fl;
+            }
+            if (ep >= 0) a_tree[ep] = 0;
           }
-          if (eparent[j] >= 0) lvl[eparent[j]] = std::max(lvl[eparent[j]], l + 1);
+          if (ep >= 0) {
+            a_nch[ep] += 1;
+            lvl[ep] = std::max(lvl[ep], l + 1);
+          }
         }
-        double cost = 0;
+        double cost = 40.0;  // (the leaf launches)
         for (int l = 0; l < nl; ++l) {
-          cost += 25.0;
-          if (bigF[l]) cost += 35.0 + 0.33 * bigF[l] + bigFl[l] / 1e7;
-          if (smallF[l]) cost += 25.0 + 1.0 * smallF[l] + smallFl[l] / 2e6;
+          if (bigF[l]) cost += 77.0 + 0.33 * bigF[l] + bigFl[l] / 1e7;
+          else if (smallF[l]) cost += 50.0 + 1.0 * smallF[l] + smallFl[l] / 2e6;   // (beside blocked fronts they ride in their launches)
         }
+        if (n_tree > 0) {
+          cost += std::max(chain[0], work[0] / 1024.0) + 10.0;
+          cost += std::max(chain[1], work[1] / 256.0) + 10.0;
+          cost += std::max(7.0 * bs_depth, 7.0 * n_tree / 1280.0) + 10.0;
+        }
+        if (std::getenv("GSX_AMAL_TRACE"))
+          fprintf(stderr, "[amalgamation] relax %.3f maxF %3d: cost %.0f us (levels %d, tree fronts %.0f, tiers %.0f|%.0f / %.0f|%.0f, depth %d)\n",
+                  rx, mf, cost, nl, n_tree, chain[0], work[0] / 1024, chain[1], work[1] / 256, bs_depth);
         if (first || cost < best_cost) {
           first = false;
           best_cost = cost;

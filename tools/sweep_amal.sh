@@ -3,7 +3,7 @@
 wl=$1; shift; cfg=$1; shift
 mkdir -p gpurun_out/r03
 for am in "$@"; do
-  GSX_TREE_TIERS=$cfg timeout -k 10 200 python bench.py --workload $wl --no-cpu-baseline --no-secondary --steps 10 --amalgamation $am > /tmp/sw.json 2>/tmp/sw.err || { echo "$am FAILED"; tail -3 /tmp/sw.err; continue; }
+  GSX_TREE_TIERS=$cfg timeout -k 10 200 python bench.py --workload $wl --no-cpu-baseline --no-secondary --steps 10 --amalgamation $am $EXTRA > /tmp/sw.json 2>/tmp/sw.err || { echo "$am FAILED"; tail -3 /tmp/sw.err; continue; }
   python - "$am" <<'PY' | tee -a gpurun_out/r03/sweep_amal_$wl.txt
 import json, sys
 d = json.load(open("/tmp/sw.json"))
