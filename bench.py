@@ -374,7 +374,8 @@ def main():
             shard_rank, shard_world = 0, args.shard_share
         else:
             # (a known-answer run of the in-place RCCL path first; all ranks fall back to a bounce buffer together if it fails)
-            inner, exchange_path = D.checked_allreduce(dist, torch.device("cuda", device))
+            pp, pn = be.shard_probe_buffer()   # the known-answer run happens on memory the LIBRARY allocated
+            inner, exchange_path = D.checked_allreduce(dist, torch.device("cuda", device), probe_ptr=pp, probe_count=pn)
             shard_rank, shard_world = rank, world
 
         def allreduce(ptr, count):

@@ -45,9 +45,10 @@ class GsxError(RuntimeError):
 class IndeterminantLinearSystemException(GsxError):
     """gtsam/linear/linearExceptions.h:94-97 — carries a key of the failing clique."""
 
-    def __init__(self, key: int, what: str = "solve"):
-        self.key = key
-        super().__init__(GSX_E_INDETERMINATE, what, f"near variable {key}")
+    def __init__(self, key, what: str = "solve", detail: str = ""):
+        self.key = key   # None when the entry point does not report one
+        near = f"near variable {key}" if key is not None else "(no variable reported by this entry point)"
+        super().__init__(GSX_E_INDETERMINATE, what, (near + " " + detail).strip())
 
 
 _p = C.POINTER
@@ -232,15 +233,16 @@ class Backend:
         f.restype = restype
         return f
 
-    def _check(self, st, what):
+    def _check(self, st, what, key=None):
+        if st == GSX_OK:
+            return
+        detail = ""
+        if self._pfx == "gsx_":
+            f = self._fn("last_error", C.c_char_p)
+            detail = (f(self._h) or b"").decode()
         if st == GSX_E_INDETERMINATE:   # IndeterminantLinearSystemException wherever a factorization is involved
-            raise IndeterminantLinearSystemException(0, self._pfx + what)
-        if st != GSX_OK:
-            detail = ""
-            if self._pfx == "gsx_":
-                f = self._fn("last_error", C.c_char_p)
-                detail = (f(self._h) or b"").decode()
-            raise GsxError(st, self._pfx + what, detail)
+            raise IndeterminantLinearSystemException(key, self._pfx + what, detail)
+        raise GsxError(st, self._pfx + what, detail)
 
     def close(self):
         if self._h:
@@ -401,7 +403,7 @@ class Backend:
                                          C.c_double(relative_error_tol), C.c_double(absolute_error_tol),
                                          C.c_double(error_tol), C.byref(r))
         if st == GSX_E_INDETERMINATE:
-            raise IndeterminantLinearSystemException(0, self._pfx + "dogleg_optimize")
+            raise IndeterminantLinearSystemException(None, self._pfx + "dogleg_optimize")
         self._check(st, "dogleg_optimize")
         return self._result_dict(r, tr)
 
@@ -411,6 +413,6 @@ class Backend:
         st = self._fn("gn_optimize")(self._h, C.c_int32(max_iterations), C.c_double(relative_error_tol),
                                      C.c_double(absolute_error_tol), C.c_double(error_tol), C.byref(r))
         if st == GSX_E_INDETERMINATE:
-            raise IndeterminantLinearSystemException(0, self._pfx + "gn_optimize")
+            raise IndeterminantLinearSystemException(None, self._pfx + "gn_optimize")
         self._check(st, "gn_optimize")
         return self._result_dict(r, tr)

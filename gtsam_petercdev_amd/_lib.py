@@ -85,6 +85,14 @@ class ProductBackend(A.Backend):
         self._check(self._fn("set_shard")(self._h, C.c_int32(rank), C.c_int32(world), self._shard_cb, None),
                     "set_shard")
 
+    def shard_probe_buffer(self):
+        """(device address, doubles) of a buffer the library hipMalloc'd itself and that holds nothing between calls — what
+        distributed.checked_allreduce probes the in-place collective on (gsx_scratch_buffer)."""
+        ptr = C.POINTER(C.c_double)()
+        n = C.c_int64()
+        self._check(self._fn("scratch_buffer")(self._h, C.byref(ptr), C.byref(n)), "scratch_buffer")
+        return C.cast(ptr, C.c_void_p).value, n.value
+
     def shard_info(self):
         """(info dict, front_owner[n_fronts] with -1 = cap, factor_owned[n_factors]) of the current ordering."""
         info = ShardInfo()
@@ -119,9 +127,10 @@ class ProductBackend(A.Backend):
         cnt = C.c_int64()
         bad = C.c_uint64()
         ptr = out.ctypes.data_as(C.POINTER(C.c_double)) if want_delta else None
-        self._check(self._fn("backsubstitute_wildfire")(self._h, C.c_double(threshold), ptr,
-                                                        C.c_int64(self.tangent_size if want_delta else 0),
-                                                        C.byref(cnt), C.byref(bad)), "backsubstitute_wildfire")
+        st = self._fn("backsubstitute_wildfire")(self._h, C.c_double(threshold), ptr,
+                                                 C.c_int64(self.tangent_size if want_delta else 0),
+                                                 C.byref(cnt), C.byref(bad))
+        self._check(st, "backsubstitute_wildfire", key=bad.value)
         return out, cnt.value
 
     def get_ordering(self) -> np.ndarray:
@@ -141,9 +150,19 @@ class ProductBackend(A.Backend):
             raise ValueError("factor_origin must have one entry per factor of the updated graph")
         desc = arrays.desc()
         st = UpdateStats()
-        self._check(self._fn("update")(self._h, C.byref(desc), fo.ctypes.data_as(C.POINTER(C.c_int32)),
-                                       nv.ctypes.data_as(C.POINTER(C.c_double)) if nv.size else None,
-                                       C.c_int64(nv.size), C.byref(st)), "update")
+        try:
+            self._check(self._fn("update")(self._h, C.byref(desc), fo.ctypes.data_as(C.POINTER(C.c_int32)),
+                                           nv.ctypes.data_as(C.POINTER(C.c_double)) if nv.size else None,
+                                           C.c_int64(nv.size), C.byref(st)), "update")
+        except A.GsxError:
+            # a failure before the switch leaves the handle as it was; one in the middle of it leaves the NEW problem
+            # with every state flag dropped (set_values + set_ordering rebuild it): follow whichever the handle holds
+            if int(self._fn("state_size", C.c_int64)(self._h)) == int(arrays.values.size) != int(self.arrays.values.size):
+                self.arrays, self._desc = arrays, desc
+                self.state_size = int(arrays.values.size)
+                self.tangent_size = int(self._fn("tangent_size", C.c_int64)(self._h))
+                self.jacobian_size = int(self._fn("jacobian_size", C.c_int64)(self._h))
+            raise
         self.arrays, self._desc = arrays, desc
         self.state_size = int(self._fn("state_size", C.c_int64)(self._h))
         self.tangent_size = int(self._fn("tangent_size", C.c_int64)(self._h))

@@ -901,7 +901,15 @@ void side_join(gsx_context* c, unsigned used) {
 // by the next readback
 void shard_allreduce(gsx_context* c, double* dptr, int64_t n) {
   if (!c->sharded() || n <= 0) return;
-  if (hipStreamSynchronize(c->stream) != hipSuccess || c->shard_cb(c->shard_user, dptr, n) != 0) c->shard_failed = true;
+  // A rank whose own stream has failed still ENTERS the collective — its peers are in it, and skipping it would leave
+  // them blocked until the backend's timeout — with its share poisoned by NaNs, so that every rank sees the failure in
+  // the sum (non-finite pivots / solution => GSX_E_INDETERMINATE there, the latched failure here).
+  if (hipStreamSynchronize(c->stream) != hipSuccess) {
+    c->shard_failed = true;
+    (void)hipGetLastError();
+    (void)hipMemset(dptr, 0xFF, (size_t)n * sizeof(double));   // (all-ones bytes are a NaN)
+  }
+  if (c->shard_cb(c->shard_user, dptr, n) != 0) c->shard_failed = true;
 }
 
 // ---- device pipeline pieces (all asynchronous) -------------------------------------------------------
@@ -1474,6 +1482,15 @@ gsx_status gsx_get_shard(gsx_handle h, gsx_shard_info* info, int32_t* front_owne
     for (int f = 0; f < S.n_fronts; ++f) front_owner[f] = S.owner[f];
   if (factor_owned)
     for (int f = 0; f < h->P.n_factors; ++f) factor_owned[f] = S.f_owned[f];
+  return GSX_OK;
+}
+
+gsx_status gsx_scratch_buffer(gsx_handle h, double** device_ptr, int64_t* count) {
+  if (!h || !device_ptr || !count) return GSX_E_INVALID;
+  gsx_status st = need_device(h);
+  if (st != GSX_OK) return st;
+  *device_ptr = h->d_partials.p;   // (rewritten from scratch by every reduction that uses it)
+  *count = gsx_context::kPartials;
   return GSX_OK;
 }
 
@@ -2246,7 +2263,7 @@ gsx_status partial_factor(gsx_handle h, std::vector<int>& dfr) {
 }
 }  // namespace
 
-gsx_status gsx_relinearize_partial(gsx_handle h, const uint64_t* keys, int32_t n_keys, const double* states,
+static gsx_status gsx_relinearize_partial_impl(gsx_handle h, const uint64_t* keys, int32_t n_keys, const double* states,
                                    int64_t n_states, gsx_partial_stats* out) {
   if (!h || (n_keys > 0 && !keys) || n_keys < 0) return GSX_E_INVALID;
   gsx_status st = ensure_ready(h, true, true);
@@ -2349,7 +2366,7 @@ gsx_status gsx_relinearize_partial(gsx_handle h, const uint64_t* keys, int32_t n
 
 // ISAM2::update's structural part on a live handle (include/gsx.h).  The numeric state that survives: the values of the
 // kept variables and the [A b] blocks of the kept factors (iSAM2's fixed linearization point).
-gsx_status gsx_update(gsx_handle h, const gsx_problem_desc* desc, const int32_t* factor_origin, const double* new_values,
+static gsx_status gsx_update_impl(gsx_handle h, const gsx_problem_desc* desc, const int32_t* factor_origin, const double* new_values,
                       int64_t n_new_values, gsx_update_stats* out) {
   if (!h || !desc || (desc->n_factors > 0 && !factor_origin)) return GSX_E_INVALID;
   gsx_status st = need_device(h);
@@ -2462,9 +2479,22 @@ gsx_status gsx_update(gsx_handle h, const gsx_problem_desc* desc, const int32_t*
     std::stable_sort(aff.begin(), aff.end(), [&](int a, int b) { return deg[a] < deg[b]; });
     ord.insert(ord.end(), aff.begin(), aff.end());
   }
-  // switch the handle over
+  // the new tree, on the host, before anything of the handle is touched: a failure up to here leaves the handle as it was
   const double relax = h->S.relax;
   const int relax_max_f = h->S.relax_max_f;
+  const auto ta = std::chrono::steady_clock::now();
+  Symbolic S2;
+  st = symbolic_analysis(P2, ord, relax, relax_max_f, 0, 1, S2, h->err);
+  if (st != GSX_OK) return st;
+  const double t_symbolic = std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
+  // switch the handle over.  From here on a failure (an allocation at config-5 sizes, a copy) leaves device tables of two
+  // different graphs behind: every state flag is dropped first and set again only after the last upload, so that a
+  // failed update makes every later numeric call answer GSX_E_STATE until gsx_set_values + gsx_set_ordering rebuild the
+  // handle — never kernels on mismatched tables.
+  h->has_symbolic = h->values_set = h->linearized = h->h_ready = h->solved = false;
+  h->fact_valid = h->fact_pending = h->hdiag_ready = h->damp_ready = false;
+  h->wf_delta_valid = false;
+  h->wf_all_replaced = true;
   HostProblem P_old = std::move(h->P);
   DevBuf<double> jac_old;
   std::swap(jac_old.p, h->d_jac.p);
@@ -2475,9 +2505,11 @@ gsx_status gsx_update(gsx_handle h, const gsx_problem_desc* desc, const int32_t*
   const HostProblem& P = h->P;
   st = upload_problem(h);
   if (st != GSX_OK) return st;
+  if (std::getenv("GSX_INJECT_UPDATE_FAILURE")) {   // (tests/test_gpu_update.py: a failure in the middle of the switch)
+    h->err = "gsx_update: injected failure";
+    return GSX_E_NOMEM;
+  }
   HIPCHK(h, hipMemcpyAsync(h->d_values.p, vals2.data(), (size_t)P.state_size * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  h->values_set = true;
-  h->values_synced = true;
   if (keep_jac) {
     // kept [A b] blocks, device to device, contiguous runs merged
     int64_t src0 = 0, dst0 = 0, len0 = 0;
@@ -2505,26 +2537,34 @@ gsx_status gsx_update(gsx_handle h, const gsx_problem_desc* desc, const int32_t*
   const auto t1 = std::chrono::steady_clock::now();
   h->relax = relax;
   h->relax_max_f = relax_max_f;
-  st = symbolic_analysis(h->P, ord, h->relax, h->relax_max_f, 0, 1, h->S, h->err);
-  if (st != GSX_OK) return st;
+  h->S = std::move(S2);
   h->order = ord;
-  h->has_symbolic = true;
   st = upload_symbolic(h);
   if (st != GSX_OK) return st;
   const auto t2 = std::chrono::steady_clock::now();
-  h->linearized = h->h_ready = h->solved = h->fact_valid = false;
-  h->hdiag_ready = h->damp_ready = false;
+  h->has_symbolic = true;   // (partial_linearize below needs the tables; the other flags follow at the very end)
+  h->values_set = true;
+  h->values_synced = true;
+  bool relinearized = false;
   if (keep_jac) {
     std::vector<int> dfac;
     for (int f = 0; f < P.n_factors; ++f)
       if (factor_origin[f] < 0) dfac.push_back(f);
     hipMemsetAsync(&h->d_status.p->n_cheirality, 0, sizeof(int), h->stream);
     st = partial_linearize(h, dfac);
-    if (st != GSX_OK) return st;
+    if (st != GSX_OK) {
+      h->has_symbolic = h->values_set = false;
+      return st;
+    }
     h->sc_dirty |= kXLin;
-    h->linearized = true;  // every factor has its [A b]: the kept ones at their old linearization point
+    relinearized = true;  // every factor has its [A b]: the kept ones at their old linearization point
   }
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (hipStreamSynchronize(h->stream) != hipSuccess) {
+    h->has_symbolic = h->values_set = false;
+    h->err = "gsx_update: device failure";
+    return GSX_E_NO_DEVICE;
+  }
+  h->linearized = relinearized;
   const auto t3 = std::chrono::steady_clock::now();
   if (out) {
     int n_aff = 0;
@@ -2532,7 +2572,7 @@ gsx_status gsx_update(gsx_handle h, const gsx_problem_desc* desc, const int32_t*
     auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
       return std::chrono::duration<double>(b - a).count();
     };
-    *out = gsx_update_stats{n_added, n_vrem, n_fadd, n_frem, n_aff, h->S.n_fronts, sec(t1, t2), sec(t0, t1) + sec(t2, t3)};
+    *out = gsx_update_stats{n_added, n_vrem, n_fadd, n_frem, n_aff, h->S.n_fronts, t_symbolic + sec(t1, t2), sec(t0, t1) + sec(t2, t3)};
   }
   return GSX_OK;
 }
@@ -2670,9 +2710,9 @@ gsx_status gsx_marginal_covariance(gsx_handle h, uint64_t key, double* out, int6
   return GSX_OK;
 }
 
-gsx_status gsx_set_block_jacobians(gsx_handle h, int32_t first_factor, int32_t n_factors, const double* values,
+static gsx_status gsx_set_block_jacobians_impl(gsx_handle h, int32_t first_factor, int32_t n_factors, const double* values,
                                    int64_t n_values) {
-  if (!h || !values || first_factor < 0 || n_factors < 0 || first_factor + n_factors > h->P.n_factors) return GSX_E_INVALID;
+  if (!h || !values || first_factor < 0 || n_factors < 0 || (int64_t)first_factor + (int64_t)n_factors > (int64_t)h->P.n_factors) return GSX_E_INVALID;
   gsx_status st = need_device(h);
   if (st != GSX_OK) return st;
   const HostProblem& P = h->P;
@@ -2737,7 +2777,7 @@ gsx_status gsx_solve_gfg_h(gsx_handle h, const double* blocks, int64_t n_blocks,
   return gsx_solve(h, 0.0, 0, 0, 0, delta_out, n, bad_key);
 }
 
-gsx_status gsx_get_conditional(gsx_handle h, int32_t front, int32_t* n_frontal, int32_t* n_cols, double* out,
+static gsx_status gsx_get_conditional_impl(gsx_handle h, int32_t front, int32_t* n_frontal, int32_t* n_cols, double* out,
                                int64_t n_out) {
   if (!h) return GSX_E_INVALID;
   gsx_status st = ensure_ready(h, false, true);
@@ -2835,6 +2875,36 @@ gsx_status gsx_cholesky_partial(double* abc, int32_t n, int32_t nfrontal, int32_
   for (int c = 0; c < n; ++c)
     for (int r = 0; r <= c; ++r) abc[(size_t)c * n + r] = a[(size_t)r * n + c];
   return GSX_OK;
+}
+
+
+// No exception crosses the C boundary (include/gsx.h): the entry points whose work is sized by caller input (host vectors
+// of the plans, staging buffers) answer an allocation failure with a status, like the readers in io.cpp.
+#define GSX_GUARD(h, call)                          \
+  try {                                             \
+    return (call);                                  \
+  } catch (const std::bad_alloc&) {                 \
+    if (h) (h)->err = "out of host memory";         \
+    return GSX_E_NOMEM;                             \
+  } catch (const std::exception& e) {               \
+    if (h) (h)->err = e.what();                     \
+    return GSX_E_INVALID;                           \
+  }
+gsx_status gsx_set_block_jacobians(gsx_handle h, int32_t first_factor, int32_t n_factors, const double* values,
+                                   int64_t n_values) {
+  GSX_GUARD(h, gsx_set_block_jacobians_impl(h, first_factor, n_factors, values, n_values));
+}
+gsx_status gsx_update(gsx_handle h, const gsx_problem_desc* desc, const int32_t* factor_origin, const double* new_values,
+                      int64_t n_new_values, gsx_update_stats* out) {
+  GSX_GUARD(h, gsx_update_impl(h, desc, factor_origin, new_values, n_new_values, out));
+}
+gsx_status gsx_get_conditional(gsx_handle h, int32_t front, int32_t* n_frontal, int32_t* n_cols, double* out,
+                               int64_t n_out) {
+  GSX_GUARD(h, gsx_get_conditional_impl(h, front, n_frontal, n_cols, out, n_out));
+}
+gsx_status gsx_relinearize_partial(gsx_handle h, const uint64_t* keys, int32_t n_keys, const double* states,
+                                   int64_t n_states, gsx_partial_stats* out) {
+  GSX_GUARD(h, gsx_relinearize_partial_impl(h, keys, n_keys, states, n_states, out));
 }
 
 gsx_status gsx_get_stats(gsx_handle h, gsx_stats* out) {

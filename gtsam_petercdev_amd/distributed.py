@@ -78,25 +78,33 @@ def torch_allreduce(dist, device, group=None, bounce=False):
     return allreduce
 
 
-def checked_allreduce(dist, device, group=None):
+def checked_allreduce(dist, device, group=None, probe_ptr=None, probe_count=0):
     """torch_allreduce, after a known-answer run of the in-place path on every rank (a buffer of rank + 1 must come back
-    as world (world + 1) / 2 everywhere).  The in-place RCCL path aliases memory that torch did not allocate; if any rank
-    sees a wrong sum or an exception there, ALL ranks switch to the bounce-buffer variant together (the verdict itself
-    travels through an ordinary tensor).  Returns (allreduce, "in_place" | "bounce" | "staged")."""
+    as world (world + 1) / 2 everywhere).  The hazard is RCCL reducing in place on memory that torch did NOT allocate
+    (the library's hipMalloc'd arena, aliased through __cuda_array_interface__): pass `probe_ptr` / `probe_count` — a
+    device range owned by the library that holds nothing yet, e.g. ProductBackend.shard_probe_buffer() — and the probe runs
+    on exactly that memory; without it the probe is a torch tensor and only checks the collective itself.  If any rank
+    sees a wrong sum, ALL ranks switch to the bounce-buffer variant together (the verdict travels through an ordinary
+    tensor).  An EXCEPTION inside a collective is fatal for the group — the peers are still inside it — and is re-raised:
+    the launcher (torch.distributed.run) tears the job down.  Returns (allreduce, "in_place" | "bounce" | "staged")."""
     import torch
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if dist.get_backend(group) != "nccl":
         return torch_allreduce(dist, device, group), "staged"
-    ok = 1
-    try:
+    if probe_ptr is not None and probe_count > 0:
+        n = int(min(probe_count, 1024))
+        view = torch.as_tensor(_DeviceDoubles(int(probe_ptr), n), device=device)
+        view.fill_(float(rank + 1))
+        torch.cuda.synchronize(device)
+        torch_allreduce(dist, device, group)(int(probe_ptr), n)
+        ok = int(bool(torch.all(view == world * (world + 1) / 2).item()))
+        view.zero_()
+    else:
         probe = torch.full((1024,), float(rank + 1), dtype=torch.float64, device=device)
         torch.cuda.synchronize(device)
         torch_allreduce(dist, device, group)(probe.data_ptr(), probe.numel())
-        if not bool(torch.all(probe == world * (world + 1) / 2).item()):
-            ok = 0
-    except Exception:   # noqa: BLE001 — any failure here means "do not trust the in-place path"
-        ok = 0
+        ok = int(bool(torch.all(probe == world * (world + 1) / 2).item()))
     flag = torch.tensor([ok], dtype=torch.int32, device=device)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
     if int(flag.item()) == 1:

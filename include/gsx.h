@@ -331,6 +331,11 @@ typedef struct gsx_shard_info {
 /* partition of the current ordering: front_owner[n_fronts] = owning rank or -1 (cap), factor_owned[n_factors] = 1
  * when this rank linearizes the factor; either array may be NULL */
 gsx_status gsx_get_shard(gsx_handle h, gsx_shard_info* info, int32_t* front_owner, int32_t* factor_owned);
+/* A device buffer the library allocated itself (hipMalloc) that holds nothing between calls: what a host probes its
+ * all-reduce on before trusting it with the cap (the hazard is a collective library reducing IN PLACE on memory it did
+ * not allocate; gtsam_petercdev_amd/distributed.py: checked_allreduce).  *count doubles at *device_ptr; the host may
+ * overwrite them freely between gsx calls. */
+gsx_status gsx_scratch_buffer(gsx_handle h, double** device_ptr, int64_t* count);
 gsx_status gsx_get_ordering(gsx_handle h, uint64_t* keys_out);
 /* Bayes-tree structure for parity checks: per front the frontal / separator
  * variable indices (CSR) and the parent front (-1 = root).  Pass NULL arrays to

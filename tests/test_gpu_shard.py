@@ -139,6 +139,15 @@ assert float(buf[999]) == 999.0
 # the known-answer check bench.py runs before it trusts the in-place path, and the bounce-buffer fallback
 fn, path = D.checked_allreduce(dist, dev)
 assert path == "in_place"
+# ... and on memory the LIBRARY hipMalloc'd (gsx_scratch_buffer), which is what the cap lives in
+from gtsam_petercdev_amd import _lib, datasets
+be = _lib.product_backend(datasets.synth_manhattan_pose2(50, seed=1))
+pp, pn = be.shard_probe_buffer()
+assert pp and pn >= 1024
+fn2, path2 = D.checked_allreduce(dist, dev, probe_ptr=pp, probe_count=pn)
+assert path2 == "in_place"
+be.set_ordering(be.compute_ordering(2))
+assert be.error() > 0                               # the scratch buffer is still the library's to use
 bounce = D.torch_allreduce(dist, dev, bounce=True)
 before = buf.clone()
 bounce(buf.data_ptr(), 1000)

@@ -176,6 +176,41 @@ def test_update_argument_checks(gpu):
     assert gb.error() > 0
 
 
+def test_failed_update_poisons_the_handle_instead_of_leaving_mismatched_tables(gpu, monkeypatch):
+    """a failure in the middle of gsx_update's switch (injected here where an allocation would fail at
+    config-5 sizes) must not leave a handle that still claims an ordering / a factorization for tables of two different
+    graphs: every later numeric call is refused (GSX_E_STATE) until values and ordering are set again — and then it works."""
+    from gtsam_petercdev_amd import GsxError
+    steps = list(_grow(n_poses=4, n_points=20, seed=5))
+    f1, i1 = steps[1]
+    arr = _arrays(f1, i1)
+    gb = gpu.product_backend(arr)
+    gb.set_ordering(gb.compute_ordering(A.ORDER_SCHUR_ND))
+    gb.linearize()
+    gb.solve(1e-3, False)
+    f2, i2 = steps[2]
+    arr2 = _arrays(f2, i2)
+    origin = list(range(len(f1))) + [-1] * (len(f2) - len(f1))
+    monkeypatch.setenv("GSX_INJECT_UPDATE_FAILURE", "1")
+    with pytest.raises(GsxError) as e:
+        gb.update(arr2, origin, _new_states(arr2, arr.var_keys))
+    assert e.value.status == A.GSX_E_NOMEM
+    monkeypatch.delenv("GSX_INJECT_UPDATE_FAILURE")
+    for call in (lambda: gb.solve(1e-3, False), gb.linearize, gb.error, lambda: gb.marginal_covariance(int(arr.var_keys[0]))):
+        with pytest.raises(GsxError) as e:
+            call()
+        assert e.value.status == A.GSX_E_STATE
+    # the handle now holds the NEW problem (the wrapper followed it): values + ordering make it whole again
+    assert gb.arrays is arr2
+    gb.set_values(arr2.values)
+    gb.set_ordering(gb.compute_ordering(A.ORDER_SCHUR_ND))
+    fresh = gpu.product_backend(arr2)
+    fresh.set_ordering(gb.get_ordering())
+    gb.linearize()
+    fresh.linearize()
+    assert np.array_equal(gb.solve(1e-3, False), fresh.solve(1e-3, False))
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_update_on_random_growth(gpu, seed):
     """Structure fuzz: a random Pose2 graph (chain, chords, a hub) revealed a few variables at a time, with random factors

@@ -450,6 +450,32 @@ def test_host_code_under_address_sanitizer(golden_dir, tmp_path):
     assert run.stdout.count(" ok") == 7
 
 
+# ---- the GTSAM-side shim is real code: a compiler sees it against the reference's own headers ----------------------------
+def test_integration_shim_parses_against_the_reference_headers(tmp_path):
+    """integration/gsx_shim.h (the binding a GTSAM maintainer adds: GsxLevenbergMarquardtOptimizer overriding solve /
+    iterate, the lowering table) goes through `g++ -fsyntax-only` against the headers of /root/reference and include/gsx.h.
+    Syntax and types only — nothing of the reference is built or linked; the two headers its cmake would generate
+    (gtsam/config.h, gtsam/dllexport.h) are replaced by a dozen defines written here into a temporary directory.  Skipped
+    where the reference tree is absent (the GPU box)."""
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "gtsam", "nonlinear")):
+        pytest.skip("reference tree absent")
+    inc = tmp_path / "gtsam"
+    inc.mkdir()
+    (inc / "config.h").write_text(
+        "#pragma once\n#define GTSAM_VERSION_MAJOR 4\n#define GTSAM_VERSION_MINOR 3\n#define GTSAM_VERSION_PATCH 0\n"
+        "#define GTSAM_VERSION_NUMERIC 40300\n#define GTSAM_VERSION_STRING \"4.3.0\"\n#define GTSAM_ALLOCATOR_STL\n"
+        "#define GTSAM_THROW_CHEIRALITY_EXCEPTION\n#define GTSAM_ROT3_EXPMAP\n#define GTSAM_POSE3_EXPMAP\n"
+        "#define GTSAM_EIGEN_VERSION_WORLD 3\n#define GTSAM_EIGEN_VERSION_MAJOR 4\n#define GTSAM_USE_EIGEN_MKL 0\n")
+    (inc / "dllexport.h").write_text("#pragma once\n#define GTSAM_EXPORT\n#define GTSAM_EXTERN_EXPORT extern\n")
+    src = tmp_path / "shim_tu.cpp"
+    src.write_text('#include "gsx_shim.h"\nint main() { return 0; }\n')
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", f"-I{tmp_path}", f"-I{ref}", f"-I{ref}/gtsam/3rdparty/Eigen",
+           f"-I{ROOT}/include", f"-I{ROOT}/integration", str(src)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+
+
 # ---- the library's own nested dissection against the reference's CCOLAMD (SURVEY §8 a21) ------------------------------------
 def _tree_cost(be, dims):
     """(factor flops sum f^3/3 + f^2 (s+1) + f (s+1)^2, height of the Bayes tree in cliques) of the handle's tree."""
