@@ -132,45 +132,39 @@ def self_launch(args):
     sys.exit(rc if rc != 0 or line is not None else 1)
 
 
-def front_split(be, arrays, small_max_n=140, leaf_max_f=16, tile=32, leaf_max_panel=8192, mine=None, force_big=None):
-    """Algorithmic bytes / flops of the factorization split by kernel class (the class rules mirror
-    csrc/symbolic.cpp).  A materialised front moves 8 n^2 bytes; a LEAN leaf (childless, f <= 16, big parent) is the
-    "fused landmark elimination" of §8(d): its Schur complement never exists, so it moves its H panel in and its L
-    panel out (16 n f bytes) and the parent's gather reads that L panel once more.
-    mine / force_big (bool per front): a sharded rank's share — only the fronts of its own subtrees and the cap
-    (which every rank factors, in the blocked class) are counted."""
+def front_split(be, arrays, tile=32, mine=None):
+    """Algorithmic bytes / flops of the factorization split by kernel class; the class of every front is
+    the library's own (gsx_get_front_classes).  A front whose square is materialised moves 8 n^2 bytes; a LEAN leaf
+    (childless, f <= 16, blocked parent) is the "fused landmark elimination" of §8(d): its Schur complement never exists, so
+    it moves its H panel in and its L panel out (16 n f bytes) and the parent's gather reads that L panel once more.
+    "small" = the LDS-class fronts incl. the medium ones (frontal panel in LDS, trailing block in HBM).
+    mine (bool per front): a sharded rank's share — only the fronts it processes (own subtrees + cap) are counted."""
     parent, fronts = be.get_tree()
+    cls_bits = be.front_classes()
     dims = arrays.var_dims
     nfr = len(fronts)
-    has_child = np.zeros(nfr, bool)
-    for p in parent:
-        if p >= 0:
-            has_child[p] = True
     F = np.array([float(dims[fv].sum()) for fv, _ in fronts])
     S1 = np.array([float(dims[sv].sum()) + 1.0 for _, sv in fronts])
     N = F + S1
-    sep_ok = np.array([bool(np.all(dims[sv] <= 16)) if len(sv) else True for _, sv in fronts])
+    kind = cls_bits & 3          # 0 leaf kernel, 1 LDS, 2 blocked, 3 medium
+    lean = (cls_bits & 8) != 0
+    big = kind == 2
     out = dict(lpanel_bytes=0.0, big_syrk_flops=0.0, big_trsm_flops=0.0, big_potrf_flops=0.0, gather_bytes=0.0,
-               n_lean=0)
+               n_lean=0, n_medium=0, n_tree=0)
     for k in ("leaf", "small", "big"):
         out.update({k + "_bytes": 0.0, k + "_flops": 0.0, "n_" + k: 0})
-    lean = np.zeros(nfr, bool)
-    big = N > small_max_n
-    if force_big is not None:
-        big = big | force_big
     for i in range(nfr):
-        f, s1, n = F[i], S1[i], N[i]
-        p = parent[i]
-        lean[i] = (not has_child[i] and 0 < f <= leaf_max_f and p >= 0 and big[p] and n * f <= leaf_max_panel
-                   and sep_ok[i] and not big[i])
         if mine is not None and not mine[i]:
             continue
+        f, s1, n = F[i], S1[i], N[i]
         fl = f ** 3 / 3 + f * f * s1 + f * s1 * s1
-        k = "leaf" if lean[i] else ("big" if big[i] else ("leaf" if (not has_child[i] and f <= leaf_max_f) else "small"))
+        k = ("leaf", "small", "big", "small")[kind[i]]
         out[k + "_bytes"] += 16.0 * n * f if lean[i] else 8.0 * n * n
         out[k + "_flops"] += fl
         out["n_" + k] += 1
         out["n_lean"] += int(lean[i])
+        out["n_medium"] += int(kind[i] == 3)
+        out["n_tree"] += int((cls_bits[i] & 4) != 0)
         out["lpanel_bytes"] += 8.0 * f * n
         if k == "big":  # blocked path (csrc/bigfront.hip), rounds of <= 192 frontal columns: flops of each kernel
             nch = int(np.ceil(f / 192.0))
@@ -470,7 +464,7 @@ def main():
     st_prof = be.stats()
     if sharded:   # this rank's share: its own subtrees + the cap (which every rank factors, in the blocked class)
         _, f_owner, _ = be.shard_info()
-        split = front_split(be, arrays, mine=(f_owner == shard_rank) | (f_owner < 0), force_big=(f_owner < 0))
+        split = front_split(be, arrays, mine=(f_owner == shard_rank) | (f_owner < 0))
     else:
         split = front_split(be, arrays)
     nfac = max(st_prof["n_factorize"], 1)
@@ -480,7 +474,7 @@ def main():
     # factorization — bytes for "hbm", flops for "mfma")
     kernels = [
         ("factor_leaf", "front_leaf_kernel", "hbm", split["leaf_bytes"]),
-        ("factor_small", "front_small_kernel", "hbm", split["small_bytes"]),
+        ("factor_small", "front_small_kernel (+front_tree, front_medium)", "hbm", split["small_bytes"]),
         ("big_diag", "big_diag_kernel", "mfma", split["big_potrf_flops"]),
         ("big_rows", "big_rows_kernel", "mfma", split["big_trsm_flops"]),
         ("big_schur", "big_schur_kernel", "mfma", split["big_syrk_flops"]),
@@ -510,7 +504,7 @@ def main():
                     launches_per_factorization=dk["launches_per_factorization"],
                     avg_launch_ms=dk["avg_launch_ms"], algorithmic_per_launch=per_launch)
     tot_leaf = per_kernel["front_leaf_kernel"]["ms_per_factorization"]
-    tot_small = per_kernel["front_small_kernel"]["ms_per_factorization"]
+    tot_small = per_kernel["front_small_kernel (+front_tree, front_medium)"]["ms_per_factorization"]
     tot_big = sum(per_kernel[k]["ms_per_factorization"] for k in per_kernel if k.startswith("big_"))
 
     out = {
@@ -528,7 +522,7 @@ def main():
         "phases_ms": phases,
         "factor_leaf_ms": tot_leaf, "factor_small_ms": tot_small, "factor_big_ms": tot_big,
         "symbolic": {k: st[k] for k in ("n_fronts", "n_levels", "max_front_dim", "max_front_rows", "n_small_fronts",
-                                        "n_big_fronts", "factor_flops", "front_bytes", "lpanel_bytes",
+                                        "n_big_fronts", "n_medium_fronts", "n_tree_fronts", "factor_flops", "front_bytes", "lpanel_bytes",
                                         "jacobian_bytes", "hessian_bytes", "total_dim")},
         "front_split": split, "kernels": per_kernel, "host_ordering_s": t_order, "host_symbolic_s": t_symbolic,
         "roofline": roofline,

@@ -96,7 +96,8 @@ class Stats(C.Structure):
                                      "ms_linearize", "ms_assemble_hessian", "ms_factorize", "ms_backsolve",
                                      "ms_linear_error", "ms_retract", "ms_error")]
         + [(n, C.c_int64) for n in ("n_linearize", "n_factorize", "n_backsolve", "n_error", "n_cheirality")]
-        + [("amalgamation_relax", C.c_double), ("amalgamation_max_frontal_dim", C.c_int64)]
+        + [("amalgamation_relax", C.c_double), ("amalgamation_max_frontal_dim", C.c_int64),
+           ("n_medium_fronts", C.c_int64), ("n_tree_fronts", C.c_int64)]
     )
 
     def as_dict(self):

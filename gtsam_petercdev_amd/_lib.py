@@ -85,6 +85,15 @@ class ProductBackend(A.Backend):
         self._check(self._fn("set_shard")(self._h, C.c_int32(rank), C.c_int32(world), self._shard_cb, None),
                     "set_shard")
 
+    def front_classes(self) -> np.ndarray:
+        """gsx_get_front_classes: per front, bits 0-1 = 0 leaf kernel / 1 LDS / 2 blocked / 3 medium, bit 2 = tree front,
+        bit 3 = lean leaf."""
+        n = C.c_int32()
+        self._check(self._fn("get_tree")(self._h, C.byref(n), None, None, None, None, None, None), "get_tree")
+        out = np.zeros(max(n.value, 1), np.int32)
+        self._check(self._fn("get_front_classes")(self._h, out.ctypes.data_as(C.POINTER(C.c_int32))), "get_front_classes")
+        return out[:n.value]
+
     def shard_probe_buffer(self):
         """(device address, doubles) of a buffer the library hipMalloc'd itself and that holds nothing between calls — what
         distributed.checked_allreduce probes the in-place collective on (gsx_scratch_buffer)."""

@@ -767,9 +767,11 @@ __device__ __forceinline__ void delta_store(double* p, double v) {
   if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else *p = v;
 }
-// LDS pool of one clique (doubles): xs[kBsSmallSep] | part[2][64] | three 32 x 33 tiles
+// LDS pool of one clique (doubles): xs[kBsSmallSep] | part[2][64] | three 32 x 33 tiles; the panel loop of a tall
+// (medium) clique keeps its kMedMaxN solution entries where the second and third tile would be
 constexpr int kBsTile = kBsSmallF * (kBsSmallF + 1);
 constexpr int kBsPool = kBsSmallSep + 4 * kBsSmallF + 3 * kBsTile;
+static_assert(2 * kBsTile >= kMedMaxN, "backsolve_panels_body: xs of a medium clique");
 template <bool COH>
 __device__ __forceinline__ void backsolve_small_body(const DevSymbolic& S, const int f, const double* arena, double* delta,
                                                      DevStatus* status, double* pool) {
@@ -946,9 +948,9 @@ template <bool COH>
 __device__ __forceinline__ void backsolve_panels_body(const DevSymbolic& S, const int f, const double* arena, double* delta,
                                                       DevStatus* status, double* pool) {
   constexpr int B = kBsSmallF;
-  double* xs = pool;                                   // n - 1 <= kBsSmallSep entries: frontal + separator
   double* y = pool + kBsSmallSep;                      // B
   double(*tile)[B + 1] = (double(*)[B + 1])(pool + kBsSmallSep + 4 * B);
+  double* xs = pool + kBsSmallSep + 4 * B + kBsTile;   // n - 1 <= kMedMaxN entries: frontal + separator
   const int n = S.fr_N[f], F = S.fr_F[f];
   const double* A = arena + S.fr_off[f];
   const int* gi = S.gidx + S.gidx_ptr[f];
@@ -1062,8 +1064,9 @@ __global__ void __launch_bounds__(256) backsolve_tree_kernel(DevSymbolic S, Back
     if (f < 0) return;   // (uniform: the list is exhausted)
     while (f >= 0) {
       const int F = S.fr_F[f];
-      if (F <= kBsSmallF) backsolve_small_body<true>(S, f, arena, delta, status, pool);
-      else if (F <= 2 * kBsSmallF) backsolve_small2_body<true>(S, f, arena, delta, status, pool);
+      const bool low = S.fr_N[f] - 2 <= kBsSmallSep;   // (the two straight-line kernels cover 144 separator rows)
+      if (low && F <= kBsSmallF) backsolve_small_body<true>(S, f, arena, delta, status, pool);
+      else if (low && F <= 2 * kBsSmallF) backsolve_small2_body<true>(S, f, arena, delta, status, pool);
       else backsolve_panels_body<true>(S, f, arena, delta, status, pool);
       __syncthreads();  // every store of the solution has drained (s_waitcnt vmcnt(0) before the barrier)
       // the first tree child (the deepest subtree: the host sorted them) is solved by this workgroup right away, the

@@ -15,6 +15,13 @@ constexpr int kTile = 32;           // tile edge of the blocked big-front path
 constexpr int kGatherChunk = 64;    // sources per gather segment: one wave, one source record per lane
 constexpr int kLeafMaxF = 16;      // leaf cliques with at most this many frontal scalars use the panel-only kernel
 constexpr int kLeafMaxPanel = 8192; // doubles of LDS (n x F) a lean leaf may use: 64 KB
+// MEDIUM fronts: more rows than fit LDS as a square, but whose n x F frontal panel does.  One workgroup eliminates such a
+// front with the panel in LDS and the trailing block in the arena (front_medium_body, kernels.hip); storage and class
+// (cls 1) are those of an LDS front, so parents, back-substitution, marginals read them unchanged.
+constexpr int kMedMaxN = 512;       // rows (two staged row maps of that many ints)
+constexpr int kMedMaxPanel = 18432; // doubles of LDS for the panel: 144 KB
+constexpr int kMedMaxLeafKids = 8;  // a front with more childless small children than this stays blocked: its leaves are
+                                    // LEAN only under a blocked parent (every BAL camera front: hundreds of landmarks)
 
 struct HostProblem {
   int n_vars = 0, n_factors = 0;
@@ -43,6 +50,7 @@ struct Symbolic {
   std::vector<int64_t> off;          // arena offset (doubles) of the n x n column-major front
   std::vector<int> level;            // 0 = leaves
   std::vector<char> cls, lean;       // size class (0 leaf kernel, 1 small, 2 big); lean leaf (no Schur complement stored)
+  std::vector<char> med;             // cls 1 with n > kSmallMaxN: a MEDIUM front (panel in LDS, trailing block in the arena)
   std::vector<int> child_ptr, children;  // CSR front -> children (in the reference's child order)
   // scalar row maps
   std::vector<int64_t> cmap_ptr;     // front -> offset in cmap of its (S+1) update-row -> parent-row map
@@ -112,7 +120,7 @@ struct Symbolic {
   double cap_cost = 0, own_cost = 0, total_cost = 0;  // flop estimates: cap, this rank's subtrees, whole tree
   // stats
   double flops = 0, front_bytes = 0, lpanel_bytes = 0;
-  int64_t max_F = 0, max_rows = 0, n_small = 0, n_big = 0;
+  int64_t max_F = 0, max_rows = 0, n_small = 0, n_big = 0, n_medium = 0;
 };
 
 // host algorithms

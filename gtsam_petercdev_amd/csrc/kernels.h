@@ -167,6 +167,13 @@ struct TreeArgs {
 };
 void launch_front_tree(const DevProblem& P, const DevSymbolic& S, const TreeArgs& T, int max_n, int threads, const double* H,
                        const double* damp, const double* scalars, double* arena, DevStatus* status, hipStream_t st);
+// MEDIUM fronts (gsx_internal.h), a workgroup each; LDS = (max_panel + max_n) doubles
+void launch_front_medium(const DevProblem& P, const DevSymbolic& S, const int* ids, int count, int max_panel, int max_n,
+                         const double* H, const double* damp, const double* scalars, double* arena, DevStatus* status,
+                         hipStream_t st);
+// the tree tier of the medium fronts (and of the LDS fronts above them)
+void launch_front_tree_med(const DevProblem& P, const DevSymbolic& S, const TreeArgs& T, size_t lds_bytes, const double* H,
+                           const double* damp, const double* scalars, double* arena, DevStatus* status, hipStream_t st);
 void launch_big_init(const DevProblem& P, const DevSymbolic& S, const BigDesc* descs, int count, int max_n,
                      int max_nfv, const double* H, const double* damp, const double* scalars, double* arena,
                      hipStream_t st);

@@ -1485,6 +1485,29 @@ void launch_begin_factorization(double* scalars, double lambda, DevStatus* statu
   begin_factorization_kernel<<<1, 1, 0, st>>>(scalars, lambda, status, tree_cursors);
 }
 
+constexpr int kVarStage = 32, kChildStage = 16;
+// LDS scratch of one workgroup of the LDS-front kernels, declared once per kernel and handed to the bodies (two bodies
+// inlined into one kernel would otherwise each bring their own copy: the medium tier's kernel needs every kilobyte)
+struct FrontScratch {
+  VarRec vrec[kVarStage];
+  ChildRec crec[kChildStage];
+  double Eb[16 * 17];   // (L_pp^-1)[i][c] of the current 16 columns at i * 17 + c
+  int vpre[kVarStage + 1];
+  int failed;
+};
+
+// A launch that asks for more LDS than a CU has must never reach the GPU (the hardware faults instead of refusing):
+// dynamic + the kernel's static LDS against the 160 KB of a gfx950 CU.  A refused launch leaves its fronts unfactored,
+// which the status words / the parity tests show; the symbolic analysis sizes every class so that this never fires.
+static bool lds_fits(const void* kernel, size_t dynamic_bytes, const char* what) {
+  hipFuncAttributes a;
+  size_t fixed = 8192;
+  if (hipFuncGetAttributes(&a, kernel) == hipSuccess) fixed = a.sharedSizeBytes;
+  if (dynamic_bytes + fixed <= (size_t)160 * 1024) return true;
+  fprintf(stderr, "gsx: %s needs %zu + %zu bytes of LDS: launch refused\n", what, dynamic_bytes, fixed);
+  return false;
+}
+
 // ---------------------------------------------------------------------------------------------
 // in-LDS partial Cholesky (choleskyPartial, gtsam/base/cholesky.cpp:108-159), lower form:
 // columns 0..F-1 become [L11; L21] (incl. the rhs row), the trailing block C -= L21 L21'.
@@ -1630,9 +1653,9 @@ __device__ __forceinline__ double tile_readlane(double v, int src_lane) {  // sr
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
   return __hiloint2double(hi, lo);
 }
-__device__ inline int lds_partial_cholesky_mfma(double* Lm, int n, int F, bool gap_test) {
-  __shared__ double Eb[16 * 17];  // (L_pp^-1)[i][c] of the current panel at i * 17 + c
-  __shared__ int failed;
+__device__ inline int lds_partial_cholesky_mfma(double* Lm, int n, int F, bool gap_test, FrontScratch& sc) {
+  double* Eb = sc.Eb;
+  int& failed = sc.failed;
   const int tid = threadIdx.x, nt = blockDim.x;
   const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
   const int li = lane & 15, lk = lane >> 4;
@@ -1747,11 +1770,11 @@ __device__ inline int lds_partial_cholesky_mfma(double* Lm, int n, int F, bool g
 }
 // panel width by frontal size: narrow panels keep the per-pivot register work small for the many cliques
 // with a handful of frontal scalars, wide panels halve the number of trailing sweeps of the larger ones
-__device__ inline int lds_partial_cholesky(double* L, int n, int F, bool gap_test) {
+__device__ inline int lds_partial_cholesky(double* L, int n, int F, bool gap_test, FrontScratch& sc) {
 #ifdef GSX_OLD_LDS_CHOLESKY
   return (F <= 24) ? lds_partial_cholesky_t<8>(L, n, F, gap_test) : lds_partial_cholesky_t<16>(L, n, F, gap_test);
 #else
-  return lds_partial_cholesky_mfma(L, n, F, gap_test);
+  return lds_partial_cholesky_mfma(L, n, F, gap_test, sc);
 #endif
 }
 
@@ -1768,7 +1791,6 @@ __device__ inline void report_failure(DevStatus* status, int front) {
 //   4. L panel -> arena (kept for back-substitution); Schur complement -> arena (pulled by a small
 //      parent, gathered by a big one).
 // ---------------------------------------------------------------------------------------------
-constexpr int kVarStage = 32, kChildStage = 16;
 #ifdef GSX_STAMP
 __device__ unsigned long long g_fs_stamp[12];
 #define FS_BEGIN unsigned long long fs0__ = wall_clock64();
@@ -1789,10 +1811,10 @@ __device__ unsigned long long g_fs_stamp[12];
 template <bool COH>
 __device__ __forceinline__ void front_small_body(const DevProblem& P, const DevSymbolic& S, const int f, const double* H,
                                                  const double* damp, const double lambda, double* arena,
-                                                 DevStatus* status, double* L) {
-  __shared__ VarRec vrec[kVarStage];
-  __shared__ int vpre[kVarStage + 1];
-  __shared__ ChildRec crec[kChildStage];
+                                                 DevStatus* status, double* L, FrontScratch& sc) {
+  VarRec* vrec = sc.vrec;
+  int* vpre = sc.vpre;
+  ChildRec* crec = sc.crec;
   FS_BEGIN
   const FrontRec fr = S.front_recs[f];
   const int n = fr.n, F = fr.F;
@@ -1908,7 +1930,7 @@ __device__ __forceinline__ void front_small_body(const DevProblem& P, const DevS
     __syncthreads();
   }
   FS_ADD(2)
-  const int fail = lds_partial_cholesky(L, n, F, false);
+  const int fail = lds_partial_cholesky(L, n, F, false, sc);
   FS_ADD(3)
   if (fail && tid == 0) report_failure(status, f);
   // L panel
@@ -1931,7 +1953,311 @@ __device__ __forceinline__ void front_small_body(const DevProblem& P, const DevS
 __global__ void __launch_bounds__(512) front_small_kernel(DevProblem P, DevSymbolic S, const int* ids, const double* H, const double* damp,
                                    const double* scalars, double* arena, DevStatus* status) {
   extern __shared__ double L[];
-  front_small_body<false>(P, S, ids[blockIdx.x], H, damp, scalars[SC_LAMBDA], arena, status, L);
+  __shared__ FrontScratch sc;
+  front_small_body<false>(P, S, ids[blockIdx.x], H, damp, scalars[SC_LAMBDA], arena, status, L, sc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// MEDIUM fronts (gsx_internal.h): n rows do not fit LDS as a square, the n x F frontal panel does.  One workgroup:
+//   1. panel [A11; A21; g'] in LDS from the H panels (+ lambda D) — H only ever touches the frontal columns;
+//   2. children in child order: entries that land in a frontal column go to the LDS panel, the others are added to the
+//      trailing block where it lives, in the arena (zeroed first; plain read-modify-write of this workgroup's own data);
+//   3. the panel is factored in LDS: per 16 columns D (one wave, registers), X (the tiles below), U — restricted to the
+//      panel's own columns;
+//   4. the trailing block takes C -= L21 L21' tile by tile on the matrix cores, operands from the LDS panel, the tile read
+//      from and written back to the arena once;
+//   5. the panel goes out as the front's L columns.
+// Storage = an LDS front's (n x n, column-major, L in the first F columns, the Schur complement behind them).
+// choleskyPartial, gtsam/base/cholesky.cpp:108-159; HessianFactor merge ctor + updateHessian, HessianFactor.cpp:240-373.
+// ---------------------------------------------------------------------------------------------
+__device__ inline int lds_panel_cholesky_mfma(double* Pm, int n, int F, FrontScratch& sc) {
+  double* Ebm = sc.Eb;
+  int& failedm = sc.failed;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  if (tid == 0) failedm = 0;
+  for (int jb = 0; jb < F; jb += 16) {
+    const int w = min(16, F - jb), rb = jb + w;
+    if (wave == 0) {
+      v4d pt, E;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = jb + li, c = jb + 4 * q + lk;
+        pt[q] = (r < F && c < F) ? (r >= c ? Pm[r + c * n] : 0.0) : (r == c ? 1.0 : 0.0);
+        E[q] = (li == 4 * q + lk) ? 1.0 : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {   // (straight-line: see lds_partial_cholesky_mfma)
+        const int q = j >> 2, lkj = j & 3;
+        __builtin_amdgcn_sched_barrier(0);
+        int lj = li;
+        asm volatile("" : "+v"(lj));
+        const double dj = tile_readlane(pt[q], lkj * 16 + j);
+        const double sj = tile_rsqrt(dj);
+        const bool colj = lk == lkj;
+        const double xj = pt[q] * sj;
+        const double xm = (colj && lj >= j) ? xj : 0.0;
+        const double ej = colj ? E[q] * sj : 0.0;
+        pt[q] = colj ? xm : pt[q];
+        E[q] = colj ? ej : E[q];
+        if (j < 15) {
+          const double xu = (lj > j) ? xm : 0.0;
+          pt = __builtin_amdgcn_mfma_f64_16x16x4f64(-xu, xu, pt, 0, 0, 0);
+          E = __builtin_amdgcn_mfma_f64_16x16x4f64(-xu, ej, E, 0, 0, 0);
+        }
+      }
+      if (lk == (li & 3)) {
+        const int qd = li >> 2;
+        const double l = (qd == 0) ? pt[0] : ((qd == 1) ? pt[1] : ((qd == 2) ? pt[2] : pt[3]));
+        if (jb + li < F && !(l > 0)) failedm = 1;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = jb + li, c = jb + 4 * q + lk;
+        if (r < F && c < F && r >= c) Pm[r + c * n] = pt[q];
+        Ebm[(4 * q + lk) * 17 + li] = E[q];
+      }
+    }
+    __syncthreads();
+    // X: every 16-row tile below the diagonal tile, X = A_ip L_pp^-T
+    const int m = n - rb, T16 = (m + 15) >> 4;
+    for (int t = wave; t < T16; t += nw) {
+      const int r = rb + 16 * t + li;
+      v4d nv = {0.0, 0.0, 0.0, 0.0};
+      double pv[4], av[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        pv[s4] = (r < n && 4 * s4 + lk < w) ? Pm[r + (jb + 4 * s4 + lk) * n] : 0.0;
+        av[s4] = Ebm[li * 17 + 4 * s4 + lk];
+      }
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) nv = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], pv[s4], nv, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (r < n && 4 * q + lk < w) Pm[r + (jb + 4 * q + lk) * n] = nv[q];
+    }
+    __syncthreads();
+    // U: rank-16 update of the panel's remaining columns rb..F-1 (all rows below): tile (row tile ti, column tile tj),
+    // column tiles only while they start inside the panel
+    {
+      const int C16 = (F - rb + 15) >> 4;   // column tiles left in the panel
+      const int ntiles = C16 > 0 ? C16 * T16 - C16 * (C16 - 1) / 2 : 0;   // tj < C16, ti >= tj
+      for (int t = wave; t < ntiles; t += nw) {
+        int tj = 0, rem = t;
+        while (rem >= T16 - tj) {
+          rem -= T16 - tj;
+          ++tj;
+        }
+        const int ti = tj + rem;
+        const int i0 = rb + ti * 16, c0 = rb + tj * 16;
+        const int col = c0 + li;
+        v4d acc;
+        double av[4], bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int rr = i0 + lk + 4 * q;
+          acc[q] = (rr < n && col < F) ? Pm[rr + col * n] : 0.0;
+          const int k = 4 * q + lk;
+          av[q] = (k < w && i0 + li < n) ? -Pm[(i0 + li) + (jb + k) * n] : 0.0;
+          bv[q] = (k < w && c0 + li < n) ? Pm[(c0 + li) + (jb + k) * n] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int rr = i0 + lk + 4 * q;
+          if (rr < n && col < F) Pm[rr + col * n] = acc[q];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  return failedm;
+}
+
+template <bool COH>
+__device__ __forceinline__ void front_medium_body(const DevProblem& P, const DevSymbolic& S, const int f, const double* H,
+                                                  const double* damp, const double lambda, double* arena,
+                                                  DevStatus* status, double* Pm, FrontScratch& sc) {
+  VarRec* mvrec = sc.vrec;
+  int* mvpre = sc.vpre;
+  ChildRec* mcrec = sc.crec;
+  FS_BEGIN
+  const FrontRec fr = S.front_recs[f];
+  const int n = fr.n, F = fr.F;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  double* A = arena + fr.off;
+  int* cml = (int*)(Pm + (size_t)n * F);  // two children's row maps (2 x n ints)
+  const int nfv = fr.nfv, nchild = fr.nchild;
+  const int s1 = n - F;
+  if (tid < min(nfv, kVarStage)) mvrec[tid] = S.fvar_recs[fr.fvar_ptr + tid];
+  if (tid < min(nchild, kChildStage)) mcrec[tid] = S.child_recs[fr.child_ptr + tid];
+  for (int e = tid; e < n * F; e += nt) Pm[e] = 0;
+  // the trailing block's lower triangle in the arena: zero (the children add into it)
+  for (int col = wave; col < s1; col += nw)
+    for (int r = col + lane; r < s1; r += 64) A[(F + r) + (i64)(F + col) * n] = 0.0;
+  FS_ADD(0)
+  for (int k0 = 0; k0 < nfv; k0 += kVarStage) {
+    const int nb = min(kVarStage, nfv - k0);
+    if (k0 > 0) {
+      __syncthreads();
+      if (tid < nb) mvrec[tid] = S.fvar_recs[fr.fvar_ptr + k0 + tid];
+    }
+    __syncthreads();
+    if (tid <= nb) {
+      int sacc = 0;
+      for (int k = 0; k < tid; ++k) sacc += mvrec[k].rows * mvrec[k].dA;
+      mvpre[tid] = sacc;
+    }
+    __syncthreads();
+    const int total = mvpre[nb];
+    constexpr int U = 8;
+    for (int e0 = tid; e0 < total; e0 += nt * U) {
+      double x[U];
+      int dst[U];
+      int k = 0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + nt * u;
+        x[u] = 0.0;
+        dst[u] = -1;
+        if (e < total) {
+          while (e >= mvpre[k + 1]) ++k;
+          const VarRec vr = mvrec[k];
+          const int el = e - mvpre[k];
+          int r, j;
+          divmod_small(el, vr.rows, 1.0f / (float)vr.rows, j, r);
+          x[u] = H[vr.h_off + el];
+          dst[u] = S.hmap[vr.hmap_off + r] + (vr.loc + j) * n;   // (columns of a frontal variable: inside the panel)
+          if (r == j) x[u] += lambda * damp[vr.toff + j];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (dst[u] >= 0) Pm[dst[u]] = x[u];
+    }
+  }
+  FS_ADD(1)
+  // children, in child order (a barrier — which also drains the arena stores — between one child and the next)
+  auto child = [&](int k) -> ChildRec { return k < kChildStage ? mcrec[k] : S.child_recs[fr.child_ptr + k]; };
+  if (nchild > 0) {
+    const ChildRec c0 = child(0);
+    for (int r = tid; r < c0.s1; r += nt) cml[r] = S.cmap[c0.cmap_off + r];
+  }
+  __syncthreads();
+  for (int ci = 0; ci < nchild; ++ci) {
+    const ChildRec cr = child(ci);
+    const int* cm = cml + (ci & 1) * n;
+    if (ci + 1 < nchild) {   // the next child's row map into the other buffer (nobody reads that one now)
+      const ChildRec cn = child(ci + 1);
+      int* cmn = cml + ((ci + 1) & 1) * n;
+      for (int r = tid; r < cn.s1; r += nt) cmn[r] = S.cmap[cn.cmap_off + r];
+    }
+    const double* src0 = arena + cr.src0;
+    const int cs1 = cr.s1, tot = cs1 * (cs1 + 1) / 2;
+    const float b = (float)(2 * cs1 + 1);
+    constexpr int U = 8;
+    for (int e0 = tid; e0 < tot; e0 += nt * U) {
+      double v[U];
+      int dr[U], dc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + nt * u;
+        v[u] = 0.0;
+        dr[u] = -1;
+        dc[u] = 0;
+        if (e < tot) {
+          int c = (int)((b - sqrtf(b * b - 8.0f * (float)e)) * 0.5f);
+          c = max(0, min(c, cs1 - 1));
+          if (c + 1 < cs1 && (c + 1) * cs1 - (c + 1) * c / 2 <= e) ++c;
+          if (c * cs1 - c * (c - 1) / 2 > e) --c;
+          const int r = c + (e - (c * cs1 - c * (c - 1) / 2));
+          if constexpr (COH) v[u] = __hip_atomic_load(&src0[(i64)c * cr.nc + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else v[u] = src0[(i64)c * cr.nc + r];
+          dr[u] = cm[r];
+          dc[u] = cm[c];
+        }
+      }
+      // the trailing entries: read-modify-write in the arena, all loads of a lane before its stores
+      double old[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) old[u] = (dr[u] >= 0 && dc[u] >= F) ? A[dr[u] + (i64)dc[u] * n] : 0.0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (dr[u] < 0) continue;
+        if (dc[u] < F) Pm[dr[u] + dc[u] * n] += v[u];
+        else A[dr[u] + (i64)dc[u] * n] = old[u] + v[u];
+      }
+    }
+    __syncthreads();
+  }
+  FS_ADD(2)
+  const int fail = lds_panel_cholesky_mfma(Pm, n, F, sc);
+  FS_ADD(3)
+  if (fail && tid == 0) report_failure(status, f);
+  // the L columns
+  for (int c = wave; c < F; c += nw)
+    for (int r = c + lane; r < n; r += 64) A[r + (i64)c * n] = Pm[r + c * n];
+  FS_ADD(4)
+  // Schur complement: C -= L21 L21', one wave per 16 x 16 tile of the trailing block's lower triangle
+  {
+    const int T16 = (s1 + 15) >> 4, ntiles = T16 * (T16 + 1) / 2;
+    for (int t = wave; t < ntiles; t += nw) {
+      int ti = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+      while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+      while (ti * (ti + 1) / 2 > t) --ti;
+      const int tj = t - ti * (ti + 1) / 2;
+      const int i0 = F + ti * 16, c0 = F + tj * 16;
+      const int col = c0 + li;
+      v4d acc;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rr = i0 + lk + 4 * q;
+        acc[q] = (rr < n && col < n && rr >= col) ? A[rr + (i64)col * n] : 0.0;
+      }
+      for (int k0 = 0; k0 < F; k0 += 4) {
+        const int k = k0 + lk;
+        const double av = (k < F && i0 + li < n) ? -Pm[(i0 + li) + k * n] : 0.0;
+        const double bv = (k < F && c0 + li < n) ? Pm[(c0 + li) + k * n] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rr = i0 + lk + 4 * q;
+        if (rr < n && col < n && rr >= col) {
+          if constexpr (COH) __hip_atomic_store(&A[rr + (i64)col * n], acc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else A[rr + (i64)col * n] = acc[q];
+        }
+      }
+    }
+  }
+  FS_ADD(11)
+#ifdef GSX_STAMP
+  if (tid == 0) { atomicAdd(&g_fs_stamp[5], (unsigned long long)n); atomicAdd(&g_fs_stamp[6], (unsigned long long)F); atomicAdd(&g_fs_stamp[7], (unsigned long long)nchild); atomicAdd(&g_fs_stamp[8], (unsigned long long)nfv); atomicAdd(&g_fs_stamp[9], 1ull); }
+#endif
+}
+// medium fronts of one launch group, a workgroup each (the level schedule and gsx_relinearize_partial)
+__global__ void __launch_bounds__(512) front_medium_kernel(DevProblem P, DevSymbolic S, const int* ids, const double* H,
+                                                           const double* damp, const double* scalars, double* arena,
+                                                           DevStatus* status) {
+  extern __shared__ double L[];
+  __shared__ FrontScratch sc;
+  front_medium_body<false>(P, S, ids[blockIdx.x], H, damp, scalars[SC_LAMBDA], arena, status, L, sc);
+}
+void launch_front_medium(const DevProblem& P, const DevSymbolic& S, const int* ids, int count, int max_panel, int max_n,
+                         const double* H, const double* damp, const double* scalars, double* arena, DevStatus* status,
+                         hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)front_medium_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+    attr = true;
+  }
+  if (count && lds_fits((const void*)front_medium_kernel, ((size_t)max_panel + max_n) * sizeof(double), "front_medium"))
+    front_medium_kernel<<<count, 512, ((size_t)max_panel + max_n) * sizeof(double), st>>>(P, S, ids, H, damp, scalars, arena,
+                                                                                          status);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1950,6 +2276,7 @@ __global__ void __launch_bounds__(512, 4) front_tree_kernel(DevProblem P, DevSym
                                                          const double* damp, const double* scalars, double* arena,
                                                          DevStatus* status) {
   extern __shared__ double L[];
+  __shared__ FrontScratch sc;
   __shared__ int s_next;
   const double lambda = scalars[SC_LAMBDA];
   for (;;) {
@@ -1960,7 +2287,7 @@ __global__ void __launch_bounds__(512, 4) front_tree_kernel(DevProblem P, DevSym
     if (k >= T.nstart) return;
     int f = T.start[k];
     while (f >= 0) {
-      front_small_body<true>(P, S, f, H, damp, lambda, arena, status, L);
+      front_small_body<true>(P, S, f, H, damp, lambda, arena, status, L, sc);
 #ifdef GSX_STAMP
       unsigned long long hs0 = wall_clock64();
 #endif
@@ -1993,11 +2320,62 @@ static void fs_stamp_print(const char* what, int count, int threads, int max_n, 
   hipStreamSynchronize(st);
   hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fs_stamp), sizeof(h));
   const double c = h[9] ? (double)h[9] : 1.0;
-  printf("[%s] count %6d thr %3d max_n %3d | fronts %llu mean n=%.0f F=%.0f ch=%.1f nfv=%.1f | mean us: head %.1f  H %.1f  children %.1f  chol %.1f  store %.1f  handoff %.1f\n",
+  printf("[%s] count %6d thr %3d max_n %3d | fronts %llu mean n=%.0f F=%.0f ch=%.1f nfv=%.1f | mean us: head %.1f  H %.1f  children %.1f  chol %.1f  store %.1f  handoff %.1f  schur(medium) %.1f\n",
          what, count, threads, max_n, h[9], h[5] / c, h[6] / c, h[7] / c, h[8] / c, h[0] / c / 100, h[1] / c / 100, h[2] / c / 100,
-         h[3] / c / 100, h[4] / c / 100, h[10] / c / 100);
+         h[3] / c / 100, h[4] / c / 100, h[10] / c / 100, h[11] / c / 100);
 }
 #endif
+// the tier of the medium fronts: they, and the LDS fronts above them in their subtrees
+__global__ void __launch_bounds__(512) front_tree_med_kernel(DevProblem P, DevSymbolic S, TreeArgs T, const double* H,
+                                                             const double* damp, const double* scalars, double* arena,
+                                                             DevStatus* status) {
+  extern __shared__ double L[];
+  __shared__ FrontScratch sc;
+  __shared__ int s_nextm;
+  const double lambda = scalars[SC_LAMBDA];
+  for (;;) {
+    if (threadIdx.x == 0) s_nextm = atomicAdd(T.cursor, 1);
+    __syncthreads();
+    const int k = s_nextm;
+    __syncthreads();
+    if (k >= T.nstart) return;
+    int f = T.start[k];
+    while (f >= 0) {
+      if (S.front_recs[f].n > kSmallMaxN) front_medium_body<true>(P, S, f, H, damp, lambda, arena, status, L, sc);
+      else front_small_body<true>(P, S, f, H, damp, lambda, arena, status, L, sc);
+      __syncthreads();  // (drains every store of the workgroup)
+      if (threadIdx.x == 0) {
+        int nxt = -1;
+        const int p = T.up[f];
+        if (p >= 0 && atomicSub(&T.pending[p], 1) == 1) {
+          T.pending[p] = T.npend[p];
+          nxt = p;
+        }
+        s_nextm = nxt;
+      }
+      __syncthreads();
+      f = s_nextm;
+      __syncthreads();
+    }
+  }
+}
+void launch_front_tree_med(const DevProblem& P, const DevSymbolic& S, const TreeArgs& T, size_t lds_bytes, const double* H,
+                           const double* damp, const double* scalars, double* arena, DevStatus* status, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)front_tree_med_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+    attr = true;
+  }
+  if (T.nstart <= 0 || !lds_fits((const void*)front_tree_med_kernel, lds_bytes, "front_tree_med")) return;
+#ifdef GSX_STAMP
+  fs_stamp_zero();
+#endif
+  front_tree_med_kernel<<<std::min(T.nstart, 256), 512, lds_bytes, st>>>(P, S, T, H, damp, scalars, arena, status);
+#ifdef GSX_STAMP
+  fs_stamp_print("tree-med", std::min(T.nstart, 256), 512, (int)(lds_bytes / 1024), st);
+#endif
+}
+
 void launch_front_tree(const DevProblem& P, const DevSymbolic& S, const TreeArgs& T, int max_n, int threads, const double* H,
                        const double* damp, const double* scalars, double* arena, DevStatus* status, hipStream_t st) {
   static bool attr = false;
@@ -2007,6 +2385,7 @@ void launch_front_tree(const DevProblem& P, const DevSymbolic& S, const TreeArgs
   }
   if (T.nstart <= 0) return;
   const size_t lds = ((size_t)max_n * max_n + max_n) * sizeof(double);
+  if (!lds_fits((const void*)front_tree_kernel, lds, "front_tree")) return;
   // as many workgroups as can be resident (LDS, 2048 threads a CU); the rest would only find the start list empty
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>({(size_t)(156 * 1024) / (lds + 2048), (size_t)2048 / threads, 16}));
   const int grid = std::min(T.nstart, 256 * per_cu);
@@ -2030,7 +2409,7 @@ void launch_front_small(const DevProblem& P, const DevSymbolic& S, const int* id
 #ifdef GSX_STAMP
   fs_stamp_zero();
 #endif
-  if (count)
+  if (count && lds_fits((const void*)front_small_kernel, ((size_t)max_n * max_n + max_n) * sizeof(double), "front_small"))
     front_small_kernel<<<count, threads, ((size_t)max_n * max_n + max_n) * sizeof(double), st>>>(P, S, ids, H, damp, scalars,
                                                                                          arena, status);
 #ifdef GSX_STAMP
@@ -2679,9 +3058,10 @@ void launch_backsolve(const DevSymbolic& S, const int* ids, int count, int threa
 // ---------------------------------------------------------------------------------------------
 __global__ void dense_small_kernel(double* a, int n, int nf, DevStatus* status) {
   extern __shared__ double L[];
+  __shared__ FrontScratch sc;
   for (int e = threadIdx.x; e < n * n; e += blockDim.x) L[e] = a[e];
   __syncthreads();
-  const int fail = lds_partial_cholesky(L, n, nf, true);   // the dense entry: one clique, tested here
+  const int fail = lds_partial_cholesky(L, n, nf, true, sc);   // the dense entry: one clique, tested here
   if (fail && threadIdx.x == 0) report_failure(status, 0);
   for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
     const int r = e % n, c = e / n;

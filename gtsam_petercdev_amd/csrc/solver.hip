@@ -69,7 +69,14 @@ struct SmallLaunch {
   int begin, count, max_n, threads;
   int max_panel = 0;  // leaf launches: largest n*F of the group (LDS doubles)
   int max_F = 0;      // rest launches: largest frontal dimension
+  bool medium = false;  // MEDIUM fronts (gsx_internal.h): front_medium_kernel, max_panel = largest n*F
 };
+// an LDS-class launch group: the whole-front-in-LDS kernel, or the medium-front one
+void launch_lds_group(const DevProblem& P, const DevSymbolic& S, const int* ids, const SmallLaunch& g, const double* H,
+                      const double* damp, const double* scalars, double* arena, DevStatus* status, hipStream_t st) {
+  if (g.medium) launch_front_medium(P, S, ids, g.count, g.max_panel, g.max_n, H, damp, scalars, arena, status, st);
+  else launch_front_small(P, S, ids, g.count, g.max_n, g.threads, H, damp, scalars, arena, status, st);
+}
 struct BigLevel {
   int begin = 0, count = 0;
   BigPlan plan;  // rounds of the level's blocked fronts (bigfront.hip)
@@ -142,6 +149,7 @@ struct gsx_context {
   unsigned bst_epoch = 0;
   struct TreeTier {
     int start0, nstart, max_n, threads;
+    size_t med_lds;   // > 0: the tier of the medium fronts (front_tree_med_kernel), bytes of LDS
   };
   std::vector<TreeTier> tree_tiers;
   DevBuf<i64> d_gt_dst;  // gather tasks / segments for big parents
@@ -661,13 +669,15 @@ gsx_status upload_symbolic(gsx_context* c) {
       i = j;
     }
     const int se = S.lvl_small_end[l];
-    while (i < se) {
+    int se_lds = se;   // the medium fronts (n > kSmallMaxN) sit at the end of the level's LDS-class range (sorted by n)
+    while (se_lds > i && S.med[S.sched[se_lds - 1]]) --se_lds;
+    while (i < se_lds) {
       const int thr = small_threads_for(S.N[S.sched[i]]);
       int j = i, maxn = 0;
       // same thread class, and rows within 1.6x of the smallest member (LDS footprint within 2.6x: in effect one group per
       // thread class — measured on the 100 000-pose graphs: 4 launches per level beat 7 finer ones (1.3x) by 3 %)
       const int n0 = std::max(S.N[S.sched[i]], 12);
-      while (j < se && small_threads_for(S.N[S.sched[j]]) == thr && S.N[S.sched[j]] * 10 <= n0 * 16) {
+      while (j < se_lds && small_threads_for(S.N[S.sched[j]]) == thr && S.N[S.sched[j]] * 10 <= n0 * 16) {
         maxn = std::max(maxn, S.N[S.sched[j]]);
         ++j;
       }
@@ -710,21 +720,34 @@ gsx_status upload_symbolic(gsx_context* c) {
         const SmallLaunch one{G[0].begin, total, maxn, std::max(256, small_threads_for(maxn))};
         G.assign(1, one);
       }
+      if (se_lds < se) {   // the level's medium fronts: one group
+        SmallLaunch m{se_lds, se - se_lds, 0, 512};
+        m.medium = true;
+        for (int k = se_lds; k < se; ++k) {
+          m.max_n = std::max(m.max_n, S.N[S.sched[k]]);
+          m.max_panel = std::max(m.max_panel, S.N[S.sched[k]] * S.F[S.sched[k]]);
+        }
+        G.push_back(m);
+      }
     }
     {
       // what the level loop of the full factorization still launches: the LDS-class fronts that are not tree fronts (they
       // sit above a blocked front), one launch a level
-      SmallLaunch r{(int)rest_ids.size(), 0, 0, 0};
-      for (int k = S.lvl_leaf_end[l]; k < se; ++k) {
-        const int f = S.sched[k];
-        if (S.tree_tier[f] >= 0) continue;
-        rest_ids.push_back(f);
-        r.count++;
-        r.max_n = std::max(r.max_n, S.N[f]);
-        r.max_F = std::max(r.max_F, S.F[f]);
+      for (int pass = 0; pass < 2; ++pass) {   // the whole-front-in-LDS ones, then the medium ones
+        SmallLaunch r{(int)rest_ids.size(), 0, 0, 0};
+        r.medium = pass == 1;
+        for (int k = S.lvl_leaf_end[l]; k < se; ++k) {
+          const int f = S.sched[k];
+          if (S.tree_tier[f] >= 0 || (S.med[f] != 0) != r.medium) continue;
+          rest_ids.push_back(f);
+          r.count++;
+          r.max_n = std::max(r.max_n, S.N[f]);
+          r.max_F = std::max(r.max_F, S.F[f]);
+          r.max_panel = std::max(r.max_panel, S.N[f] * S.F[f]);
+        }
+        r.threads = r.medium ? 512 : small_threads_for(r.max_n);
+        if (r.count) c->rest_launch[l].push_back(r);
       }
-      r.threads = small_threads_for(r.max_n);
-      if (r.count) c->rest_launch[l].push_back(r);
     }
     BigLevel& B = c->big_level[l];
     B.begin = (int)c->big_descs.size();
@@ -741,13 +764,19 @@ gsx_status upload_symbolic(gsx_context* c) {
   HIPCHK(c, c->d_rest_ids.upload(rest_ids, st));
   {
     c->tree_tiers.clear();
-    const int ntier = std::min<int>((int)S.tree_bounds.size(), kTreeCursors);
+    const int nb = (int)S.tree_bounds.size();
+    const int ntier = std::min<int>((int)S.tree_start_ptr.size() - 1, kTreeCursors);
     for (int t = 0; t < ntier; ++t) {
       int maxn = 0;
+      size_t lds = 0;   // the medium tier: doubles of LDS of its most demanding front
       for (int f = 0; f < S.n_fronts; ++f)
-        if (S.tree_tier[f] == t) maxn = std::max(maxn, S.N[f]);
+        if (S.tree_tier[f] == t) {
+          maxn = std::max(maxn, S.N[f]);
+          lds = std::max(lds, S.med[f] ? (size_t)S.N[f] * S.F[f] + S.N[f] : (size_t)S.N[f] * S.N[f] + S.N[f]);
+        }
       c->tree_tiers.push_back({S.tree_start_ptr[t], S.tree_start_ptr[t + 1] - S.tree_start_ptr[t], maxn,
-                               S.tree_threads[t] > 0 ? S.tree_threads[t] : small_threads_for(maxn)});
+                               t < nb ? (S.tree_threads[t] > 0 ? S.tree_threads[t] : small_threads_for(maxn)) : 512,
+                               t >= nb ? lds * sizeof(double) : (size_t)0});
     }
     HIPCHK(c, c->d_tree_start.upload(S.tree_start, st));
     HIPCHK(c, c->d_tree_up.upload(S.tree_up, st));
@@ -994,6 +1023,18 @@ void dev_big_factor(gsx_context* c, const BigDesc* descs, int count, const BigPl
   }
 }
 
+// GSX_DEBUG_LAUNCH=1: synchronise after the launches of the dependency-driven kernels and say what came back
+void debug_sync(gsx_context* c, const char* what, int a, int b) {
+  static const bool on = std::getenv("GSX_DEBUG_LAUNCH") != nullptr;
+  if (!on) return;
+  fprintf(stderr, "[gsx] %s (%d, %d) ...", what, a, b);
+  fflush(stderr);
+  const hipError_t e = hipStreamSynchronize(c->stream);
+  const hipError_t e2 = hipGetLastError();
+  fprintf(stderr, " %s / %s\n", hipGetErrorString(e), hipGetErrorString(e2));
+  fflush(stderr);
+}
+
 void dev_factorize(gsx_context* c, double lambda) {
   const Symbolic& S = c->S;
   c->fact_valid = false;   // becomes true when the read-back shows no failed front (readback)
@@ -1028,8 +1069,9 @@ void dev_factorize(gsx_context* c, double lambda) {
     }
     for (const SmallLaunch& sl : c->rest_launch[l]) {
       if (c->profiling > 0) timer_begin(c, PH_FACTOR_SMALL);
-      launch_front_small(c->DP, c->DS, c->d_rest_ids.p + sl.begin, sl.count, sl.max_n, sl.threads, c->d_H.p, c->d_damp.p,
-                         c->d_scalars.p, c->d_arena.p, c->d_status.p, side ? side_stream(c, gi++, &used) : c->stream);
+      launch_lds_group(c->DP, c->DS, c->d_rest_ids.p + sl.begin, sl, c->d_H.p, c->d_damp.p, c->d_scalars.p, c->d_arena.p,
+                       c->d_status.p, side ? side_stream(c, gi++, &used) : c->stream);
+      debug_sync(c, sl.medium ? "front_medium (level)" : "front_small (level)", sl.count, sl.medium ? sl.max_panel : sl.max_n);
       if (c->profiling > 0) timer_end(c, PH_FACTOR_SMALL);
     }
     if (side) side_join(c, used);
@@ -1039,10 +1081,15 @@ void dev_factorize(gsx_context* c, double lambda) {
         const gsx_context::TreeTier& tt = c->tree_tiers[t];
         if (!tt.nstart) continue;
         if (c->profiling > 0) timer_begin(c, PH_FACTOR_SMALL);
-        launch_front_tree(c->DP, c->DS,
-                          TreeArgs{c->d_tree_start.p + tt.start0, tt.nstart, c->d_tree_cursor.p + t, c->d_tree_pending.p,
-                                   c->d_tree_up.p, c->d_tree_npend.p},
-                          tt.max_n, tt.threads, c->d_H.p, c->d_damp.p, c->d_scalars.p, c->d_arena.p, c->d_status.p, c->stream);
+        const TreeArgs ta{c->d_tree_start.p + tt.start0, tt.nstart, c->d_tree_cursor.p + t, c->d_tree_pending.p,
+                          c->d_tree_up.p, c->d_tree_npend.p};
+        if (tt.med_lds)
+          launch_front_tree_med(c->DP, c->DS, ta, tt.med_lds, c->d_H.p, c->d_damp.p, c->d_scalars.p, c->d_arena.p,
+                                c->d_status.p, c->stream);
+        else
+          launch_front_tree(c->DP, c->DS, ta, tt.max_n, tt.threads, c->d_H.p, c->d_damp.p, c->d_scalars.p, c->d_arena.p,
+                            c->d_status.p, c->stream);
+        debug_sync(c, tt.med_lds ? "front_tree_med" : "front_tree", tt.nstart, (int)tt.med_lds);
         if (c->profiling > 0) timer_end(c, PH_FACTOR_SMALL);
       }
     }
@@ -1111,11 +1158,12 @@ void dev_backsolve(gsx_context* c, const WildfireArgs* wf = nullptr) {
     int small_maxn = 0, small_maxF = 0;
     if (tree) {
       n_small = 0;
-      for (const SmallLaunch& rl : c->rest_launch[l]) {   // (at most one range a level)
-        small_ids = c->d_rest_ids.p + rl.begin;
-        n_small = rl.count;
-        small_maxn = rl.max_n;
-        small_maxF = rl.max_F;
+      // (the level's ranges — whole-front-in-LDS ones, then medium ones — are consecutive in d_rest_ids)
+      if (!c->rest_launch[l].empty()) small_ids = c->d_rest_ids.p + c->rest_launch[l][0].begin;
+      for (const SmallLaunch& rl : c->rest_launch[l]) {
+        n_small += rl.count;
+        small_maxn = std::max(small_maxn, rl.max_n);
+        small_maxF = std::max(small_maxF, rl.max_F);
       }
     } else {
       for (int k = le; k < se; ++k) {
@@ -1167,6 +1215,7 @@ void dev_backsolve(gsx_context* c, const WildfireArgs* wf = nullptr) {
                                               c->d_bst_counters.p + 1, c->bst_epoch},
                             c->d_arena.p, c->d_delta.p, c->d_status.p, c->stream);
       if (c->profiling > 0) timer_end(c, PH_K_BACKSOLVE);
+      debug_sync(c, "backsolve_tree", c->bst_roots, c->bst_total);
     }
     // all leaf-kernel cliques of the level in one launch (a wave each)
     if (S.lvl_leaf_end[l] > S.lvl_ptr[l])
@@ -1482,6 +1531,15 @@ gsx_status gsx_get_shard(gsx_handle h, gsx_shard_info* info, int32_t* front_owne
     for (int f = 0; f < S.n_fronts; ++f) front_owner[f] = S.owner[f];
   if (factor_owned)
     for (int f = 0; f < h->P.n_factors; ++f) factor_owned[f] = S.f_owned[f];
+  return GSX_OK;
+}
+
+gsx_status gsx_get_front_classes(gsx_handle h, int32_t* classes) {
+  if (!h || !classes) return GSX_E_INVALID;
+  if (!h->has_symbolic) return GSX_E_STATE;
+  const Symbolic& S = h->S;
+  for (int f = 0; f < S.n_fronts; ++f)
+    classes[f] = (S.med[f] ? 3 : S.cls[f]) | (S.tree_tier[f] >= 0 ? 4 : 0) | (S.lean[f] ? 8 : 0);
   return GSX_OK;
 }
 
@@ -2156,7 +2214,7 @@ gsx_status partial_factor(gsx_handle h, std::vector<int>& dfr) {
     std::vector<int> gm_task, gm_slot, gm_nslots;
     struct LevelPlan {
       std::vector<std::array<int, 4>> leaf;   // begin, count, max_panel, threads
-      std::vector<std::array<int, 4>> small;  // begin, count, max_n, threads
+      std::vector<SmallLaunch> small;         // ranges of `ids`, with the launch shape of the full schedule's group
       int big_begin = 0, big_count = 0;
       BigPlan big_plan;
       std::vector<int> seg_idx, gm_idx;
@@ -2177,8 +2235,12 @@ gsx_status partial_factor(gsx_handle h, std::vector<int>& dfr) {
           leaf.push_back(h->h_leaf_recs[h->fr_sched_pos[f] - h->leaf_base]);
         } else if (cls == 1) {
           const SmallLaunch& sl = h->small_launch[l][g];
-          if (!same) L.small.push_back({(int)ids.size(), 0, sl.max_n, sl.threads});
-          L.small.back()[1]++;
+          if (!same) {
+            L.small.push_back(sl);
+            L.small.back().begin = (int)ids.size();
+            L.small.back().count = 0;
+          }
+          L.small.back().count++;
           ids.push_back(f);
         } else {
           if (!L.big_count) L.big_begin = (int)big.size();
@@ -2237,9 +2299,9 @@ gsx_status partial_factor(gsx_handle h, std::vector<int>& dfr) {
       for (const auto& g : L.leaf)
         launch_front_leaf(h->DP, h->DS, ps.leaf.p + g[0], g[1], g[2], g[3], h->d_H.p, h->d_damp.p, h->d_scalars.p,
                           h->d_arena.p, h->d_status.p, sm);
-      for (const auto& g : L.small)
-        launch_front_small(h->DP, h->DS, ps.ids.p + g[0], g[1], g[2], g[3], h->d_H.p, h->d_damp.p, h->d_scalars.p,
-                           h->d_arena.p, h->d_status.p, sm);
+      for (const SmallLaunch& g : L.small)
+        launch_lds_group(h->DP, h->DS, ps.ids.p + g.begin, g, h->d_H.p, h->d_damp.p, h->d_scalars.p, h->d_arena.p,
+                         h->d_status.p, sm);
       if (l == 0 && L.nseg) launch_big_gather(GA, L.seg0, L.nseg, L.m0, L.nm, h->d_arena.p, sm);  // gather group 0
       if (L.big_count) {
         if (l > 0 && L.nseg) launch_big_gather(GA, L.seg0, L.nseg, L.m0, L.nm, h->d_arena.p, sm);
@@ -2617,55 +2679,67 @@ gsx_status gsx_joint_marginal_covariance(gsx_handle h, const uint64_t* keys, int
   gsx_status st = marginals_prepare(h);
   if (st != GSX_OK) return st;
   const Symbolic& S = h->S;
-  std::vector<int> vars(n_keys), offs(n_keys + 1, 0);
+  // column groups: a variable's unit columns go through the path kernel at most 16 at a time (fewer when the cliques on its
+  // path to the root are tall: the kernel keeps two (rows x columns) panels in LDS) — Marginals.cpp:107-136 has no limit on
+  // the dimension of a variable, and neither has this entry point
+  struct Group {
+    int var, col0, width, off;   // off: first row / column of the group in the joint matrix
+  };
+  std::vector<Group> groups;
+  std::vector<int> vars(n_keys);
+  int D = 0;
+  constexpr size_t kLds = 160 * 1024 - 4096 - 4096;
   for (int k = 0; k < n_keys; ++k) {
     vars[k] = find_var(h, keys[k]);
-    if (vars[k] < 0 || h->P.dims[vars[k]] > 16) {
+    if (vars[k] < 0) {
       h->err = "joint marginal of a key that is not a variable of the graph";
       return GSX_E_INVALID;
     }
     for (int q = 0; q < k; ++q)
       if (vars[q] == vars[k]) return GSX_E_INVALID;
-    offs[k + 1] = offs[k] + h->P.dims[vars[k]];
+    int max_n = 0;
+    for (int f = S.front_of_var[vars[k]]; f >= 0; f = S.parent[f]) max_n = std::max(max_n, S.N[f]);
+    const int fit = (int)std::min<size_t>(16, kLds / ((size_t)2 * max_n * sizeof(double)));
+    if (fit < 1) {
+      h->err = "marginal: the cliques on the path to the root are too large for the one-workgroup kernel";
+      return GSX_E_NOMEM;
+    }
+    const int d = h->P.dims[vars[k]];
+    for (int c0 = 0; c0 < d; c0 += fit) groups.push_back({vars[k], c0, std::min(fit, d - c0), D + c0});
+    D += d;
   }
-  const int D = offs[n_keys];
   if (n_out != (int64_t)D * D) return GSX_E_INVALID;
   const int64_t nt = std::max<int64_t>(h->P.tan_size, 1);
   DevBuf<double> d_Y, d_blk, d_sig;
   DevBuf<int> d_path;
   HIPCHK(h, d_Y.alloc((size_t)nt * D));
-  HIPCHK(h, d_blk.alloc((size_t)D * D));
+  HIPCHK(h, d_blk.alloc((size_t)16 * 16));
   HIPCHK(h, d_sig.alloc(256));
   HIPCHK(h, hipMemsetAsync(d_Y.p, 0, (size_t)nt * D * sizeof(double), h->stream));
-  for (int k = 0; k < n_keys; ++k) {
-    const int v = vars[k], dA = h->P.dims[v];
+  for (const Group& g : groups) {
     std::vector<int> path;
     int max_n = 0;
-    for (int f = S.front_of_var[v]; f >= 0; f = S.parent[f]) {
+    for (int f = S.front_of_var[g.var]; f >= 0; f = S.parent[f]) {
       path.push_back(f);
       max_n = std::max(max_n, S.N[f]);
     }
-    if ((size_t)2 * max_n * dA * sizeof(double) > 160 * 1024 - 4096 - 4096) {
-      h->err = "marginal: the cliques on the path to the root are too large for the one-workgroup kernel";
-      return GSX_E_NOMEM;
-    }
     HIPCHK(h, d_path.upload(path, h->stream));
-    launch_marginal_path(h->DS, d_path.p, (int)path.size(), S.h_loc[v], dA, max_n, h->d_arena.p, d_sig.p,
-                         d_Y.p + (size_t)offs[k] * nt, nt, h->stream);
+    launch_marginal_path(h->DS, d_path.p, (int)path.size(), S.h_loc[g.var] + g.col0, g.width, max_n, h->d_arena.p, d_sig.p,
+                         d_Y.p + (size_t)g.off * nt, nt, h->stream);
     HIPCHK(h, hipStreamSynchronize(h->stream));  // (d_path is reused)
   }
   std::vector<double> blk((size_t)16 * 16);
-  for (int a = 0; a < n_keys; ++a)
-    for (int b = a; b < n_keys; ++b) {
-      const int dA = offs[a + 1] - offs[a], dB = offs[b + 1] - offs[b];
-      launch_joint_cross(d_Y.p + (size_t)offs[a] * nt, d_Y.p + (size_t)offs[b] * nt, nt, dA, dB, d_blk.p, h->stream);
+  for (size_t a = 0; a < groups.size(); ++a)
+    for (size_t b = a; b < groups.size(); ++b) {
+      const int dA = groups[a].width, dB = groups[b].width, oa = groups[a].off, ob = groups[b].off;
+      launch_joint_cross(d_Y.p + (size_t)oa * nt, d_Y.p + (size_t)ob * nt, nt, dA, dB, d_blk.p, h->stream);
       HIPCHK(h, hipMemcpyAsync(blk.data(), d_blk.p, (size_t)dA * dB * sizeof(double), hipMemcpyDeviceToHost, h->stream));
       HIPCHK(h, hipStreamSynchronize(h->stream));
       for (int i = 0; i < dA; ++i)
         for (int j = 0; j < dB; ++j) {
           const double x = blk[i + (size_t)j * dA];
-          out[(size_t)(offs[a] + i) * D + offs[b] + j] = x;
-          out[(size_t)(offs[b] + j) * D + offs[a] + i] = x;
+          out[(size_t)(oa + i) * D + ob + j] = x;
+          out[(size_t)(ob + j) * D + oa + i] = x;
         }
     }
   HIPCHK(h, hipGetLastError());
@@ -2681,10 +2755,6 @@ gsx_status gsx_marginal_covariance(gsx_handle h, uint64_t key, double* out, int6
   }
   const int dA = h->P.dims[v];
   if (n_out != (int64_t)dA * dA) return GSX_E_INVALID;
-  if (dA > 16) {
-    h->err = "marginal: variables of more than 16 dimensions are not supported by the path kernel";
-    return GSX_E_INVALID;
-  }
   gsx_status st = marginals_prepare(h);
   if (st != GSX_OK) return st;
   const Symbolic& S = h->S;
@@ -2694,10 +2764,9 @@ gsx_status gsx_marginal_covariance(gsx_handle h, uint64_t key, double* out, int6
     path.push_back(f);
     max_n = std::max(max_n, S.N[f]);
   }
-  if ((size_t)2 * max_n * dA * sizeof(double) > 160 * 1024 - 4096 - 4096) {
-    h->err = "marginal: the cliques on the path to the root are too large for the one-workgroup kernel";
-    return GSX_E_NOMEM;
-  }
+  // a wide variable, or tall cliques on its path: the variable's columns in groups (the joint entry point splits them)
+  if (dA > 16 || (size_t)2 * max_n * dA * sizeof(double) > 160 * 1024 - 4096 - 4096)
+    return gsx_joint_marginal_covariance(h, &key, 1, out, n_out);
   DevBuf<int> d_path;
   DevBuf<double> d_out;
   HIPCHK(h, d_path.upload(path, h->stream));
@@ -2918,6 +2987,11 @@ gsx_status gsx_get_stats(gsx_handle h, gsx_stats* out) {
     out->max_front_rows = S.max_rows;
     out->n_small_fronts = S.n_small;
     out->n_big_fronts = S.n_big;
+    out->n_medium_fronts = 0;
+    for (int f = 0; f < S.n_fronts; ++f) {
+      out->n_medium_fronts += S.med[f] && S.cls[f] == 1;
+      out->n_tree_fronts += S.tree_tier[f] >= 0;
+    }
     out->factor_flops = S.flops;
     out->front_bytes = S.front_bytes;
     out->lpanel_bytes = S.lpanel_bytes;

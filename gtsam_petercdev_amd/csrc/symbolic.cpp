@@ -485,17 +485,34 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
   // have any number of rows.
   S.lean.assign(nfr, 0);
   S.cls.assign(nfr, 1);
+  S.med.assign(nfr, 0);
+  // MEASURED AND SWITCHED OFF (GSX_MEDIUM=1 turns it on; tests/test_gpu_parity.py keeps the path honest): a medium front
+  // takes ~53 us in its one workgroup (pose3_100k, mean n = 170, F = 45: children 13, panel 15, trailing update 18) and
+  // the medium fronts of a pose graph form a chain a dozen deep, while the level schedule of the blocked path gives up
+  // only six of its seventeen levels for them (the top fronts are wide in F): pose3_100k 2.94 -> 3.46 ms, pose2_100k
+  // 1.65 -> 1.99 ms with the medium tier on.
+  const bool med_off = std::getenv("GSX_MEDIUM") == nullptr;
+  for (int f = 0; f < nfr; ++f) {   // medium fronts first: a leaf's leanness depends on its parent's class
+    if (cap[f] || S.N[f] <= kSmallMaxN || S.N[f] > kMedMaxN || (int64_t)S.N[f] * S.F[f] > kMedMaxPanel || med_off) continue;
+    int leaf_kids = 0;
+    for (int c = S.child_ptr[f]; c < S.child_ptr[f + 1]; ++c) {
+      const int ch = S.children[c];
+      leaf_kids += S.child_ptr[ch + 1] == S.child_ptr[ch] && S.F[ch] <= kLeafMaxF;
+    }
+    S.med[f] = leaf_kids <= kMedMaxLeafKids;
+    S.n_medium += S.med[f];
+  }
   std::vector<int64_t> fsize(nfr);
   for (int f = 0; f < nfr; ++f) {
     const bool childless = S.child_ptr[f + 1] == S.child_ptr[f];
     const int par = S.parent[f];
     bool lean = !cap[f] && childless && S.F[f] <= kLeafMaxF && S.F[f] > 0 && par >= 0 &&
-                (S.N[par] > kSmallMaxN || cap[par]) && (int64_t)S.N[f] * S.F[f] <= kLeafMaxPanel;
+                ((S.N[par] > kSmallMaxN && !S.med[par]) || cap[par]) && (int64_t)S.N[f] * S.F[f] <= kLeafMaxPanel;
     if (lean)
       for (int k = S.fvar_ptr[f] + nfv[f]; k < S.fvar_ptr[f + 1]; ++k) lean = lean && P.dims[S.fvars[k]] <= 16;
     S.lean[f] = lean;
     if (lean) S.cls[f] = 0;
-    else if (S.N[f] > kSmallMaxN || cap[f]) S.cls[f] = 2;
+    else if ((S.N[f] > kSmallMaxN && !S.med[f]) || cap[f]) S.cls[f] = 2;
     else if (childless && S.F[f] <= kLeafMaxF) S.cls[f] = 0;
     if (S.cls[f] == 2) S.n_big++; else S.n_small++;
     int64_t sz = lean ? (int64_t)S.N[f] * S.F[f] : (int64_t)S.N[f] * S.N[f];
@@ -536,22 +553,23 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     S.tree_up.assign(nfr, -1);
     S.tree_npend.assign(nfr, 0);
     const int nt = (int)S.tree_bounds.size();
+    // (a last tier beyond the bounds holds the MEDIUM fronts and everything above them in their subtrees)
     std::vector<int> subn(nfr, 0);
     for (int f = 0; f < nfr && nt > 0; ++f) {  // children have smaller ids
       if (!S.scheduled[f] || S.cls[f] != 1) continue;
       bool ok = true;
-      int mx = S.N[f];
+      int mx = S.med[f] ? kSmallMaxN + 1 : S.N[f];   // (any medium front: the tier after the last bound)
       for (int c = S.child_ptr[f]; c < S.child_ptr[f + 1] && ok; ++c) {
         const int ch = S.children[c];
         if (S.cls[ch] == 0 && !S.lean[ch]) continue;  // done by the leaf launch before the tree kernels
         ok = S.tree_tier[ch] >= 0;
         mx = std::max(mx, subn[ch]);
       }
-      if (!ok || mx > S.tree_bounds.back()) continue;
+      if (!ok || (mx > S.tree_bounds.back() && mx <= kSmallMaxN)) continue;
       subn[f] = mx;
       int t = 0;
-      while (S.tree_bounds[t] < mx) ++t;
-      S.tree_tier[f] = t;
+      while (t < nt && S.tree_bounds[t] < mx) ++t;
+      S.tree_tier[f] = t;    // t == nt: the medium tier
     }
     for (int f = 0; f < nfr; ++f) {
       const int p = S.parent[f];
@@ -578,6 +596,10 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
       const int l = S.level[f];
       if (S.cls[f] != 1 || S.tree_tier[f] >= 0 || n_blk[l] == 0 || n_lds[l] > 1024) continue;
       S.cls[f] = 2;
+      if (S.med[f]) {
+        S.med[f] = 0;
+        S.n_medium--;
+      }
       S.n_big++;
       S.n_small--;
       int64_t sz = (int64_t)S.N[f] * S.N[f];
@@ -804,7 +826,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     S.lvl_small_end[l] = e;
   }
   {
-    const int nt = (int)S.tree_bounds.size();
+    const int nt = (int)S.tree_bounds.size() + 1;   // (+ the medium tier)
     S.tree_start_ptr.assign(nt + 1, 0);
     S.tree_start.clear();
     for (int t = 0; t < nt; ++t) {

@@ -225,6 +225,8 @@ typedef struct gsx_stats {
   int64_t n_cheirality;          /* SFM factors zeroed by cheirality in the last linearize */
   double amalgamation_relax;     /* the amalgamation in effect (the library's choice under GSX_AMALGAMATION_AUTO) */
   int64_t amalgamation_max_frontal_dim;
+  int64_t n_medium_fronts;       /* of the LDS fronts: frontal panel in LDS, trailing block in HBM */
+  int64_t n_tree_fronts;         /* fronts eliminated dependency-driven, one launch per tier, instead of level by level */
 } gsx_stats;
 
 /* ---- on-disk formats (host only) -------------------------
@@ -336,6 +338,10 @@ gsx_status gsx_get_shard(gsx_handle h, gsx_shard_info* info, int32_t* front_owne
  * not allocate; gtsam_petercdev_amd/distributed.py: checked_allreduce).  *count doubles at *device_ptr; the host may
  * overwrite them freely between gsx calls. */
 gsx_status gsx_scratch_buffer(gsx_handle h, double** device_ptr, int64_t* count);
+/* how each front of the current tree is eliminated: bits 0-1 = 0 leaf kernel (panel only), 1 whole front in LDS,
+ * 2 blocked path in HBM, 3 medium (frontal panel in LDS, trailing block in HBM); bit 2 = tree front (dependency-driven
+ * launch); bit 3 = lean leaf (no Schur complement stored: its blocked parent's gather forms it) */
+gsx_status gsx_get_front_classes(gsx_handle h, int32_t* classes);
 gsx_status gsx_get_ordering(gsx_handle h, uint64_t* keys_out);
 /* Bayes-tree structure for parity checks: per front the frontal / separator
  * variable indices (CSR) and the parent front (-1 = root).  Pass NULL arrays to

@@ -978,12 +978,17 @@ def test_leaf_clique_with_many_trailing_rows(gpu, oracle, m):
     assert relerr(gb.marginal_covariance(1), ob.marginal_covariance(1)) < 1e-8
 
 
+@pytest.mark.parametrize("medium", [False, True])
 @pytest.mark.parametrize("seed,dense", [(1, False), (2, True)])
-def test_linear_graph_with_wide_variables(gpu, oracle, seed, dense):
+def test_linear_graph_with_wide_variables(gpu, oracle, seed, dense, medium, monkeypatch):
     """Vector variables of 1 to 40 dimensions (blocks wider than one 16 x 16 matrix-core tile: the gather's wide path, H
     panels and fronts with ragged blocks) in a linear-Gaussian graph — the NonlinearOptimizer::solve seam hands over
     whatever dimensions the caller's variables have.  dense=True adds a cluster that makes blocked (n > 140) fronts with
     wide children below them."""
+    # medium=True: the MEDIUM-front path (gsx_internal.h; frontal panel in LDS, trailing block in HBM — measured slower on
+    # the bench graphs and off by default, DESIGN §4), which these graphs' 150-290-row cliques take
+    if medium:
+        monkeypatch.setenv("GSX_MEDIUM", "1")
     rng = np.random.default_rng(seed)
     dims = [int(d) for d in rng.choice([1, 2, 5, 9, 17, 24, 33, 40], size=36)]
     fg = GaussianFactorGraph()
@@ -1018,14 +1023,17 @@ def test_linear_graph_with_wide_variables(gpu, oracle, seed, dense):
             assert relerr(gb.solve(lam, diag), ob.solve(lam, diag)) < 1e-9, (kind, lam)
         gb.solve(0.0, False)
         ob.solve(0.0, False)
-        # (the marginal path kernel takes variables of up to 16 dimensions — through fronts with wider neighbours here)
+        # marginals of the widest variable of at most 16 dimensions (one pass of the path kernel) and of the widest of all
+        # (Marginals.cpp:107-136 knows no limit: its columns go through the kernel in groups), and a joint of the two
         kw = int(arr.var_keys[int(np.argmax(np.where(arr.var_dims <= 16, arr.var_dims, 0)))])
         assert relerr(gb.marginal_covariance(kw), ob.marginal_covariance(kw)) < 1e-8
-        with pytest.raises(A.GsxError):
-            gb.marginal_covariance(int(arr.var_keys[int(np.argmax(arr.var_dims))]))
+        kx = int(arr.var_keys[int(np.argmax(arr.var_dims))])
+        assert relerr(gb.marginal_covariance(kx), ob.marginal_covariance(kx)) < 1e-8
+        assert relerr(gb.joint_marginal_covariance([kw, kx]), ob.joint_marginal_covariance([kw, kx])) < 1e-8
     st = gb.stats()
     if dense:
         assert st["n_big_fronts"] > 0
+    assert (st["n_medium_fronts"] > 0) == medium   # (NATURAL ordering, the last one set: 150-290-row cliques)
 
 
 @pytest.mark.parametrize("seed", range(24))
@@ -1091,6 +1099,14 @@ def _split_dims(total, rng):
         out.append(d)
         total -= d
     return out
+
+
+@pytest.mark.parametrize("dim_a", [15, 17, 33, 64, 65, 127])
+def test_two_clique_medium_fronts(gpu, oracle, dim_a, monkeypatch):
+    """The same two-clique trees with the MEDIUM-front path switched on (off by default: DESIGN §4): the child (A | B) with
+    131 separator scalars has more than 140 rows and a panel that fits LDS."""
+    monkeypatch.setenv("GSX_MEDIUM", "1")
+    _two_clique_case(gpu, oracle, dim_a, 131)
 
 
 @pytest.mark.parametrize("dim_b", [12, 60, 131])

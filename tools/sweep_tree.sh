@@ -8,6 +8,6 @@ for cfg in "$@"; do
 import json, sys
 d = json.load(open("/tmp/sw.json"))
 k = d["kernels"]
-print("%-44s ms/step %.3f  small %.3f (%d launches) leaf %.3f big %.3f backsolve %.3f" % (sys.argv[1], d["ms_per_step"], d["factor_small_ms"], k["front_small_kernel"]["launches_per_factorization"], d["factor_leaf_ms"], d["factor_big_ms"], d["phases_ms"]["ms_backsolve"]))
+print("%-44s ms/step %.3f  small %.3f (%d launches) leaf %.3f big %.3f backsolve %.3f" % (sys.argv[1], d["ms_per_step"], d["factor_small_ms"], [v for n, v in k.items() if n.startswith("front_small")][0]["launches_per_factorization"], d["factor_leaf_ms"], d["factor_big_ms"], d["phases_ms"]["ms_backsolve"]))
 PY
 done
