@@ -119,7 +119,7 @@ void launch_scatter_states(const DevProblem& P, const int* vars, const int* src_
 void launch_mask_copy(const double* in, const unsigned char* mask, int64_t n, double* out, hipStream_t st);
 
 enum { SC_LAMBDA = 0, SC_ERR = 1, SC_LIN0 = 2, SC_LIND = 3, SC_TRIAL_ERR = 4, SC_DOT0 = 5, SC_DOT1 = 6, SC_DOT2 = 7,
-       SC_DOT3 = 8, SC_COUNT = 12 };
+       SC_DOT3 = 8, SC_LIN0_LOCAL = 9 /* 1/2 sum |b|^2 of this rank's factors: never exchanged */, SC_COUNT = 12 };
 
 struct BigDesc {   // one big front of a level
   i64 off, xoff;             // arena offsets of the n x n front and of its n x F L-panel area
@@ -140,6 +140,10 @@ void launch_error(const DevProblem& P, const double* values, double* partials, i
 // slice > 0: the staged kernel (doubles of LDS per wave = the largest [A b] range of 64 consecutive factors); 0: the direct one
 void launch_linear_error(const DevProblem& P, const double* jac, const double* delta, double* partials,
                          int n_partials_cap, double* scalars, int slice, hipStream_t st);
+// the linearized errors of an LM trial from the right-hand sides and the solved step (kernels.hip: lin0_kernel)
+void launch_lin0(const DevProblem& P, const double* jac, double* partials, int cap, double* scalars, hipStream_t st);
+void launch_model_error(const DevProblem& P, const DevSymbolic& S, const int* vars, int nvars, const double* H,
+                        const double* delta, const double* damp, double* partials, int cap, double* scalars, hipStream_t st);
 void launch_retract(const DevProblem& P, const double* values, const double* delta, double* out, hipStream_t st);
 void launch_assemble_h_group(const DevProblem& P, const DevSymbolic& S, const int* vars, int count, int threads,
                              int lds_bytes, bool global, const double* jac, double* H, hipStream_t st);

@@ -715,6 +715,69 @@ void launch_linear_error(const DevProblem& P, const double* jac, const double* d
   reduce_final_pair_kernel<<<2, 256, 0, st>>>(partials, nb, scalars, SC_LIN0);
 }
 
+// The two linearized errors of an LM trial WITHOUT a pass over the Jacobians (GaussianFactorGraph::error at 0 and at
+// delta, gtsam/linear/GaussianFactorGraph.cpp:71-78, LevenbergMarquardtOptimizer.cpp:178-184):
+//   e(0) = 1/2 sum |b_i|^2                      — the right-hand sides alone, once per linearization (lin0_kernel);
+//   e(delta) = e(0) - 1/2 g'delta - 1/2 lambda delta'D delta   for the delta that solves (H + lambda D) delta = g
+// (1/2 |A delta - b|^2 = 1/2 delta'H delta - g'delta + 1/2 b'b and delta'H delta = g'delta - lambda delta'D delta), with
+// g = J'b read from the rhs rows of the H panels — a few hundred KB instead of every [A b] block.  The model decrease
+// e(0) - e(delta) comes out without the cancellation of the direct evaluation.
+__global__ void __launch_bounds__(256) lin0_kernel(DevProblem P, const double* jac, double* partials) {
+  double acc = 0;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < P.n_active; k += gridDim.x * blockDim.x) {
+    const int f = P.f_active ? P.f_active[k] : k;
+    const int m = P.f_rows[f];
+    const double* b = jac + P.f_jac_off[f] + (i64)m * (P.f_cols[f] - 1);
+    double s = 0;
+    for (int r = 0; r < m; ++r) s += b[r] * b[r];
+    acc += 0.5 * s;
+  }
+  const double t = block_sum(acc);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+__global__ void __launch_bounds__(256) model_error_kernel(DevProblem P, DevSymbolic S, const int* vars, int nvars,
+                                                          const double* H, const double* delta, const double* damp,
+                                                          const double* scalars, double* partials) {
+  const double lambda = scalars[SC_LAMBDA];
+  double acc = 0;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nvars; k += gridDim.x * blockDim.x) {
+    const int v = vars[k];
+    const int d = P.var_dim[v], rows = S.h_rows[v], to = P.var_tan_off[v];
+    const double* p = H + S.h_off[v] + (rows - 1);   // the rhs row of the panel = (J'b)_v
+    for (int j = 0; j < d; ++j) {
+      const double x = delta[to + j];
+      acc += x * (p[(i64)j * rows] + lambda * damp[to + j] * x);
+    }
+  }
+  const double t = block_sum(acc);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+// scalars[SC_LIN0] = e(0) (this rank's share), scalars[SC_LIND] = e(0) - 1/2 sum partials
+__global__ void __launch_bounds__(256) model_final_kernel(const double* partials, int n, double* scalars) {
+  double acc = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) acc += partials[i];
+  const double s = block_sum(acc);
+  if (threadIdx.x == 0) {
+    const double e0 = scalars[SC_LIN0_LOCAL];
+    scalars[SC_LIN0] = e0;
+    scalars[SC_LIND] = e0 - 0.5 * s;
+  }
+}
+void launch_lin0(const DevProblem& P, const double* jac, double* partials, int cap, double* scalars, hipStream_t st) {
+  int nb = (P.n_active + 255) / 256;
+  nb = nb < 1 ? 1 : (nb > cap ? cap : nb);
+  lin0_kernel<<<nb, 256, 0, st>>>(P, jac, partials);
+  reduce_final_kernel<<<1, 256, 0, st>>>(partials, nb, 1, scalars, SC_LIN0_LOCAL);
+}
+void launch_model_error(const DevProblem& P, const DevSymbolic& S, const int* vars, int nvars, const double* H,
+                        const double* delta, const double* damp, double* partials, int cap, double* scalars,
+                        hipStream_t st) {
+  int nb = (nvars + 255) / 256;
+  nb = nb < 1 ? 1 : (nb > cap ? cap : nb);
+  model_error_kernel<<<nb, 256, 0, st>>>(P, S, vars, nvars, H, delta, damp, scalars, partials);
+  model_final_kernel<<<1, 256, 0, st>>>(partials, nb, scalars);
+}
+
 // ---------------------------------------------------------------------------------------------
 // retract (Values::retract, gtsam/nonlinear/Values.cpp:53-64): one thread per variable
 // ---------------------------------------------------------------------------------------------

@@ -176,6 +176,7 @@ struct gsx_context {
   DevStatus* h_status = nullptr;
   static constexpr int kPartials = 4096;
   bool values_set = false, linearized = false, h_ready = false, hdiag_ready = false, solved = false, damp_ready = false;
+  bool lin0_ready = false;   // scalars[SC_LIN0_LOCAL] = 1/2 sum |b|^2 of the current [A b] blocks (cleared whenever they change)
   bool fact_valid = false;   // the arena holds a SUCCESSFUL factorization of the current linearization and tree ...
   double fact_lambda = 0.0;  // ... for this lambda
   bool fact_pending = false; // a factorization is queued whose status the host has not read yet (readback decides)
@@ -951,6 +952,7 @@ void dev_linearize(gsx_context* c) {
   timer_end(c, PH_LINEARIZE);
   c->sc_dirty |= kXLin;
   c->linearized = true;
+  c->lin0_ready = false;
   c->fact_valid = false;
   c->h_ready = false;
   if (c->damp_kind != 0) c->damp_ready = false;  // (lambda I weights do not depend on the linearization: keep them)
@@ -1229,10 +1231,23 @@ void dev_backsolve(gsx_context* c, const WildfireArgs* wf = nullptr) {
   timer_end(c, PH_BACKSOLVE);
 }
 
-void dev_linear_error(gsx_context* c) {
+// solved_step: d_delta is the solution of the damped system just factored (the LM trial) — the two linearized errors then
+// come from the right-hand sides and the step (kernels.hip: lin0_kernel / model_error_kernel), no pass over [A b];
+// otherwise (an arbitrary point: Dogleg, gsx_linear_error) the direct evaluation
+void dev_linear_error(gsx_context* c, bool solved_step = false) {
+  static const bool direct_only = std::getenv("GSX_LINERR_DIRECT") != nullptr;
   timer_begin(c, PH_LINERR);
-  launch_linear_error(c->DP, c->d_jac.p, c->d_delta.p, c->d_partials.p, gsx_context::kPartials, c->d_scalars.p,
-                      c->lin_err_slice, c->stream);
+  if (solved_step && !direct_only && c->h_ready) {
+    if (!c->lin0_ready) {
+      launch_lin0(c->DP, c->d_jac.p, c->d_partials.p, gsx_context::kPartials, c->d_scalars.p, c->stream);
+      c->lin0_ready = true;
+    }
+    launch_model_error(c->DP, c->DS, c->d_hvars.p, (int)c->hv_list.size(), c->d_H.p, c->d_delta.p, c->d_damp.p,
+                       c->d_partials.p, gsx_context::kPartials, c->d_scalars.p, c->stream);
+  } else {
+    launch_linear_error(c->DP, c->d_jac.p, c->d_delta.p, c->d_partials.p, gsx_context::kPartials, c->d_scalars.p,
+                        c->lin_err_slice, c->stream);
+  }
   c->sc_dirty |= (1u << SC_LIN0) | (1u << SC_LIND);
   timer_end(c, PH_LINERR);
 }
@@ -1310,7 +1325,7 @@ gsx_status lm_try_lambda(gsx_context* c, const gsx_lm_params& p, Trace& tr, gsx_
   dev_damping(c, p.diagonal_damping, p.min_diagonal, p.max_diagonal);
   dev_factorize(c, c->lm_lambda);
   dev_backsolve(c);
-  dev_linear_error(c);
+  dev_linear_error(c, true);
   dev_retract(c, c->d_delta.p);
   dev_error(c, c->d_trial.p, SC_TRIAL_ERR);
   gsx_status st = readback(c);
@@ -1878,7 +1893,7 @@ gsx_status gsx_lm_trial(gsx_handle h, int32_t relinearize, double lambda, int32_
   dev_damping(h, diagonal_damping, min_diagonal, max_diagonal);
   dev_factorize(h, lambda);
   dev_backsolve(h);
-  dev_linear_error(h);
+  dev_linear_error(h, true);
   dev_retract(h, h->d_delta.p);
   dev_error(h, h->d_trial.p, SC_TRIAL_ERR);
   st = readback(h);
@@ -2168,6 +2183,7 @@ gsx_status partial_linearize(gsx_handle h, std::vector<int>& dfac) {
     launch_linearize(h->DP, lp, cnt, h->d_values.p, h->d_jac.p, h->d_status.p, sm);
     timer_end(h, PH_LINEARIZE);
   }
+  h->lin0_ready = false;   // (some [A b] blocks changed)
   return GSX_OK;
 }
 // 2. the H panels of the listed variables, group by group with the groups' own launch shapes
@@ -2554,7 +2570,7 @@ static gsx_status gsx_update_impl(gsx_handle h, const gsx_problem_desc* desc, co
   // failed update makes every later numeric call answer GSX_E_STATE until gsx_set_values + gsx_set_ordering rebuild the
   // handle — never kernels on mismatched tables.
   h->has_symbolic = h->values_set = h->linearized = h->h_ready = h->solved = false;
-  h->fact_valid = h->fact_pending = h->hdiag_ready = h->damp_ready = false;
+  h->fact_valid = h->fact_pending = h->hdiag_ready = h->damp_ready = h->lin0_ready = false;
   h->wf_delta_valid = false;
   h->wf_all_replaced = true;
   HostProblem P_old = std::move(h->P);
@@ -2819,6 +2835,7 @@ static gsx_status gsx_set_block_jacobians_impl(gsx_handle h, int32_t first_facto
   }
   HIPCHK(h, hipStreamSynchronize(h->stream));  // (the staging buffer is reused by the next call)
   h->h_ready = false;      // H must be re-assembled from the new blocks
+  h->lin0_ready = false;
   h->hdiag_ready = false;
   h->fact_valid = false;
   h->solved = false;
