@@ -210,6 +210,11 @@ struct gsx_context {
   hipEvent_t side_done[kSide] = {};
   hipEvent_t side_start = nullptr;
   bool side_ready = false;
+  // the SIDE work of a factorization (Symbolic::side_*): a low-priority queue of its own
+  hipStream_t bulk = nullptr;
+  hipEvent_t bulk_go = nullptr, bulk_done = nullptr;
+  size_t leaf_side_group0 = 0;   // leaf_launch[0][leaf_side_group0 ..) are the side leaves' launches
+  bool bulk_pending = false;     // side work of the factorization in flight that the main queue has not waited for yet
   // sharding (gsx_set_shard)
   int shard_rank = 0, shard_world = 1;
   gsx_allreduce_fn shard_cb = nullptr;
@@ -644,7 +649,11 @@ gsx_status upload_symbolic(gsx_context* c) {
     int i = S.lvl_ptr[l];
     for (int k = i; k < S.lvl_leaf_end[l]; ++k) c->leaf_max_F[l] = std::max(c->leaf_max_F[l], S.F[S.sched[k]]);
     // leaf-kernel fronts: sorted by (F, N); a launch = same F, panel size within 1.5x — or more, see below
-    const int le = S.lvl_leaf_end[l];
+    const int le_all = S.lvl_leaf_end[l];
+    if (l == 0) c->leaf_side_group0 = (size_t)-1;
+    for (int part = 0; part < 2; ++part) {   // the leaves launched with the level, then (level 0 only) the side leaves
+    const int le = (l == 0 && part == 0) ? S.leaf_side_begin : le_all;
+    if (l == 0 && part == 1) c->leaf_side_group0 = c->leaf_launch[l].size();
     while (i < le) {
       const int F0 = S.F[S.sched[i]], n0 = std::max(S.N[S.sched[i]], 8);
       int j = i, maxp = 0, maxn = 0;
@@ -668,6 +677,7 @@ gsx_status upload_symbolic(gsx_context* c) {
       for (int k = i; k < j; ++k) rows_below = std::max(rows_below, S.N[S.sched[k]] - S.F[S.sched[k]]);
       c->leaf_launch[l].push_back({i, j - i, maxn, narrow ? 64 : (maxn <= 72 && rows_below <= 64 ? 64 : (maxn <= 110 ? 128 : 256)), maxp});
       i = j;
+    }
     }
     const int se = S.lvl_small_end[l];
     int se_lds = se;   // the medium fronts (n > kSmallMaxN) sit at the end of the level's LDS-class range (sorted by n)
@@ -1037,6 +1047,21 @@ void debug_sync(gsx_context* c, const char* what, int a, int b) {
   fflush(stderr);
 }
 
+// the low-priority queue of the side work (created on first use)
+bool bulk_ready(gsx_context* c) {
+  if (c->bulk) return true;
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return false;
+  if (hipStreamCreateWithPriority(&c->bulk, hipStreamNonBlocking, least) != hipSuccess) {
+    c->bulk = nullptr;
+    return false;
+  }
+  if (hipEventCreateWithFlags(&c->bulk_go, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->bulk_done, hipEventDisableTiming) != hipSuccess)
+    return false;
+  return true;
+}
+
 void dev_factorize(gsx_context* c, double lambda) {
   const Symbolic& S = c->S;
   c->fact_valid = false;   // becomes true when the read-back shows no failed front (readback)
@@ -1062,7 +1087,33 @@ void dev_factorize(gsx_context* c, double lambda) {
     const bool side = c->profiling <= 0 && n_groups >= 4 && c->rest_launch[l].size() >= 4 && max_count < 16384 && side_fork(c);
     unsigned used = 0;
     int gi = 0;
-    for (const SmallLaunch& sl : c->leaf_launch[l]) {
+    // The SIDE work (Symbolic::side_*): the lean leaves whose parents sit above the first blocked level, and their
+    // product-form gather, on the low-priority queue — beside the latency-bound blocked chain of the lower levels
+    // instead of in front of it.  (With per-launch timers everything stays on the one timed queue.)
+    const int sg = S.n_levels;   // the side gather group
+    const bool have_side = S.side_level0 >= 0 && l == 0;
+    const bool use_bulk = have_side && c->profiling <= 0 && bulk_ready(c);
+    const size_t n_main_leaf = (l == 0 && c->leaf_side_group0 != (size_t)-1) ? c->leaf_side_group0 : c->leaf_launch[l].size();
+    if (use_bulk) {
+      // (Forked right behind the zeroing / H terms of the blocked fronts.  Measured on BAL-1723, ms per LM iteration: no
+      //  second queue 1.924; forked here 1.880; forked behind the main queue's own leaves and gather 1.904 — the side work then
+      //  runs beside the first blocked level only, whose 11-workgroup big_rows launch goes from 63 to 153 us under it.  The
+      //  low stream priority does not keep the side kernels off the CUs: what is gained is the blocked chain starting
+      //  earlier, what is lost is every kernel running beside them running slower.)
+      hipEventRecord(c->bulk_go, c->stream);
+      hipStreamWaitEvent(c->bulk, c->bulk_go, 0);
+      for (size_t g = n_main_leaf; g < c->leaf_launch[l].size(); ++g) {
+        const SmallLaunch& sl = c->leaf_launch[l][g];
+        launch_front_leaf(c->DP, c->DS, c->d_leaf_recs.p + (sl.begin - c->leaf_base), sl.count, sl.max_panel, sl.threads,
+                          c->d_H.p, c->d_damp.p, c->d_scalars.p, c->d_arena.p, c->d_status.p, c->bulk);
+      }
+      launch_big_gather(c->GA, S.gseg_lvl_ptr[sg], S.gseg_lvl_ptr[sg + 1] - S.gseg_lvl_ptr[sg], S.gm_lvl_ptr[sg],
+                        S.gm_lvl_ptr[sg + 1] - S.gm_lvl_ptr[sg], c->d_arena.p, c->bulk);
+      hipEventRecord(c->bulk_done, c->bulk);
+      c->bulk_pending = true;
+    }
+    for (size_t g = 0; g < (use_bulk ? n_main_leaf : c->leaf_launch[l].size()); ++g) {
+      const SmallLaunch& sl = c->leaf_launch[l][g];
       if (c->profiling > 0) timer_begin(c, PH_FACTOR_LEAF);
       launch_front_leaf(c->DP, c->DS, c->d_leaf_recs.p + (sl.begin - c->leaf_base), sl.count, sl.max_panel, sl.threads, c->d_H.p,
                         c->d_damp.p, c->d_scalars.p, c->d_arena.p, c->d_status.p,
@@ -1101,6 +1152,17 @@ void dev_factorize(gsx_context* c, double lambda) {
       launch_big_gather(c->GA, S.gseg_lvl_ptr[0], S.gseg_lvl_ptr[1] - S.gseg_lvl_ptr[0], S.gm_lvl_ptr[0],
                         S.gm_lvl_ptr[1] - S.gm_lvl_ptr[0], c->d_arena.p, c->stream);
       if (c->profiling > 0) timer_end(c, PH_K_GATHER);
+    }
+    if (have_side && !use_bulk && S.gseg_lvl_ptr[sg + 1] > S.gseg_lvl_ptr[sg]) {   // (no second queue: in line)
+      if (c->profiling > 0) timer_begin(c, PH_K_GATHER);
+      launch_big_gather(c->GA, S.gseg_lvl_ptr[sg], S.gseg_lvl_ptr[sg + 1] - S.gseg_lvl_ptr[sg], S.gm_lvl_ptr[sg],
+                        S.gm_lvl_ptr[sg + 1] - S.gm_lvl_ptr[sg], c->d_arena.p, c->stream);
+      if (c->profiling > 0) timer_end(c, PH_K_GATHER);
+    }
+    // the fronts above the first blocked level take the side leaves' contributions: those must have landed
+    if (S.side_level0 >= 0 && l == S.side_level0 + 1 && c->bulk_pending) {
+      hipStreamWaitEvent(c->stream, c->bulk_done, 0);
+      c->bulk_pending = false;
     }
     const BigLevel& B = c->big_level[l];
     if (B.count) {
@@ -1455,6 +1517,12 @@ gsx_status gsx_destroy(gsx_handle h) {
         hipEventDestroy(h->side_done[i]);
       }
       hipEventDestroy(h->side_start);
+    }
+    if (h->bulk) {
+      hipStreamSynchronize(h->bulk);
+      hipStreamDestroy(h->bulk);
+      if (h->bulk_go) hipEventDestroy(h->bulk_go);
+      if (h->bulk_done) hipEventDestroy(h->bulk_done);
     }
     if (h->h_scalars) hipHostFree(h->h_scalars);
     if (h->h_status) hipHostFree(h->h_status);

@@ -801,6 +801,28 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     }
   }
   clk.mark("row maps");
+  // ---- side leaves (gsx_internal.h): lean leaves under blocked parents above the first blocked level ----
+  S.side.assign(nfr, 0);
+  S.side_level0 = -1;
+  {
+    static const bool side_off = std::getenv("GSX_SIDE_OFF") != nullptr;
+    int l0 = -1;
+    for (int f = 0; f < nfr; ++f)
+      if (S.cls[f] == 2 && S.scheduled[f] && (l0 < 0 || S.level[f] < l0)) l0 = S.level[f];
+    int64_t n_side = 0, n_lean = 0;
+    if (l0 >= 0 && !side_off && S.shard_world == 1)
+      for (int f = 0; f < nfr; ++f)
+        if (S.lean[f] && S.scheduled[f]) {
+          ++n_lean;
+          if (S.level[S.parent[f]] > l0) {
+            S.side[f] = 1;
+            ++n_side;
+          }
+        }
+    // (worth a second queue only when it moves real work: a tenth of the lean leaves, and thousands of them)
+    if (n_side >= 4096 && n_side * 10 >= n_lean) S.side_level0 = l0;
+    else std::fill(S.side.begin(), S.side.end(), 0);
+  }
   // ---- schedule: by level; inside a level: leaf-kernel fronts, other small (LDS) fronts by N, big fronts ----
   auto cls = [&](int f) { return (int)S.cls[f]; };
   S.sched.clear();
@@ -810,6 +832,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     if (S.level[a] != S.level[b]) return S.level[a] < S.level[b];
     const int ca = cls(a), cb = cls(b);
     if (ca != cb) return ca < cb;
+    if (ca == 0 && S.side[a] != S.side[b]) return S.side[a] < S.side[b];   // the side leaves last among the leaves
     if (ca == 0 && S.F[a] != S.F[b]) return S.F[a] < S.F[b];
     return S.N[a] < S.N[b];
   });
@@ -825,6 +848,9 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     while (e < S.lvl_ptr[l + 1] && cls(S.sched[e]) == 1) ++e;
     S.lvl_small_end[l] = e;
   }
+  S.leaf_side_begin = S.n_levels ? S.lvl_leaf_end[0] : 0;
+  if (S.side_level0 >= 0)
+    while (S.leaf_side_begin > S.lvl_ptr[0] && S.side[S.sched[S.leaf_side_begin - 1]]) --S.leaf_side_begin;
   {
     const int nt = (int)S.tree_bounds.size() + 1;   // (+ the medium tier)
     S.tree_start_ptr.assign(nt + 1, 0);
@@ -854,7 +880,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
       std::vector<int> ld, dims, front;
       std::vector<Src> src;
     };
-    std::vector<LevelOut> lout(S.n_levels);
+    std::vector<LevelOut> lout(S.n_levels + 1);   // (+ the side group)
     std::vector<int> parents;
     for (int p = 0; p < nfr; ++p)
       if (S.cls[p] == 2 && S.scheduled[p]) parents.push_back(p);
@@ -879,6 +905,8 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
       // contribution to a cap front, its own level otherwise
       int lv[3] = {0, S.level[p], S.level[p]};
       if (S.owner[p] < 0) lv[1] = S.cap_level0;
+      // (a parent's lean children are all side leaves or none: sidedness is the parent's level)
+      if (S.side_level0 >= 0 && S.level[p] > S.side_level0) lv[0] = S.n_levels;
       loc.clear();
       for (int ci = S.child_ptr[p]; ci < S.child_ptr[p + 1]; ++ci) {
         const int ch = S.children[ci];
@@ -944,7 +972,8 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
       }
     }
     clk.mark("  gather: contributions");
-    S.gt_lvl_ptr.assign(S.n_levels + 1, 0);
+    const int ngl = S.n_levels + 1;   // gather groups: the levels + the side group
+    S.gt_lvl_ptr.assign(ngl + 1, 0);
     size_t n_src = 0;
     for (const LevelOut& L : lout) n_src += L.src.size();
     S.gs_child.resize(n_src);
@@ -952,7 +981,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     S.gs_loc2.resize(n_src);
     {
       size_t base = 0;
-      for (int l = 0; l < S.n_levels; ++l) {
+      for (int l = 0; l < ngl; ++l) {
         LevelOut& L = lout[l];
         for (size_t t = 0; t < L.dst.size(); ++t) {
           S.gt_dst.push_back(L.dst[t]);
@@ -972,18 +1001,21 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
       }
     }
     S.gt_ptr.push_back((int64_t)n_src);
-    for (int l = 0; l < S.n_levels; ++l) S.gt_lvl_ptr[l + 1] += S.gt_lvl_ptr[l];
+    for (int l = 0; l < ngl; ++l) S.gt_lvl_ptr[l + 1] += S.gt_lvl_ptr[l];
     clk.mark("  gather: tasks");
     // Segments: a task's source list is cut into chunks of at most kGatherChunk sources, one wave each.
     // Single-segment tasks add straight into the destination; multi-segment tasks write partial sums
     // to scratch slots which a second pass adds in slot order (fixed order => deterministic).
-    S.gseg_lvl_ptr.assign(S.n_levels + 1, 0);
-    S.gm_lvl_ptr.assign(S.n_levels + 1, 0);
+    S.gseg_lvl_ptr.assign(ngl + 1, 0);
+    S.gm_lvl_ptr.assign(ngl + 1, 0);
     S.g_max_slots = 0;
+    S.side_slot0 = 0;
     const int ntasks = (int)S.gt_dst.size();
     int t = 0;
-    for (int l = 0; l < S.n_levels; ++l) {
-      int slots = 0;
+    for (int l = 0; l < ngl; ++l) {
+      // (the side group runs beside the level gathers: scratch slots of its own, behind theirs)
+      if (l == S.n_levels) S.side_slot0 = S.g_max_slots;
+      int slots = l == S.n_levels ? S.side_slot0 : 0;
       // (shorter chunks for the levels with few sources were measured: slower — more waves, more scratch)
       const int chunk = kGatherChunk;
       for (; t < S.gt_lvl_ptr[l + 1]; ++t) {

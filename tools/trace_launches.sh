@@ -21,7 +21,7 @@ with open("$out/last_solve.txt", "w") as o:
         s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
         name = r['Kernel_Name'].split('(')[0].replace('gsx::', '').replace('(anonymous namespace)::', '').replace('void ', '')[:40]
         gap = 0 if prev_end is None else (s - prev_end) / 1e3
-        o.write("%-40s grid %8s wg %5s lds %7s  %8.1f us  gap %6.1f\n" % (name, r['Grid_Size_X'], r['Workgroup_Size_X'], r.get('LDS_Block_Size', '?'), (e - s) / 1e3, gap))
+        o.write("%-40s q%s grid %8s wg %5s lds %7s  start %8.1f  %8.1f us  gap %6.1f\n" % (name, r.get('Queue_Id', '?'), r['Grid_Size_X'], r['Workgroup_Size_X'], r.get('LDS_Block_Size', '?'), (s - int(rows[i0]['Start_Timestamp'])) / 1e3, (e - s) / 1e3, gap))
         tot[name] = tot.get(name, 0) + (e - s) / 1e3
         prev_end = e
     o.write("total span %.1f us\n" % ((int(rows[-1]['End_Timestamp']) - int(rows[i0]['Start_Timestamp'])) / 1e3))
