@@ -28,6 +28,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 
 #include "gsx_internal.h"
 #include "kernels.h"
@@ -40,6 +41,14 @@ constexpr int T = kTile;          // 32: edge of the diagonal tiles of the store
 constexpr int kMaxChunk = 192;    // frontal columns one round factors (12 tile rows of 16: 78 tiles over 8 waves)
 
 #ifdef GSX_STAMP
+__device__ unsigned long long g_rstamp[16][8];   // big_diag_rows_kernel: [wave][phase] cycles, block 0
+#define RST_BEGIN unsigned long long rst0__ = __builtin_amdgcn_s_memtime();
+#define RST_ADD(slot)                                                              \
+  {                                                                                \
+    unsigned long long t__ = __builtin_amdgcn_s_memtime();                         \
+    if (lane == 0 && blockIdx.x == 0) g_rstamp[wv][slot] += t__ - rst0__;          \
+    rst0__ = t__;                                                                  \
+  }
 __device__ unsigned long long g_bstamp[16];
 #define BST_BEGIN unsigned long long bst0__ = __builtin_amdgcn_s_memtime();
 #define BST_ADD(slot)                                                          \
@@ -51,6 +60,8 @@ __device__ unsigned long long g_bstamp[16];
 #else
 #define BST_BEGIN
 #define BST_ADD(slot)
+#define RST_BEGIN
+#define RST_ADD(slot)
 #endif
 
 __device__ __forceinline__ void lds_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -321,6 +332,255 @@ __global__ void __launch_bounds__(NW * 64) big_diag_kernel(const BigDesc* descs,
   }
 }
 
+// ---- A'. the same L11 = chol(A11[c0 .. c0 + fw)), ROW-OWNED and barrier-free --------------------------------------------
+// Round 3.  In the kernel above every tile column costs two workgroup barriers, and the critical path D(tc) -> O of the
+// tile under the diagonal -> U of the next diagonal tile -> D(tc + 1) crosses waves twice; measured 4.6 us per 16 pivots
+// of which the D chain is 1.5-1.9.  Here wave r owns tile ROW r (tiles (r, 0..r), in registers) and nothing is a barrier:
+//   * wave tc factors its diagonal tile (D, as above) and publishes L_dd^-T (flag);
+//   * every wave r > tc then forms its tile of the column, L(r, tc) = A(r, tc) L_dd^-T (O), publishes its 16 rows of the
+//     column's strip (a per-row flag), and updates its tiles (r, tc+1 .. r) with the strip rows of the waves above it as
+//     they appear (U);
+//   * wave tc + 1's only remaining tile is its diagonal one: O, one U, and it is in its own D — ONE cross-wave hand-off
+//     (the inverse) per 16 pivots on the critical path, no wait for anybody's trailing updates.
+// Strips live in three LDS buffers (column tc in buffer tc mod 3); a wave writes column tc only when every reader of
+// column tc - 3 has reported done.  All waits are bounded polls of LDS words written by waves of this workgroup (always
+// resident together); a poll that runs out marks the front as failed instead of hanging.
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) big_diag_rows_kernel(const BigDesc* descs, int c0, int chunk, double* arena,
+                                                                DevStatus* status) {
+  constexpr int LS = 18;
+  constexpr int kRows = NW * 16;
+  __shared__ double Ls[3][kRows][LS];   // strips: rows of L of a tile column, 16 columns each
+  __shared__ double dinv[kRows];
+  __shared__ double ldiag[kRows];
+  __shared__ int flagE[NW];             // column tc: the inverse of its diagonal tile is in Xd
+  __shared__ int rowCols[NW];           // row r: number of columns whose strip rows it has published
+  __shared__ int doneCnt[NW];           // column tc: waves that have finished reading its strip
+  __shared__ int sfail;
+  extern __shared__ double dyn[];       // Xd: the 16 x 16 inverses [tc][i][17]; then L10 of every 32-tile [kb][16][17]
+  const BigDesc d = descs[blockIdx.x];
+  const int n = d.N, F = d.F;
+  if (c0 >= F) return;
+  const int fw = min(chunk, F - c0);
+  const int nt16 = (fw + 15) >> 4, nt32 = (fw + T - 1) / T;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double* A = arena + d.off;
+  double* X = arena + d.xoff;
+  double* Xd = dyn;
+  double* t10 = dyn + (size_t)nt16 * 16 * 17;
+  if (tid < NW) {
+    flagE[tid] = 0;
+    rowCols[tid] = 0;
+    doneCnt[tid] = 0;
+  }
+  if (tid == 0) sfail = 0;
+  const int r = wv;                      // this wave's tile row
+  const bool active = r < nt16;
+  const int rr = 16 * r + li;            // this lane's row
+  v4d acc[NW];
+#pragma unroll
+  for (int j = 0; j < NW; ++j) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int cc = 16 * j + 4 * q + lk;
+      double v = (rr == cc) ? 1.0 : 0.0;  // padding beyond fw: identity
+      if (active && j <= r && rr < fw && cc < fw) {
+        const int hi = max(rr, cc), lo = min(rr, cc);  // the diagonal tile is kept symmetric
+        v = A[(c0 + hi) + (i64)(c0 + lo) * n];
+      }
+      acc[j][q] = v;
+    }
+  }
+  lds_bar();   // (the flags are zero)
+  RST_BEGIN
+  int fail = 0;
+  // bounded poll of an LDS word another wave of this workgroup will set
+  auto wait_ge = [&](int* word, int want) {
+    int polls = 0;
+    while (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++polls > (1 << 18)) {   // (tens of milliseconds: a logic error, not a slow wave)
+        fail = 1;
+        break;
+      }
+    }
+  };
+  // a finished tile (r, tc): L inside a diagonal 32-tile goes to the square, the rest to the L-panel area; the tile under
+  // the diagonal inside a 32-tile also to LDS (the stored 32 x 32 inverses are assembled from it)
+  auto store_tile = [&](const v4d& t, int tc) {
+    const int jb = 16 * tc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int cc = jb + 4 * q + lk;
+      if (rr >= fw || cc >= fw || rr < cc) continue;
+      const bool same = (rr >> 5) == (cc >> 5);
+      (same ? A : X)[(c0 + rr) + (i64)(c0 + cc) * n] = t[q];
+      if (same && r == tc + 1) t10[((size_t)(rr >> 5) * 16 + (rr & 15)) * 17 + (cc & 15)] = t[q];
+    }
+  };
+  if (active) {
+    v4d last = {0.0, 0.0, 0.0, 0.0};   // L(r, r - 1): stored after this row's D (the hand-off comes first)
+    // ---- the columns left of the diagonal: O, then U of the tiles right of the column.  tc is a compile-time index (the
+    //      tiles are registers); a wave leaves the chain of guards at its own row ----
+#pragma unroll
+    for (int tc = 0; tc < NW - 1; ++tc) {
+      if (tc < r) {
+        // the strip buffer of column tc was column tc - 3's: every reader of that one must be done
+        if (tc >= 3) wait_ge(&doneCnt[tc - 3], nt16 - 1 - (tc - 3));
+        RST_ADD(1)
+        wait_ge(&flagE[tc], 1);
+        RST_ADD(2)
+        // O: L(r, tc) = A(r, tc) L_dd^-T
+        const double* xd = Xd + (size_t)tc * 16 * 17 + li * 17 + lk;
+        v4d nt = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) nt = __builtin_amdgcn_mfma_f64_16x16x4f64(xd[4 * s4], acc[tc][s4], nt, 0, 0, 0);
+        if (tc + 1 == r) {
+          // the critical hand-off: this row's diagonal tile takes its last update straight from the registers (both
+          // operands are this wave's own L(r, tc)); everything else of the step waits until D is out
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) acc[tc + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-nt[s4], nt[s4], acc[tc + 1], 0, 0, 0);
+          last = nt;
+        }
+        // this row's 16 rows of the column's strip
+        double(*Lb)[LS] = Ls[tc % 3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Lb[rr][4 * q + lk] = nt[q];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(&rowCols[r], tc + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        RST_ADD(3)
+        if (tc + 1 < r) {
+          // U: (r, j) -= L(r, tc) L(j, tc)' for j = tc + 1 .. r, the rows above as they appear
+          const double* pb = &Lb[rr][lk];
+          const double b0 = pb[0], b1 = pb[4], b2 = pb[8], b3 = pb[12];
+#pragma unroll
+          for (int j = tc + 1; j < NW; ++j) {
+            if (j <= r) {
+              if (j < r) {
+                RST_ADD(6)
+                wait_ge(&rowCols[j], tc + 1);
+                RST_ADD(5)
+              }
+              const double* pa = &Lb[16 * j + li][lk];
+              const double a0 = pa[0], a1 = pa[4], a2 = pa[8], a3 = pa[12];
+              acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0, b0, acc[j], 0, 0, 0);
+              acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, b1, acc[j], 0, 0, 0);
+              acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a2, b2, acc[j], 0, 0, 0);
+              acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a3, b3, acc[j], 0, 0, 0);
+            }
+          }
+          RST_ADD(6)
+          store_tile(nt, tc);
+          if (lane == 0) __hip_atomic_fetch_add(&doneCnt[tc], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          RST_ADD(4)
+        }
+      }
+    }
+    // ---- D: this row's diagonal tile, alone (straight-line: see big_diag_kernel) ----
+    {
+      const int jb = 16 * r;
+      asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+      v4d pt = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int j = 0; j < NW; ++j)
+        if (j == r) pt = acc[j];
+      RST_ADD(7)
+      __builtin_amdgcn_s_setprio(3);
+      v4d E;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) E[q] = (li == 4 * q + lk) ? 1.0 : 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int q = j >> 2, lkj = j & 3;
+        __builtin_amdgcn_sched_barrier(0);
+        int lj = li;
+        asm volatile("" : "+v"(lj));
+        const double dj = readlane_f64(pt[q], lkj * 16 + j);
+        const double sj = rsqrt_refined(dj);
+        const bool colj = lk == lkj;
+        const double xj = pt[q] * sj;
+        const double xm = (colj && lj >= j) ? xj : 0.0;
+        const double ej = colj ? E[q] * sj : 0.0;
+        pt[q] = colj ? xm : pt[q];
+        E[q] = colj ? ej : E[q];
+        if (j < 15) {
+          const double xu = (lj > j) ? xm : 0.0;
+          pt = __builtin_amdgcn_mfma_f64_16x16x4f64(-xu, xu, pt, 0, 0, 0);
+          E = __builtin_amdgcn_mfma_f64_16x16x4f64(-xu, ej, E, 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      double* xd = Xd + (size_t)r * 16 * 17;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xd[(4 * q + lk) * 17 + li] = E[q];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(&flagE[r], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      RST_ADD(0)
+      // (off the critical path from here on)
+      if (lk == (li & 3)) {
+        const int qd = li >> 2;
+        const double l = (qd == 0) ? pt[0] : ((qd == 1) ? pt[1] : ((qd == 2) ? pt[2] : pt[3]));
+        ldiag[jb + li] = l;
+        dinv[jb + li] = 1.0 / l;
+        if (jb + li < fw && !(l > 0)) fail = 1;  // non-positive or non-finite pivot (Eigen::LLT NumericalIssue)
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {   // the inverse's strictly lower part inside its 32-tile, transposed
+        const int i = 4 * q + lk, c = li;
+        if (i > c && jb + i < fw) A[(c0 + jb + c) + (i64)(c0 + jb + i) * n] = E[q];
+      }
+      store_tile(pt, r);
+      if (r > 0) {
+        store_tile(last, r - 1);
+        if (lane == 0) __hip_atomic_fetch_add(&doneCnt[r - 1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      RST_ADD(4)
+    }
+  }
+  if (fail) sfail = 1;
+  lds_bar();
+
+  // ---- (L^-1)' of every diagonal 32-tile into its strictly upper triangle, 1 / L_cc into the L-panel area ----
+  for (int c = tid; c < fw; c += NW * 64) X[(c0 + c) + (i64)(c0 + c) * n] = dinv[c];
+  for (int kb = wv; kb < nt32; kb += NW) {
+    if (fw - kb * T <= 16) continue;  // a single 16-block
+    const double* L10 = t10 + (size_t)kb * 16 * 17;
+    const double* X00 = Xd + (size_t)(2 * kb) * 16 * 17;
+    const double* X11 = Xd + (size_t)(2 * kb + 1) * 16 * 17;
+    const int w1 = min(16, fw - kb * T - 16);
+    v4d t1 = {0.0, 0.0, 0.0, 0.0}, t2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {  // T[i][jj] = sum_k L10[i][k] X00[k][jj]; lane: t1[q] = T[4 q + lk][li]
+      const double a = (li < w1) ? L10[li * 17 + 4 * s4 + lk] : 0.0;
+      t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X00[(4 * s4 + lk) * 17 + li], t1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+      t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-X11[li * 17 + 4 * s4 + lk], t1[s4], t2, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = 4 * q + lk;
+      if (i < w1) A[(c0 + kb * T + li) + (i64)(c0 + kb * T + 16 + i) * n] = t2[q];
+    }
+  }
+  if (tid == 0) {
+    int bad = sfail;
+    if (d.parent == kStandaloneFront && c0 + fw == F) {  // (the dense entry: one clique, tested here — cholesky.cpp:145-158)
+      int e1, e2;
+      (void)frexp(ldiag[fw - 1], &e1);
+      if (F >= 2) {
+        const double p2 = (fw >= 2) ? ldiag[fw - 2] : A[(F - 2) + (i64)(F - 2) * n];
+        (void)frexp(p2, &e2);
+        if (!(e2 - e1 < 12)) bad = 1;
+      } else if (!(e1 > -12)) {
+        bad = 1;
+      }
+    }
+    if (bad) report_failure(status, d.front);
+  }
+}
+
 // lane roles of the 256-thread kernels: wave wv owns the 16 x 16 quadrant (row half wv & 1, column half wv >> 1) of
 // a 32 x 32 tile; entry q of a lane = (row r0 + li, column cq0 + 4 q + lk)
 struct Quad {
@@ -515,6 +775,13 @@ void big_stamp_dump(const char* what) {
 
   unsigned long long z[16] = {0};
   hipMemcpyToSymbol(HIP_SYMBOL(g_bstamp), z, sizeof(z));
+  unsigned long long rs[16][8];
+  hipMemcpyFromSymbol(rs, HIP_SYMBOL(g_rstamp), sizeof(rs));
+  for (int w = 0; w < 12; ++w)
+    printf("[rstamp] wave %2d: D %8llu | wait buffer %8llu | wait E %8llu | O+publish %8llu | store %8llu | wait rows %8llu | U %8llu | top %8llu\n",
+           w, rs[w][0], rs[w][1], rs[w][2], rs[w][3], rs[w][4], rs[w][5], rs[w][6], rs[w][7]);
+  unsigned long long rz[16][8] = {};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_rstamp), rz, sizeof(rz));
 }
 #endif
 
@@ -562,6 +829,22 @@ void launch_big_diag(const BigDesc* descs, int count, const BigPlan& plan, int r
   const int c0 = round * plan.chunk, fw = plan.fw[round];
   const size_t lds = lds_for(fw);
   const int nt16 = (fw + 15) / 16;
+  static const bool v1 = std::getenv("GSX_DIAG_V1") != nullptr;
+  if (!v1) {   // the row-owned, barrier-free kernel
+    static bool attr2 = false;
+    const auto lds2_for = [](int w) { return (size_t)(((w + 15) / 16) * 16 * 17 + ((w + T - 1) / T) * 16 * 17) * sizeof(double); };
+    if (!attr2) {
+      hipFuncSetAttribute((const void*)big_diag_rows_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2_for(kMaxChunk));
+      hipFuncSetAttribute((const void*)big_diag_rows_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2_for(kMaxChunk));
+      hipFuncSetAttribute((const void*)big_diag_rows_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2_for(kMaxChunk));
+      attr2 = true;
+    }
+    const size_t lds2 = lds2_for(fw);
+    if (nt16 <= 4) big_diag_rows_kernel<4><<<count, 256, lds2, st>>>(descs, c0, plan.chunk, arena, status);
+    else if (nt16 <= 8) big_diag_rows_kernel<8><<<count, 512, lds2, st>>>(descs, c0, plan.chunk, arena, status);
+    else big_diag_rows_kernel<12><<<count, 768, lds2, st>>>(descs, c0, plan.chunk, arena, status);
+    return;
+  }
   // tiles: nt16 (nt16 + 1) / 2 over the waves, at least as many waves as tile rows
   if (nt16 <= 4) big_diag_kernel<4, 3><<<count, 256, lds, st>>>(descs, c0, plan.chunk, arena, status);
   else if (nt16 <= 6) big_diag_kernel<8, 3><<<count, 512, lds, st>>>(descs, c0, plan.chunk, arena, status);

@@ -589,12 +589,13 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     for (int f = 0; f < nfr; ++f) nlev = std::max(nlev, S.level[f] + 1);
     std::vector<int> n_lds(nlev, 0), n_blk(nlev, 0);
     for (int f = 0; f < nfr; ++f) {
+      if (!S.scheduled[f]) continue;   // (another rank's subtree: not in this rank's launches)
       if (S.cls[f] == 1 && S.tree_tier[f] < 0) n_lds[S.level[f]]++;  // (tree fronts cost no launch of their level)
       else if (S.cls[f] == 2) n_blk[S.level[f]]++;
     }
     for (int f = 0; f < nfr; ++f) {
       const int l = S.level[f];
-      if (S.cls[f] != 1 || S.tree_tier[f] >= 0 || n_blk[l] == 0 || n_lds[l] > 1024) continue;
+      if (!S.scheduled[f] || S.cls[f] != 1 || S.tree_tier[f] >= 0 || n_blk[l] == 0 || n_lds[l] > 1024) continue;
       S.cls[f] = 2;
       if (S.med[f]) {
         S.med[f] = 0;

@@ -48,5 +48,8 @@ int main(int argc, char** argv) {
   }
   printf("n=%d F=%d count=%d rounds=%d chunk=%d: diag %.1f us  rows %.1f us  schur %.1f us  (per factorization, event-timed incl. ~launch)\n",
          n, F, count, plan.rounds(), plan.chunk, 1e3 * tot[0] / reps, 1e3 * tot[1] / reps, 1e3 * tot[2] / reps);
+#ifdef GSX_STAMP
+  big_stamp_dump("bench (totals over all repetitions; s_memtime ticks of 100 MHz)");
+#endif
   return 0;
 }
