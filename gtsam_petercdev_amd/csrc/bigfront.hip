@@ -332,6 +332,63 @@ __global__ void __launch_bounds__(NW * 64) big_diag_kernel(const BigDesc* descs,
   }
 }
 
+// ---- D, four pivots at a time --------------------------------------------------------------------------------------
+// The pivot-by-pivot tile factorization above issues ~38 vector instructions and two matrix-core instructions per pivot
+// (the lane masks, the reciprocal square root, two rank-1 updates), ~370 cycles on a lone wave — and that chain is the
+// critical path of every blocked front.  Here the 16 x 16 tile goes four columns at a time: the 4 x 4 diagonal block is
+// read out with ten lane reads and factored, together with its inverse, in wave-uniform registers (every lane the same
+// numbers: 4 reciprocal square roots and ~30 multiply-adds); then ONE matrix-core instruction forms the block's four
+// columns of L, X = A_b M' (M = L44^-1 sits in the sixteen lanes of the operand that face the block), and ONE applies the
+// rank-4 update to the columns to the right; the inverse tile E = L_dd^-T follows with the same two instructions.
+// pt: the tile, lane (li, lk) holds (row li, column 4 q + lk); only its lower triangle is read.  A non-positive pivot
+// turns its column into NaNs (caught by the caller's test of the diagonal).
+// MEASURED, NOT USED (compile with GSX_D_BLOCK4 to switch it in; parity-green): 125 instructions per four pivots against
+// 180, and no faster — 5 400-7 600 cycles per tile against 5 900-8 600 (tools/bigfront_bench.hip, F = 192: 51.7 us
+// against 50.0; F = 30: 15.7 against 18.0).  The twenty v_readlane of the 4 x 4 block cost ~30 cycles each, as much as
+// the matrix-core and mask instructions they replace: the chain is bound by how fast ONE wave issues instructions
+// that feed scalar registers, not by their number.
+__device__ __forceinline__ void tile_potrf16_b4(v4d& pt, v4d& E, const int li, const int lk) {
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int base = 4 * b;
+    const double d00 = readlane_f64(pt[b], base), d10 = readlane_f64(pt[b], base + 1), d20 = readlane_f64(pt[b], base + 2),
+                 d30 = readlane_f64(pt[b], base + 3), d11 = readlane_f64(pt[b], 16 + base + 1),
+                 d21 = readlane_f64(pt[b], 16 + base + 2), d31 = readlane_f64(pt[b], 16 + base + 3),
+                 d22 = readlane_f64(pt[b], 32 + base + 2), d32 = readlane_f64(pt[b], 32 + base + 3),
+                 d33 = readlane_f64(pt[b], 48 + base + 3);
+    // L44 and M = L44^-1 (r_i = 1 / l_ii)
+    const double r0 = rsqrt_refined(d00);
+    const double l10 = d10 * r0, l20 = d20 * r0, l30 = d30 * r0;
+    const double r1 = rsqrt_refined(fma(-l10, l10, d11));
+    const double l21 = fma(-l20, l10, d21) * r1, l31 = fma(-l30, l10, d31) * r1;
+    const double r2 = rsqrt_refined(fma(-l21, l21, fma(-l20, l20, d22)));
+    const double l32 = fma(-l31, l21, fma(-l30, l20, d32)) * r2;
+    const double r3 = rsqrt_refined(fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, d33))));
+    const double m10 = -r1 * (l10 * r0), m21 = -r2 * (l21 * r1), m32 = -r3 * (l32 * r2);
+    const double m20 = -r2 * fma(l21, m10, l20 * r0), m31 = -r3 * fma(l32, m21, l31 * r1);
+    const double m30 = -r3 * fma(l32, m20, fma(l31, m10, l30 * r0));
+    // the operand Linv16[li][base + lk]: M[li - base][lk] on the block's rows, zero elsewhere
+    const int i = li - base;
+    const double row0 = lk == 0 ? r0 : 0.0;
+    const double row1 = lk == 0 ? m10 : (lk == 1 ? r1 : 0.0);
+    const double row2 = lk == 0 ? m20 : (lk == 1 ? m21 : (lk == 2 ? r2 : 0.0));
+    const double row3 = lk == 0 ? m30 : (lk == 1 ? m31 : (lk == 2 ? m32 : r3));
+    const double aop = i == 0 ? row0 : (i == 1 ? row1 : (i == 2 ? row2 : (i == 3 ? row3 : 0.0)));
+    const v4d z = {0.0, 0.0, 0.0, 0.0};
+    const v4d x = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, pt[b], z, 0, 0, 0);
+    const v4d eb = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, E[b], z, 0, 0, 0);
+    const bool below = li >= base + 4;
+    const double xn = x[b];
+    pt[b] = below ? xn : ((i >= 0 && lk <= i) ? xn : 0.0);   // (zero above the diagonal)
+    E[b] = eb[b];
+    if (b < 3) {
+      const double xu = below ? xn : 0.0;
+      pt = __builtin_amdgcn_mfma_f64_16x16x4f64(-xu, xu, pt, 0, 0, 0);
+      E = __builtin_amdgcn_mfma_f64_16x16x4f64(-xu, eb[b], E, 0, 0, 0);
+    }
+  }
+}
+
 // ---- A'. the same L11 = chol(A11[c0 .. c0 + fw)), ROW-OWNED and barrier-free --------------------------------------------
 // Round 3.  In the kernel above every tile column costs two workgroup barriers, and the critical path D(tc) -> O of the
 // tile under the diagonal -> U of the next diagonal tile -> D(tc + 1) crosses waves twice; measured 4.6 us per 16 pivots
@@ -490,6 +547,7 @@ __global__ void __launch_bounds__(NW * 64) big_diag_rows_kernel(const BigDesc* d
       v4d E;
 #pragma unroll
       for (int q = 0; q < 4; ++q) E[q] = (li == 4 * q + lk) ? 1.0 : 0.0;
+#ifndef GSX_D_BLOCK4   // (the four-pivots-at-a-time variant below: measured no faster, see tile_potrf16_b4)
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int q = j >> 2, lkj = j & 3;
@@ -510,6 +568,9 @@ __global__ void __launch_bounds__(NW * 64) big_diag_rows_kernel(const BigDesc* d
           E = __builtin_amdgcn_mfma_f64_16x16x4f64(-xu, ej, E, 0, 0, 0);
         }
       }
+#else
+      tile_potrf16_b4(pt, E, li, lk);
+#endif
       __builtin_amdgcn_s_setprio(0);
       double* xd = Xd + (size_t)r * 16 * 17;
 #pragma unroll
