@@ -522,7 +522,7 @@ def main():
         "phases_ms": phases,
         "factor_leaf_ms": tot_leaf, "factor_small_ms": tot_small, "factor_big_ms": tot_big,
         "symbolic": {k: st[k] for k in ("n_fronts", "n_levels", "max_front_dim", "max_front_rows", "n_small_fronts",
-                                        "n_big_fronts", "n_medium_fronts", "n_tree_fronts", "factor_flops", "front_bytes", "lpanel_bytes",
+                                        "n_big_fronts", "n_medium_fronts", "n_tree_fronts", "n_upper_levels", "factor_flops", "front_bytes", "lpanel_bytes",
                                         "jacobian_bytes", "hessian_bytes", "total_dim")},
         "front_split": split, "kernels": per_kernel, "host_ordering_s": t_order, "host_symbolic_s": t_symbolic,
         "roofline": roofline,

@@ -74,11 +74,22 @@ struct Symbolic {
   std::vector<int> lvl_small_end;    // level -> end of the small (LDS) fronts inside the level range
   std::vector<int> lvl_leaf_end;     // level 0 only: end of the leaf-kernel fronts (no children, F <= kLeafMaxF)
   int n_levels = 0;
+  // The UPPER schedule of the full factorization / back-substitution: the fronts that are neither tree fronts nor leaf-kernel
+  // cliques (every blocked front, and the LDS fronts above one) are levelled among THEMSELVES — ulevel = longest chain of
+  // upper fronts below — because everything else is finished by the leaf launches and the tree kernels before the first
+  // of them starts.  (The height-from-the-leaves levels above stay the order of gsx_relinearize_partial and of the wildfire
+  // pass.)  pose3_100k: 17 levels with blocked fronts by height, 11 by ulevel.
+  std::vector<int> ulevel;           // front -> upper level, -1: not an upper front
+  std::vector<int> usched;           // upper fronts by (ulevel, LDS-class before blocked, n)
+  std::vector<int> ulvl_ptr;         // ulevel -> range in usched (size n_ulevels + 1)
+  std::vector<int> ulvl_small_end;   // ulevel -> end of the LDS-class fronts inside the range
+  int n_ulevels = 0;
+  int cap_ulevel0 = -1;              // first upper level of the cap, -1: no cap
   // SIDE work: lean leaves whose (blocked) parent sits above the first blocked level are needed late — their leaf
   // factorization and their product-form gather (gather group `n_levels`, scratch slots from side_slot0) run on a second,
   // low-priority queue beside the blocked chain of the lower levels; the main queue waits for them before level
   // side_level0 + 1.  side_level0 < 0: none.
-  int side_level0 = -1;              // the first level with blocked fronts
+  int side_level0 = -1;              // the first UPPER level with blocked fronts
   int leaf_side_begin = 0;           // position in sched where the side leaves of level 0 start (== lvl_leaf_end[0]: none)
   int side_slot0 = 0;                // first scratch slot of the side gather group
   std::vector<char> side;            // front -> side leaf
@@ -100,13 +111,13 @@ struct Symbolic {
   std::vector<int64_t> gt_ptr;       // task -> range in the source arrays (size n_tasks + 1)
   std::vector<int> gs_child, gs_loc; // source: child front id, offset of the block inside the child's front
   std::vector<int> gs_loc2;          // lean child: row of the second factor in its L panel (gs_loc = row of the first); else -1
-  std::vector<int> gt_lvl_ptr;       // level of the PARENT -> task range (size n_levels + 2: the side group last)
+  std::vector<int> gt_lvl_ptr;       // upper level of the PARENT -> task range (size n_ulevels + 2: the side group last)
   // segments of the source lists (one wave each) and the multi-segment tasks that need a combine pass
   std::vector<int> gseg_task, gseg_slot;          // segment -> task, scratch slot (-1: adds straight to dst)
   std::vector<int64_t> gseg_begin, gseg_end;      // segment -> source range
-  std::vector<int> gseg_lvl_ptr;                  // level -> segment range (size n_levels + 2: the side group last)
+  std::vector<int> gseg_lvl_ptr;                  // upper level -> segment range (size n_ulevels + 2: the side group last)
   std::vector<int> gm_task, gm_slot, gm_nslots;   // multi-segment task -> first slot, number of slots
-  std::vector<int> gm_lvl_ptr;                    // level -> multi-task range (size n_levels + 2)
+  std::vector<int> gm_lvl_ptr;                    // upper level -> multi-task range (size n_ulevels + 2)
   int g_max_slots = 0;                            // scratch slots needed (x 128 doubles), reused per level
   // choleskyPartial's conditioning test per REFERENCE clique: arena offsets of the last / second-to-last (-1: single pivot)
   // diagonal entries of L, and the front that holds them (only the fronts this rank factors)

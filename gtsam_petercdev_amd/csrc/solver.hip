@@ -141,7 +141,7 @@ struct gsx_context {
   // fronts level by level (rest_launch: ranges of d_rest_ids); small_launch keeps ALL of them for the filtered plans of
   // gsx_relinearize_partial
   std::vector<std::vector<SmallLaunch>> rest_launch;
-  DevBuf<int> d_rest_ids, d_tree_start, d_tree_up, d_tree_npend, d_tree_pending, d_tree_cursor;
+  DevBuf<int> d_usched, d_rest_ids, d_tree_start, d_tree_up, d_tree_npend, d_tree_pending, d_tree_cursor;
   // back-substitution of the tree fronts in one launch (bigfront.hip: backsolve_tree_kernel)
   DevBuf<int> d_bst_roots, d_bst_child_ptr, d_bst_children, d_bst_counters;
   DevBuf<unsigned long long> d_bst_ready;
@@ -194,7 +194,7 @@ struct gsx_context {
   std::vector<GatherSeg> h_gsegs;
   std::vector<int> hv_list, hv_group_of_var, hv_pos;
   std::vector<int> fr_sched_pos, fr_group;        // front -> position in the schedule; launch group / big-desc index
-  std::vector<int> fr_seg_ptr, fr_segs, seg_level; // destination front -> its gather segments; segment -> level
+  std::vector<int> fr_seg_ptr, fr_segs, seg_level; // destination front -> its gather segments; segment -> gather group
   std::vector<int> fr_gm_ptr, fr_gms, gm_level;    // ... and its multi-segment combine entries
   struct PartialScratch {                          // device tables of gsx_relinearize_partial, reused between calls
     DevBuf<int> marked, src_off, lists[6], hv, ids, gm_task, gm_slot, gm_nslots;
@@ -638,12 +638,10 @@ gsx_status upload_symbolic(gsx_context* c) {
   }
   // ---- factorization launch plan ---------------------------------------------------------------------
   c->small_launch.assign(S.n_levels, {});
-  c->big_level.assign(S.n_levels, BigLevel());
   c->big_descs.clear();
   c->big_max_n = c->big_max_nfv = 0;
   c->leaf_launch.assign(S.n_levels, {});
   c->leaf_max_F.assign(S.n_levels, 0);
-  c->rest_launch.assign(S.n_levels, {});
   std::vector<int> rest_ids;
   for (int l = 0; l < S.n_levels; ++l) {
     int i = S.lvl_ptr[l];
@@ -741,29 +739,33 @@ gsx_status upload_symbolic(gsx_context* c) {
         G.push_back(m);
       }
     }
-    {
-      // what the level loop of the full factorization still launches: the LDS-class fronts that are not tree fronts (they
-      // sit above a blocked front), one launch a level
-      for (int pass = 0; pass < 2; ++pass) {   // the whole-front-in-LDS ones, then the medium ones
-        SmallLaunch r{(int)rest_ids.size(), 0, 0, 0};
-        r.medium = pass == 1;
-        for (int k = S.lvl_leaf_end[l]; k < se; ++k) {
-          const int f = S.sched[k];
-          if (S.tree_tier[f] >= 0 || (S.med[f] != 0) != r.medium) continue;
-          rest_ids.push_back(f);
-          r.count++;
-          r.max_n = std::max(r.max_n, S.N[f]);
-          r.max_F = std::max(r.max_F, S.F[f]);
-          r.max_panel = std::max(r.max_panel, S.N[f] * S.F[f]);
-        }
-        r.threads = r.medium ? 512 : small_threads_for(r.max_n);
-        if (r.count) c->rest_launch[l].push_back(r);
+  }
+  // ---- the UPPER schedule (Symbolic::ulevel): what the level loop of the full factorization / back-substitution runs —
+  //      per upper level the LDS-class fronts that are not tree fronts (whole-front-in-LDS ones, then medium ones: two
+  //      launches at most) and the blocked fronts ----
+  c->big_level.assign(S.n_ulevels, BigLevel());
+  c->rest_launch.assign(S.n_ulevels, {});
+  for (int l = 0; l < S.n_ulevels; ++l) {
+    const int b0 = S.ulvl_ptr[l], se = S.ulvl_small_end[l];
+    for (int pass = 0; pass < 2; ++pass) {
+      SmallLaunch r{(int)rest_ids.size(), 0, 0, 0};
+      r.medium = pass == 1;
+      for (int k = b0; k < se; ++k) {
+        const int f = S.usched[k];
+        if ((S.med[f] != 0) != r.medium) continue;
+        rest_ids.push_back(f);
+        r.count++;
+        r.max_n = std::max(r.max_n, S.N[f]);
+        r.max_F = std::max(r.max_F, S.F[f]);
+        r.max_panel = std::max(r.max_panel, S.N[f] * S.F[f]);
       }
+      r.threads = r.medium ? 512 : small_threads_for(r.max_n);
+      if (r.count) c->rest_launch[l].push_back(r);
     }
     BigLevel& B = c->big_level[l];
     B.begin = (int)c->big_descs.size();
-    for (int k = se; k < S.lvl_ptr[l + 1]; ++k) {
-      const int f = S.sched[k];
+    for (int k = se; k < S.ulvl_ptr[l + 1]; ++k) {
+      const int f = S.usched[k];
       c->big_descs.push_back(BigDesc{(i64)S.off[f], (i64)S.off[f] + big_panel_offset(S.N[f]), S.N[f], S.F[f], f,
                                      S.parent[f]});
       c->big_max_n = std::max(c->big_max_n, S.N[f]);
@@ -772,6 +774,7 @@ gsx_status upload_symbolic(gsx_context* c) {
     B.count = (int)c->big_descs.size() - B.begin;
     plan_big_group(c->big_descs.data() + B.begin, B.count, B.plan);
   }
+  HIPCHK(c, c->d_usched.upload(S.usched, st));
   HIPCHK(c, c->d_rest_ids.upload(rest_ids, st));
   {
     c->tree_tiers.clear();
@@ -838,8 +841,8 @@ gsx_status upload_symbolic(gsx_context* c) {
     auto csr = [&](const std::vector<int>& task_of, const std::vector<int>& lvl_ptr, std::vector<int>& ptr,
                    std::vector<int>& items, std::vector<int>& level_of) {
       ptr.assign(S.n_fronts + 1, 0);
-      level_of.assign(task_of.size(), 0);
-      for (int l = 0; l < S.n_levels; ++l)
+      level_of.assign(task_of.size(), 0);   // (the gather GROUP: an upper level, or n_ulevels = the side group)
+      for (int l = 0; l + 1 < (int)lvl_ptr.size(); ++l)
         for (int i = lvl_ptr[l]; i < lvl_ptr[l + 1]; ++i) level_of[i] = l;
       for (int t : task_of) ptr[S.gt_front[t] + 1]++;
       for (int f = 0; f < S.n_fronts; ++f) ptr[f + 1] += ptr[f];
@@ -1074,26 +1077,16 @@ void dev_factorize(gsx_context* c, double lambda) {
   if (!c->big_descs.empty())
     launch_big_init(c->DP, c->DS, c->d_big.p, (int)c->big_descs.size(), c->big_max_n, c->big_max_nfv, c->d_H.p,
                     c->d_damp.p, c->d_scalars.p, c->d_arena.p, c->stream);
-  for (int l = 0; l < S.n_levels; ++l) {
-    // The leaf / small (LDS) launches of a level are independent of each other.  Few, GPU-filling ones (the landmark
-    // cliques of a bundle adjustment) go one after the other; many partly-filled ones (the size groups of a pose
-    // graph's lower levels, each bound by the latency of its slowest front) run side by side.
-    const size_t n_groups = c->leaf_launch[l].size() + c->rest_launch[l].size();
-    int max_count = 0;
-    for (const SmallLaunch& sl : c->leaf_launch[l]) max_count = std::max(max_count, sl.count);
-    for (const SmallLaunch& sl : c->rest_launch[l]) max_count = std::max(max_count, sl.count);
-    // (a fork + join costs ~85 us of cross-queue event latency, measured: only worth it for many groups)
-    // the long ones are the LDS-front launches (40-150 us each); leaf launches are 10-30 us and do not justify a fork)
-    const bool side = c->profiling <= 0 && n_groups >= 4 && c->rest_launch[l].size() >= 4 && max_count < 16384 && side_fork(c);
-    unsigned used = 0;
-    int gi = 0;
-    // The SIDE work (Symbolic::side_*): the lean leaves whose parents sit above the first blocked level, and their
-    // product-form gather, on the low-priority queue — beside the latency-bound blocked chain of the lower levels
-    // instead of in front of it.  (With per-launch timers everything stays on the one timed queue.)
-    const int sg = S.n_levels;   // the side gather group
-    const bool have_side = S.side_level0 >= 0 && l == 0;
-    const bool use_bulk = have_side && c->profiling <= 0 && bulk_ready(c);
-    const size_t n_main_leaf = (l == 0 && c->leaf_side_group0 != (size_t)-1) ? c->leaf_side_group0 : c->leaf_launch[l].size();
+  // ---- the leaf-kernel cliques (all childless: one group of launches) ----
+  // The SIDE work (Symbolic::side_*): the lean leaves whose parents sit above the first blocked level, and their
+  // product-form gather, on the low-priority queue — beside the latency-bound blocked chain of the lower levels
+  // instead of in front of it.  (With per-launch timers everything stays on the one timed queue.)
+  const int sg = S.n_ulevels;   // the side gather group
+  const bool have_side = S.side_level0 >= 0;
+  const bool use_bulk = have_side && c->profiling <= 0 && bulk_ready(c);
+  if (S.n_levels > 0) {
+    const std::vector<SmallLaunch>& LL = c->leaf_launch[0];
+    const size_t n_main_leaf = c->leaf_side_group0 != (size_t)-1 ? c->leaf_side_group0 : LL.size();
     if (use_bulk) {
       // (Forked right behind the zeroing / H terms of the blocked fronts.  Measured on BAL-1723, ms per LM iteration: no
       //  second queue 1.924; forked here 1.880; forked behind the main queue's own leaves and gather 1.904 — the side work then
@@ -1102,8 +1095,8 @@ void dev_factorize(gsx_context* c, double lambda) {
       //  earlier, what is lost is every kernel running beside them running slower.)
       hipEventRecord(c->bulk_go, c->stream);
       hipStreamWaitEvent(c->bulk, c->bulk_go, 0);
-      for (size_t g = n_main_leaf; g < c->leaf_launch[l].size(); ++g) {
-        const SmallLaunch& sl = c->leaf_launch[l][g];
+      for (size_t g = n_main_leaf; g < LL.size(); ++g) {
+        const SmallLaunch& sl = LL[g];
         launch_front_leaf(c->DP, c->DS, c->d_leaf_recs.p + (sl.begin - c->leaf_base), sl.count, sl.max_panel, sl.threads,
                           c->d_H.p, c->d_damp.p, c->d_scalars.p, c->d_arena.p, c->d_status.p, c->bulk);
       }
@@ -1112,74 +1105,69 @@ void dev_factorize(gsx_context* c, double lambda) {
       hipEventRecord(c->bulk_done, c->bulk);
       c->bulk_pending = true;
     }
-    for (size_t g = 0; g < (use_bulk ? n_main_leaf : c->leaf_launch[l].size()); ++g) {
-      const SmallLaunch& sl = c->leaf_launch[l][g];
+    for (size_t g = 0; g < (use_bulk ? n_main_leaf : LL.size()); ++g) {
+      const SmallLaunch& sl = LL[g];
       if (c->profiling > 0) timer_begin(c, PH_FACTOR_LEAF);
       launch_front_leaf(c->DP, c->DS, c->d_leaf_recs.p + (sl.begin - c->leaf_base), sl.count, sl.max_panel, sl.threads, c->d_H.p,
-                        c->d_damp.p, c->d_scalars.p, c->d_arena.p, c->d_status.p,
-                        side ? side_stream(c, gi++, &used) : c->stream);
+                        c->d_damp.p, c->d_scalars.p, c->d_arena.p, c->d_status.p, c->stream);
       if (c->profiling > 0) timer_end(c, PH_FACTOR_LEAF);
     }
+  }
+  // ---- the tree fronts of every level: one launch per tier (their leaf-kernel children were the launches above) ----
+  for (size_t t = 0; t < c->tree_tiers.size(); ++t) {
+    const gsx_context::TreeTier& tt = c->tree_tiers[t];
+    if (!tt.nstart) continue;
+    if (c->profiling > 0) timer_begin(c, PH_FACTOR_SMALL);
+    const TreeArgs ta{c->d_tree_start.p + tt.start0, tt.nstart, c->d_tree_cursor.p + t, c->d_tree_pending.p,
+                      c->d_tree_up.p, c->d_tree_npend.p};
+    if (tt.med_lds)
+      launch_front_tree_med(c->DP, c->DS, ta, tt.med_lds, c->d_H.p, c->d_damp.p, c->d_scalars.p, c->d_arena.p,
+                            c->d_status.p, c->stream);
+    else
+      launch_front_tree(c->DP, c->DS, ta, tt.max_n, tt.threads, c->d_H.p, c->d_damp.p, c->d_scalars.p, c->d_arena.p,
+                        c->d_status.p, c->stream);
+    debug_sync(c, tt.med_lds ? "front_tree_med" : "front_tree", tt.nstart, (int)tt.med_lds);
+    if (c->profiling > 0) timer_end(c, PH_FACTOR_SMALL);
+  }
+  // ---- the upper levels (Symbolic::ulevel): everything below them is complete ----
+  for (int l = 0; l < S.n_ulevels; ++l) {
     for (const SmallLaunch& sl : c->rest_launch[l]) {
       if (c->profiling > 0) timer_begin(c, PH_FACTOR_SMALL);
       launch_lds_group(c->DP, c->DS, c->d_rest_ids.p + sl.begin, sl, c->d_H.p, c->d_damp.p, c->d_scalars.p, c->d_arena.p,
-                       c->d_status.p, side ? side_stream(c, gi++, &used) : c->stream);
+                       c->d_status.p, c->stream);
       debug_sync(c, sl.medium ? "front_medium (level)" : "front_small (level)", sl.count, sl.medium ? sl.max_panel : sl.max_n);
       if (c->profiling > 0) timer_end(c, PH_FACTOR_SMALL);
     }
-    if (side) side_join(c, used);
-    if (l == 0) {
-      // the tree fronts of every level: one launch per tier (their leaf-kernel children were the launches above)
-      for (size_t t = 0; t < c->tree_tiers.size(); ++t) {
-        const gsx_context::TreeTier& tt = c->tree_tiers[t];
-        if (!tt.nstart) continue;
-        if (c->profiling > 0) timer_begin(c, PH_FACTOR_SMALL);
-        const TreeArgs ta{c->d_tree_start.p + tt.start0, tt.nstart, c->d_tree_cursor.p + t, c->d_tree_pending.p,
-                          c->d_tree_up.p, c->d_tree_npend.p};
-        if (tt.med_lds)
-          launch_front_tree_med(c->DP, c->DS, ta, tt.med_lds, c->d_H.p, c->d_damp.p, c->d_scalars.p, c->d_arena.p,
-                                c->d_status.p, c->stream);
-        else
-          launch_front_tree(c->DP, c->DS, ta, tt.max_n, tt.threads, c->d_H.p, c->d_damp.p, c->d_scalars.p, c->d_arena.p,
-                            c->d_status.p, c->stream);
-        debug_sync(c, tt.med_lds ? "front_tree_med" : "front_tree", tt.nstart, (int)tt.med_lds);
-        if (c->profiling > 0) timer_end(c, PH_FACTOR_SMALL);
-      }
-    }
-    if (l == 0 && S.gseg_lvl_ptr[1] > S.gseg_lvl_ptr[0]) {
-      // gather group 0: the product-form contributions of all lean leaves to all big fronts (symbolic.cpp)
-      if (c->profiling > 0) timer_begin(c, PH_K_GATHER);
-      launch_big_gather(c->GA, S.gseg_lvl_ptr[0], S.gseg_lvl_ptr[1] - S.gseg_lvl_ptr[0], S.gm_lvl_ptr[0],
-                        S.gm_lvl_ptr[1] - S.gm_lvl_ptr[0], c->d_arena.p, c->stream);
-      if (c->profiling > 0) timer_end(c, PH_K_GATHER);
-    }
-    if (have_side && !use_bulk && S.gseg_lvl_ptr[sg + 1] > S.gseg_lvl_ptr[sg]) {   // (no second queue: in line)
-      if (c->profiling > 0) timer_begin(c, PH_K_GATHER);
-      launch_big_gather(c->GA, S.gseg_lvl_ptr[sg], S.gseg_lvl_ptr[sg + 1] - S.gseg_lvl_ptr[sg], S.gm_lvl_ptr[sg],
-                        S.gm_lvl_ptr[sg + 1] - S.gm_lvl_ptr[sg], c->d_arena.p, c->stream);
-      if (c->profiling > 0) timer_end(c, PH_K_GATHER);
-    }
-    // the fronts above the first blocked level take the side leaves' contributions: those must have landed
-    if (S.side_level0 >= 0 && l == S.side_level0 + 1 && c->bulk_pending) {
+    // the fronts above the first blocked level take the side leaves' contributions: those must have landed (and they
+    // come first in every destination block's sum, as in the one-queue order)
+    if (have_side && l == S.side_level0 + 1 && c->bulk_pending) {
       hipStreamWaitEvent(c->stream, c->bulk_done, 0);
       c->bulk_pending = false;
     }
     const BigLevel& B = c->big_level[l];
+    const bool prof = c->profiling > 0;
+    if (prof && B.count) timer_begin(c, PH_FACTOR_BIG);
+    // deterministic extend-add into this level's blocked fronts: the children are complete.  (Group 0 also holds the
+    // product-form contributions of the lean leaves — of all levels, or of the levels up to the first blocked one when
+    // the others are side work.)
+    if (S.gseg_lvl_ptr[l + 1] > S.gseg_lvl_ptr[l]) {
+      if (prof) timer_begin(c, PH_K_GATHER);
+      launch_big_gather(c->GA, S.gseg_lvl_ptr[l], S.gseg_lvl_ptr[l + 1] - S.gseg_lvl_ptr[l], S.gm_lvl_ptr[l],
+                        S.gm_lvl_ptr[l + 1] - S.gm_lvl_ptr[l], c->d_arena.p, c->stream);
+      if (prof) timer_end(c, PH_K_GATHER);
+    }
+    if (l == 0 && have_side && !use_bulk && S.gseg_lvl_ptr[sg + 1] > S.gseg_lvl_ptr[sg]) {   // (no second queue: in line)
+      if (prof) timer_begin(c, PH_K_GATHER);
+      launch_big_gather(c->GA, S.gseg_lvl_ptr[sg], S.gseg_lvl_ptr[sg + 1] - S.gseg_lvl_ptr[sg], S.gm_lvl_ptr[sg],
+                        S.gm_lvl_ptr[sg + 1] - S.gm_lvl_ptr[sg], c->d_arena.p, c->stream);
+      if (prof) timer_end(c, PH_K_GATHER);
+    }
     if (B.count) {
-      if (c->profiling > 0) timer_begin(c, PH_FACTOR_BIG);
-      // children of every earlier level are complete: deterministic extend-add into this level's big fronts
-      const bool prof = c->profiling > 0;
-      if (l > 0) {  // (group 0 was launched above)
-        if (prof) timer_begin(c, PH_K_GATHER);
-        launch_big_gather(c->GA, S.gseg_lvl_ptr[l], S.gseg_lvl_ptr[l + 1] - S.gseg_lvl_ptr[l], S.gm_lvl_ptr[l],
-                          S.gm_lvl_ptr[l + 1] - S.gm_lvl_ptr[l], c->d_arena.p, c->stream);
-        if (prof) timer_end(c, PH_K_GATHER);
-      }
       // sharded: every rank's share of the cap (H terms, damping, its subtrees' Schur complements) is in; their sum
       // is the assembled cap, which all ranks now factor alike
-      if (l == S.cap_level0) shard_allreduce(c, c->d_arena.p + S.cap_begin, S.cap_end - S.cap_begin);
+      if (l == S.cap_ulevel0) shard_allreduce(c, c->d_arena.p + S.cap_begin, S.cap_end - S.cap_begin);
       dev_big_factor(c, c->d_big.p + B.begin, B.count, B.plan, c->stream, prof);
-      if (c->profiling > 0) timer_end(c, PH_FACTOR_BIG);
+      if (prof) timer_end(c, PH_FACTOR_BIG);
     }
   }
   // choleskyPartial's conditioning test, per clique of the reference tree (cholesky.cpp:145-158)
@@ -1190,16 +1178,17 @@ void dev_factorize(gsx_context* c, double lambda) {
 
 // wf: ISAM2's partial back-substitution — the kernels skip the cliques no change reaches (DS.wf_*), and a bookkeeping pass
 // follows every level (nullptr: all cliques)
-void dev_backsolve(gsx_context* c, const WildfireArgs* wf = nullptr) {
+// the level-by-level back-substitution over ALL fronts (the wildfire pass: its bookkeeping runs level by level)
+void dev_backsolve_levels(gsx_context* c, const WildfireArgs* wf) {
   const Symbolic& S = c->S;
   timer_begin(c, PH_BACKSOLVE);
   c->wf_delta_valid = false;  // (set again by the callers that leave a complete undamped solution behind)
-  // (the wildfire pass keeps the level launches: its bookkeeping runs level by level)
-  static const bool bs_tree_off = std::getenv("GSX_BS_TREE_OFF") != nullptr;
-  const bool tree = wf == nullptr && c->bst_total > 0 && !bs_tree_off;
+  const bool tree = false;
   for (int l = S.n_levels - 1; l >= 0; --l) {
-    const BigLevel& B = c->big_level[l];
     const int se = S.lvl_small_end[l];
+    struct {
+      int count;
+    } B{S.lvl_ptr[l + 1] - se};
     const int le = S.lvl_leaf_end[l], n_rest = S.lvl_ptr[l + 1] - le;
     // the blocked fronts of the level: their own kernel when L11's tiles fit in LDS (bigfront.hip)
     int big_maxn = 0, big_maxF = 0, big_maxS = 0;
@@ -1290,6 +1279,73 @@ void dev_backsolve(gsx_context* c, const WildfireArgs* wf = nullptr) {
       launch_wildfire_post(c->DS, c->d_sched.p + le, n_rest, true, *wf, c->d_delta.p, c->stream);
     }
   }
+  timer_end(c, PH_BACKSOLVE);
+}
+
+
+// OptimizeClique top-down (gtsam/linear/linearAlgorithms-inst.h:49-117): the upper fronts level by level (Symbolic::ulevel),
+// then the tree fronts of all levels in one launch, then the leaf-kernel cliques.
+void dev_backsolve(gsx_context* c, const WildfireArgs* wf = nullptr) {
+  static const bool levels_only = std::getenv("GSX_BS_TREE_OFF") != nullptr;
+  if (wf != nullptr || levels_only) {
+    dev_backsolve_levels(c, wf);
+    return;
+  }
+  const Symbolic& S = c->S;
+  timer_begin(c, PH_BACKSOLVE);
+  c->wf_delta_valid = false;  // (set again by the callers that leave a complete undamped solution behind)
+  for (int l = S.n_ulevels - 1; l >= 0; --l) {
+    const int b0 = S.ulvl_ptr[l], se = S.ulvl_small_end[l], e = S.ulvl_ptr[l + 1];
+    // the blocked fronts of the level: their own kernel when L11's tiles fit in LDS (bigfront.hip)
+    if (e > se) {
+      int big_maxn = 0, big_maxF = 0, big_maxS = 0;
+      for (int k = se; k < e; ++k) {
+        big_maxn = std::max(big_maxn, S.N[S.usched[k]]);
+        big_maxF = std::max(big_maxF, S.F[S.usched[k]]);
+        big_maxS = std::max(big_maxS, S.N[S.usched[k]] - S.F[S.usched[k]]);
+      }
+      if (c->profiling > 0) timer_begin(c, PH_K_BACKSOLVE);
+      if (backsolve_big_lds(big_maxn, big_maxF, big_maxS) > 0)
+        launch_backsolve_big(c->DS, c->d_usched.p + se, e - se, big_maxn, big_maxF, c->d_arena.p, c->d_delta.p, c->d_status.p,
+                             c->stream);
+      else
+        launch_backsolve(c->DS, c->d_usched.p + se, e - se, 1024, big_maxn, c->d_arena.p, c->d_delta.p, c->d_status.p,
+                         c->stream);
+      if (c->profiling > 0) timer_end(c, PH_K_BACKSOLVE);
+    }
+    // the LDS-class fronts of the level that are not tree fronts (consecutive in d_usched)
+    if (se > b0) {
+      int maxn = 0, maxF = 0;
+      for (int k = b0; k < se; ++k) {
+        maxn = std::max(maxn, S.N[S.usched[k]]);
+        maxF = std::max(maxF, S.F[S.usched[k]]);
+      }
+      if (c->profiling > 0) timer_begin(c, PH_K_BACKSOLVE);
+      if (backsolve_small_fits(maxn, maxF))
+        launch_backsolve_small(c->DS, c->d_usched.p + b0, se - b0, maxF, c->d_arena.p, c->d_delta.p, c->d_status.p, c->stream);
+      else
+        launch_backsolve(c->DS, c->d_usched.p + b0, se - b0, maxn <= 48 ? 64 : 256, maxn, c->d_arena.p, c->d_delta.p,
+                         c->d_status.p, c->stream);
+      if (c->profiling > 0) timer_end(c, PH_K_BACKSOLVE);
+    }
+  }
+  if (c->bst_total > 0) {
+    // every upper front is solved: the tree fronts of all levels, one launch
+    hipMemsetAsync(c->d_bst_counters.p, 0, 2 * sizeof(int), c->stream);
+    if (++c->bst_epoch == 0) c->bst_epoch = 1;
+    if (c->profiling > 0) timer_begin(c, PH_K_BACKSOLVE);
+    launch_backsolve_tree(c->DS,
+                          BacksolveTreeArgs{c->d_bst_roots.p, c->bst_roots, c->bst_total, c->d_bst_child_ptr.p,
+                                            c->d_bst_children.p, c->d_bst_ready.p, c->d_bst_counters.p,
+                                            c->d_bst_counters.p + 1, c->bst_epoch},
+                          c->d_arena.p, c->d_delta.p, c->d_status.p, c->stream);
+    if (c->profiling > 0) timer_end(c, PH_K_BACKSOLVE);
+    debug_sync(c, "backsolve_tree", c->bst_roots, c->bst_total);
+  }
+  // all leaf-kernel cliques (childless: level 0) in one launch, a wave each
+  if (S.n_levels > 0 && S.lvl_leaf_end[0] > S.lvl_ptr[0])
+    launch_backsolve_leaf(c->DS, c->d_leaf_recs.p + (S.lvl_ptr[0] - c->leaf_base), S.lvl_leaf_end[0] - S.lvl_ptr[0],
+                          c->leaf_max_F[0], c->d_arena.p, c->d_delta.p, c->d_status.p, c->stream);
   timer_end(c, PH_BACKSOLVE);
 }
 
@@ -2301,8 +2357,20 @@ gsx_status partial_factor(gsx_handle h, std::vector<int>& dfr) {
       std::vector<SmallLaunch> small;         // ranges of `ids`, with the launch shape of the full schedule's group
       int big_begin = 0, big_count = 0;
       BigPlan big_plan;
-      std::vector<int> seg_idx, gm_idx;
-      int seg0 = 0, nseg = 0, m0 = 0, nm = 0;
+      // the gather segments of the level's dirty blocked fronts by gather group (launched one group after the other, in
+      // the full schedule's order: the side / lean group before the stored children's — same sums, same bits)
+      struct GroupPlan {
+        int group;
+        std::vector<int> seg_idx, gm_idx;
+        int seg0 = 0, nseg = 0, m0 = 0, nm = 0;
+      };
+      std::vector<GroupPlan> groups;
+      GroupPlan& group(int g) {
+        for (GroupPlan& gp : groups)
+          if (gp.group == g) return gp;
+        groups.push_back(GroupPlan{g, {}, {}});
+        return groups.back();
+      }
     };
     std::vector<LevelPlan> plan(S.n_levels);
     int big_max_n = 0, big_max_nfv = 0;
@@ -2335,9 +2403,9 @@ gsx_status partial_factor(gsx_handle h, std::vector<int>& dfr) {
           big_max_nfv = std::max(big_max_nfv, S.nfrontal_vars[f]);
           // its gather segments (sources: ALL its children, clean or not), at the level the full schedule runs them
           for (int k = h->fr_seg_ptr[f]; k < h->fr_seg_ptr[f + 1]; ++k)
-            plan[h->seg_level[h->fr_segs[k]]].seg_idx.push_back(h->fr_segs[k]);
+            L.group(h->seg_level[h->fr_segs[k]]).seg_idx.push_back(h->fr_segs[k]);
           for (int k = h->fr_gm_ptr[f]; k < h->fr_gm_ptr[f + 1]; ++k)
-            plan[h->gm_level[h->fr_gms[k]]].gm_idx.push_back(h->fr_gms[k]);
+            L.group(h->gm_level[h->fr_gms[k]]).gm_idx.push_back(h->fr_gms[k]);
         }
         last_level = l;
         last_cls = cls;
@@ -2347,17 +2415,25 @@ gsx_status partial_factor(gsx_handle h, std::vector<int>& dfr) {
     for (int l = 0; l < S.n_levels; ++l) {
       LevelPlan& L = plan[l];
       plan_big_group(big.data() + L.big_begin, L.big_count, L.big_plan);
-      // (no particular order is needed: every segment adds into its own destination block or its own scratch slot)
-      L.seg0 = (int)segs.size();
-      for (int i : L.seg_idx) segs.push_back(h->h_gsegs[i]);
-      L.nseg = (int)L.seg_idx.size();
-      L.m0 = (int)gm_task.size();
-      for (int i : L.gm_idx) {
-        gm_task.push_back(S.gm_task[i]);
-        gm_slot.push_back(S.gm_slot[i]);
-        gm_nslots.push_back(S.gm_nslots[i]);
+      // group order: the side group (index n_ulevels) and group 0 hold the lean leaves' sums — first, as in the full
+      // schedule; inside a group no particular order is needed (every segment adds into its own destination block or its
+      // own scratch slot)
+      std::stable_sort(L.groups.begin(), L.groups.end(), [&](const LevelPlan::GroupPlan& a, const LevelPlan::GroupPlan& b) {
+        const int ka = a.group == S.n_ulevels ? -1 : a.group, kb = b.group == S.n_ulevels ? -1 : b.group;
+        return ka < kb;
+      });
+      for (LevelPlan::GroupPlan& G : L.groups) {
+        G.seg0 = (int)segs.size();
+        for (int i : G.seg_idx) segs.push_back(h->h_gsegs[i]);
+        G.nseg = (int)G.seg_idx.size();
+        G.m0 = (int)gm_task.size();
+        for (int i : G.gm_idx) {
+          gm_task.push_back(S.gm_task[i]);
+          gm_slot.push_back(S.gm_slot[i]);
+          gm_nslots.push_back(S.gm_nslots[i]);
+        }
+        G.nm = (int)G.gm_idx.size();
       }
-      L.nm = (int)L.gm_idx.size();
     }
     HIPCHK(h, ps.leaf.stage(leaf, sm));
     HIPCHK(h, ps.ids.stage(ids, sm));
@@ -2386,9 +2462,9 @@ gsx_status partial_factor(gsx_handle h, std::vector<int>& dfr) {
       for (const SmallLaunch& g : L.small)
         launch_lds_group(h->DP, h->DS, ps.ids.p + g.begin, g, h->d_H.p, h->d_damp.p, h->d_scalars.p, h->d_arena.p,
                          h->d_status.p, sm);
-      if (l == 0 && L.nseg) launch_big_gather(GA, L.seg0, L.nseg, L.m0, L.nm, h->d_arena.p, sm);  // gather group 0
       if (L.big_count) {
-        if (l > 0 && L.nseg) launch_big_gather(GA, L.seg0, L.nseg, L.m0, L.nm, h->d_arena.p, sm);
+        for (const LevelPlan::GroupPlan& G : L.groups)
+          if (G.nseg) launch_big_gather(GA, G.seg0, G.nseg, G.m0, G.nm, h->d_arena.p, sm);
         dev_big_factor(h, ps.big.p + L.big_begin, L.big_count, L.big_plan, sm, false);
       }
     }
@@ -3072,6 +3148,7 @@ gsx_status gsx_get_stats(gsx_handle h, gsx_stats* out) {
     out->max_front_rows = S.max_rows;
     out->n_small_fronts = S.n_small;
     out->n_big_fronts = S.n_big;
+    out->n_upper_levels = S.n_ulevels;
     out->n_medium_fronts = 0;
     for (int f = 0; f < S.n_fronts; ++f) {
       out->n_medium_fronts += S.med[f] && S.cls[f] == 1;

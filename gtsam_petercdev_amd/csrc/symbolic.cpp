@@ -270,7 +270,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
           }
           if (ep >= 0) {
             a_nch[ep] += 1;
-            lvl[ep] = std::max(lvl[ep], l + 1);
+            if (!tree && !leafk) lvl[ep] = std::max(lvl[ep], l + 1);   // (the upper levels: gsx_internal.h)
           }
         }
         double cost = 40.0;  // (the leaf launches)
@@ -579,23 +579,46 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
       }
     }
   }
+  // ---- the upper levels (gsx_internal.h) ----
+  S.ulevel.assign(nfr, -1);
+  S.n_ulevels = 0;
+  S.cap_ulevel0 = -1;
+  {
+    auto upper = [&](int f) { return S.scheduled[f] && S.cls[f] != 0 && S.tree_tier[f] < 0; };
+    for (int f = 0; f < nfr; ++f)
+      if (upper(f)) S.ulevel[f] = 0;
+    for (int f = 0; f < nfr; ++f) {   // children have smaller ids
+      const int p = S.parent[f];
+      if (S.ulevel[f] >= 0 && p >= 0 && S.ulevel[p] >= 0) S.ulevel[p] = std::max(S.ulevel[p], S.ulevel[f] + 1);
+    }
+    if (S.n_cap) {   // every cap level above every subtree level: ONE exchange per factorization (see the sharding above)
+      int ubase = 0;
+      for (int f = 0; f < nfr; ++f)
+        if (!cap[f] && S.ulevel[f] >= 0) ubase = std::max(ubase, S.ulevel[f] + 1);
+      for (int f = 0; f < nfr; ++f)
+        if (cap[f]) S.ulevel[f] = ubase;
+      for (int f = 0; f < nfr; ++f)
+        if (cap[f] && S.parent[f] >= 0) S.ulevel[S.parent[f]] = std::max(S.ulevel[S.parent[f]], S.ulevel[f] + 1);
+      S.cap_ulevel0 = ubase;
+    }
+    for (int f = 0; f < nfr; ++f) S.n_ulevels = std::max(S.n_ulevels, S.ulevel[f] + 1);
+  }
   {
     // A level's LDS fronts cost one launch bound by the latency of its slowest front (60-100 us for a 100-140 row front:
     // a barrier per pivot) however few they are.  Where the level has blocked (big) fronts anyway and only a handful of
     // LDS fronts, those join the blocked path: no launch of their own, and the level's panel-step chain is set by the
     // big fronts' wider frontal blocks in any case (measured on the 100 000-pose graphs, limit swept 256 / 1024 / 4096:
     // 1024 is best — 7.79 -> 7.13 ms and 4.56 -> 3.69 ms per iteration).
-    int nlev = 0;
-    for (int f = 0; f < nfr; ++f) nlev = std::max(nlev, S.level[f] + 1);
-    std::vector<int> n_lds(nlev, 0), n_blk(nlev, 0);
+    // (levels = the upper levels: tree fronts and leaf-kernel cliques cost no launch of a level)
+    std::vector<int> n_lds(S.n_ulevels + 1, 0), n_blk(S.n_ulevels + 1, 0);
     for (int f = 0; f < nfr; ++f) {
-      if (!S.scheduled[f]) continue;   // (another rank's subtree: not in this rank's launches)
-      if (S.cls[f] == 1 && S.tree_tier[f] < 0) n_lds[S.level[f]]++;  // (tree fronts cost no launch of their level)
-      else if (S.cls[f] == 2) n_blk[S.level[f]]++;
+      if (S.ulevel[f] < 0) continue;
+      if (S.cls[f] == 1) n_lds[S.ulevel[f]]++;
+      else if (S.cls[f] == 2) n_blk[S.ulevel[f]]++;
     }
     for (int f = 0; f < nfr; ++f) {
-      const int l = S.level[f];
-      if (!S.scheduled[f] || S.cls[f] != 1 || S.tree_tier[f] >= 0 || n_blk[l] == 0 || n_lds[l] > 1024) continue;
+      const int l = S.ulevel[f];
+      if (l < 0 || S.cls[f] != 1 || n_blk[l] == 0 || n_lds[l] > 1024) continue;
       S.cls[f] = 2;
       if (S.med[f]) {
         S.med[f] = 0;
@@ -809,13 +832,13 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     static const bool side_off = std::getenv("GSX_SIDE_OFF") != nullptr;
     int l0 = -1;
     for (int f = 0; f < nfr; ++f)
-      if (S.cls[f] == 2 && S.scheduled[f] && (l0 < 0 || S.level[f] < l0)) l0 = S.level[f];
+      if (S.cls[f] == 2 && S.scheduled[f] && (l0 < 0 || S.ulevel[f] < l0)) l0 = S.ulevel[f];
     int64_t n_side = 0, n_lean = 0;
     if (l0 >= 0 && !side_off && S.shard_world == 1)
       for (int f = 0; f < nfr; ++f)
         if (S.lean[f] && S.scheduled[f]) {
           ++n_lean;
-          if (S.level[S.parent[f]] > l0) {
+          if (S.ulevel[S.parent[f]] > l0) {
             S.side[f] = 1;
             ++n_side;
           }
@@ -862,6 +885,25 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
       S.tree_start_ptr[t + 1] = (int)S.tree_start.size();
     }
   }
+  {
+    S.usched.clear();
+    for (int f = 0; f < nfr; ++f)
+      if (S.ulevel[f] >= 0) S.usched.push_back(f);
+    std::stable_sort(S.usched.begin(), S.usched.end(), [&](int a, int b) {
+      if (S.ulevel[a] != S.ulevel[b]) return S.ulevel[a] < S.ulevel[b];
+      if (S.cls[a] != S.cls[b]) return S.cls[a] < S.cls[b];
+      return S.N[a] < S.N[b];
+    });
+    S.ulvl_ptr.assign(S.n_ulevels + 1, 0);
+    S.ulvl_small_end.assign(S.n_ulevels, 0);
+    for (int f : S.usched) S.ulvl_ptr[S.ulevel[f] + 1]++;
+    for (int l = 0; l < S.n_ulevels; ++l) S.ulvl_ptr[l + 1] += S.ulvl_ptr[l];
+    for (int l = 0; l < S.n_ulevels; ++l) {
+      int e = S.ulvl_ptr[l];
+      while (e < S.ulvl_ptr[l + 1] && S.cls[S.usched[e]] == 1) ++e;
+      S.ulvl_small_end[l] = e;
+    }
+  }
   clk.mark("schedule");
   // ---- gather tasks for big parents ------------------------------------------------------------------------
   {
@@ -881,7 +923,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
       std::vector<int> ld, dims, front;
       std::vector<Src> src;
     };
-    std::vector<LevelOut> lout(S.n_levels + 1);   // (+ the side group)
+    std::vector<LevelOut> lout(S.n_ulevels + 1);   // (the upper levels + the side group)
     std::vector<int> parents;
     for (int p = 0; p < nfr; ++p)
       if (S.cls[p] == 2 && S.scheduled[p]) parents.push_back(p);
@@ -904,10 +946,10 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
       poffv[nvp] = S.N[p] - 1;
       // the (at most three) levels its contributions run at: 0 for lean children, the first cap level for a subtree's
       // contribution to a cap front, its own level otherwise
-      int lv[3] = {0, S.level[p], S.level[p]};
-      if (S.owner[p] < 0) lv[1] = S.cap_level0;
+      int lv[3] = {0, S.ulevel[p], S.ulevel[p]};
+      if (S.owner[p] < 0) lv[1] = S.cap_ulevel0;
       // (a parent's lean children are all side leaves or none: sidedness is the parent's level)
-      if (S.side_level0 >= 0 && S.level[p] > S.side_level0) lv[0] = S.n_levels;
+      if (S.side_level0 >= 0 && S.ulevel[p] > S.side_level0) lv[0] = S.n_ulevels;
       loc.clear();
       for (int ci = S.child_ptr[p]; ci < S.child_ptr[p + 1]; ++ci) {
         const int ch = S.children[ci];
@@ -932,7 +974,10 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
         // product-form sources (lean children) depend on the leaf kernel only: all of them, for every parent level, go
         // into gather group 0, launched once right after the leaves (throughput-bound), which leaves the per-level
         // gathers on the latency-bound chain with the few stored complements of big children
-        const int rank = S.lean[ch] ? 0 : ((S.owner[p] < 0 && S.owner[ch] >= 0) ? 1 : 2);
+        int rank = S.lean[ch] ? 0 : ((S.owner[p] < 0 && S.owner[ch] >= 0) ? 1 : 2);
+        // (two tasks for one destination block must never share a launch: sources whose group is the lean children's
+        //  group join their task — one sum per block, in child order)
+        if (rank != 0 && lv[rank] == lv[0]) rank = 0;
         for (int a = 0; a < nb; ++a)
           for (int b = a; b < nb; ++b) {  // block (row b, col a), b >= a
             Local c;
@@ -973,7 +1018,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
       }
     }
     clk.mark("  gather: contributions");
-    const int ngl = S.n_levels + 1;   // gather groups: the levels + the side group
+    const int ngl = S.n_ulevels + 1;   // gather groups: the upper levels + the side group
     S.gt_lvl_ptr.assign(ngl + 1, 0);
     size_t n_src = 0;
     for (const LevelOut& L : lout) n_src += L.src.size();
@@ -1015,8 +1060,8 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
     int t = 0;
     for (int l = 0; l < ngl; ++l) {
       // (the side group runs beside the level gathers: scratch slots of its own, behind theirs)
-      if (l == S.n_levels) S.side_slot0 = S.g_max_slots;
-      int slots = l == S.n_levels ? S.side_slot0 : 0;
+      if (l == S.n_ulevels) S.side_slot0 = S.g_max_slots;
+      int slots = l == S.n_ulevels ? S.side_slot0 : 0;
       // (shorter chunks for the levels with few sources were measured: slower — more waves, more scratch)
       const int chunk = kGatherChunk;
       for (; t < S.gt_lvl_ptr[l + 1]; ++t) {

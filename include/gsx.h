@@ -227,6 +227,7 @@ typedef struct gsx_stats {
   int64_t amalgamation_max_frontal_dim;
   int64_t n_medium_fronts;       /* of the LDS fronts: frontal panel in LDS, trailing block in HBM */
   int64_t n_tree_fronts;         /* fronts eliminated dependency-driven, one launch per tier, instead of level by level */
+  int64_t n_upper_levels;        /* launch rounds of the fronts that are neither: levelled among themselves (longest chain) */
 } gsx_stats;
 
 /* ---- on-disk formats (host only) -------------------------
