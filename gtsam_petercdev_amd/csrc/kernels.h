@@ -9,6 +9,15 @@ namespace gsx {
 
 typedef long long i64;
 
+// Everything a per-factor kernel needs before it touches the state, in ONE 32-byte record (graph order): the chain
+// factor id -> key pointer -> variable ids -> state offsets -> state was five dependent loads deep.
+struct FactorRec {
+  i64 jac_off;
+  int s0, s1;                 // state offsets of the first two variables (-1: none)
+  int meas_off, noise_off;    // doubles into meas / noise
+  int type_kind;              // f_type | noise kind (with the robust bits) << 8 | type of the first variable << 24
+  int rows_dim;               // rows | dimension of the first variable << 16
+};
 // Immutable problem tables on the device (graph order).
 struct DevProblem {
   int n_vars, n_factors;
@@ -16,6 +25,7 @@ struct DevProblem {
   const int *f_type, *f_rows, *f_key_ptr, *f_vars, *f_noise_kind, *f_cols;
   const i64 *f_meas_off, *f_noise_off, *f_jac_off;
   const double *meas, *noise;
+  const FactorRec* frec;  // per factor
   const int* f_active;  // factors this rank evaluates in the error kernels (nullptr: all n_active = n_factors)
   int n_active;
 };

@@ -236,10 +236,10 @@ __global__ void __launch_bounds__(256) linearize_sfm_kernel(DevProblem P, const 
   const int i = ((int)blockIdx.x - gb) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int f = list[i];
-  const int kp = P.f_key_ptr[f];
-  const double* cam = values + P.var_state_off[P.f_vars[kp]];
-  const double* pt = values + P.var_state_off[P.f_vars[kp + 1]];
-  const double* z = P.meas + P.f_meas_off[f];
+  const FactorRec fr = P.frec[f];
+  const double* cam = values + fr.s0;
+  const double* pt = values + fr.s1;
+  const double* z = P.meas + fr.meas_off;
   double camr[17], ptr3[3], pi[2], H1[18], H2[6], J[26];
 #pragma unroll
   for (int k = 0; k < 17; ++k) camr[k] = cam[k];
@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(256) linearize_sfm_kernel(DevProblem P, const 
     for (int k = 0; k < 26; ++k) J[k] = 0;
     atomicAdd(&status->n_cheirality, 1);
   }
-  whiten_store<2, 13>(J, P.f_noise_kind[f], P.noise + P.f_noise_off[f], jac + P.f_jac_off[f]);
+  whiten_store<2, 13>(J, (fr.type_kind >> 8) & 0xffff, P.noise + fr.noise_off, jac + fr.jac_off);
 }
 
 // BearingRangeFactor<Pose2,Point2> — gtsam/sam/BearingRangeFactor.h (ExpressionFactor: e = -Local(h(x), z))
@@ -342,11 +342,11 @@ __global__ void __launch_bounds__(256) linearize_between_pose2_kernel(DevProblem
   const int i = ((int)blockIdx.x - gb) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int f = list[i];
-  const int kp = P.f_key_ptr[f];
-  const P2 x1 = load_pose2(values + P.var_state_off[P.f_vars[kp]]);
-  const P2 x2 = load_pose2(values + P.var_state_off[P.f_vars[kp + 1]]);
+  const FactorRec fr = P.frec[f];
+  const P2 x1 = load_pose2(values + fr.s0);
+  const P2 x2 = load_pose2(values + fr.s1);
   const P2 h = compose(inverse(x1), x2);
-  const P2 zh = compose(inverse(load_pose2(P.meas + P.f_meas_off[f])), h);
+  const P2 zh = compose(inverse(load_pose2(P.meas + fr.meas_off)), h);
   const P2 hi = inverse(h);
   // Ad(h^-1) = [[c,-s,y],[s,c,-x],[0,0,1]]; A1 = -Ad, A2 = I, b = -e
   double J[21];
@@ -357,7 +357,7 @@ __global__ void __launch_bounds__(256) linearize_between_pose2_kernel(DevProblem
   J[12] = 0; J[13] = 1; J[14] = 0;
   J[15] = 0; J[16] = 0; J[17] = 1;
   J[18] = -zh.x; J[19] = -zh.y; J[20] = -theta(zh);
-  whiten_store<3, 7>(J, P.f_noise_kind[f], P.noise + P.f_noise_off[f], jac + P.f_jac_off[f]);
+  whiten_store<3, 7>(J, (fr.type_kind >> 8) & 0xffff, P.noise + fr.noise_off, jac + fr.jac_off);
 }
 
 __global__ void __launch_bounds__(256) linearize_between_pose3_kernel(DevProblem P, const int* list, int n,
@@ -371,11 +371,11 @@ __global__ void __launch_bounds__(256) linearize_between_pose3_kernel(DevProblem
   const int i = ((int)blockIdx.x - gb) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int f = list[i];
-  const int kp = P.f_key_ptr[f];
-  const P3 x1 = load_pose3(values + P.var_state_off[P.f_vars[kp]]);
-  const P3 x2 = load_pose3(values + P.var_state_off[P.f_vars[kp + 1]]);
+  const FactorRec fr = P.frec[f];
+  const P3 x1 = load_pose3(values + fr.s0);
+  const P3 x2 = load_pose3(values + fr.s1);
   const P3 h = between(x1, x2);
-  const P3 zh = compose(inverse(load_pose3(P.meas + P.f_meas_off[f])), h);
+  const P3 zh = compose(inverse(load_pose3(P.meas + fr.meas_off)), h);
   double e[6], Ad[36], J[78];
   pose3_logmap(zh, e);
   pose3_adjoint(inverse(h), Ad);
@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(256) linearize_between_pose3_kernel(DevProblem
     }
 #pragma unroll
   for (int r = 0; r < 6; ++r) J[72 + r] = -e[r];
-  whiten_store<6, 13>(J, P.f_noise_kind[f], P.noise + P.f_noise_off[f], jac + P.f_jac_off[f]);
+  whiten_store<6, 13>(J, (fr.type_kind >> 8) & 0xffff, P.noise + fr.noise_off, jac + fr.jac_off);
 }
 
 // priors of every type and BetweenFactor on vector spaces: rare, runtime dims, built in place
@@ -460,15 +460,15 @@ void launch_linearize(const DevProblem& P, const int* const type_lists[6], const
 // graph error (NoiseModelFactor::error, gtsam/nonlinear/NonlinearFactor.cpp:138-149)
 // ---------------------------------------------------------------------------------------------
 __device__ inline double factor_error(const DevProblem& P, int f, const double* values) {
-  const int type = P.f_type[f];
+  const FactorRec fr = P.frec[f];
+  const int type = fr.type_kind & 0xff;
   if (type == GSX_F_LINEAR) return 0.0;
-  const int kp = P.f_key_ptr[f];
-  const int kind = P.f_noise_kind[f];
-  const double* np = P.noise + P.f_noise_off[f];
-  const double* z = P.meas + P.f_meas_off[f];
+  const int kind = (fr.type_kind >> 8) & 0xffff;
+  const double* np = P.noise + fr.noise_off;
+  const double* z = P.meas + fr.meas_off;
   if (type == GSX_F_SFM) {
-    const double* cam = values + P.var_state_off[P.f_vars[kp]];
-    const double* pt = values + P.var_state_off[P.f_vars[kp + 1]];
+    const double* cam = values + fr.s0;
+    const double* pt = values + fr.s1;
     double camr[17], ptr3[3], pi[2], e[2];
 #pragma unroll
     for (int k = 0; k < 17; ++k) camr[k] = cam[k];
@@ -479,8 +479,8 @@ __device__ inline double factor_error(const DevProblem& P, int f, const double* 
     return whitened_half_sqnorm<2>(e, kind, np);
   }
   if (type == GSX_F_BEARINGRANGE) {
-    const double* pose = values + P.var_state_off[P.f_vars[kp]];
-    const double* pt = values + P.var_state_off[P.f_vars[kp + 1]];
+    const double* pose = values + fr.s0;
+    const double* pt = values + fr.s1;
     double ps[3] = {pose[0], pose[1], pose[2]}, p2[2] = {pt[0], pt[1]}, br[2], e[2];
     bearing_range_2d(ps, p2, br, nullptr, nullptr);
     e[0] = wrap_angle(br[0] - z[0]);
@@ -488,8 +488,8 @@ __device__ inline double factor_error(const DevProblem& P, int f, const double* 
     return whitened_half_sqnorm<2>(e, kind, np);
   }
   if (type == GSX_F_PROJECTION) {
-    const double* pose = values + P.var_state_off[P.f_vars[kp]];
-    const double* pt = values + P.var_state_off[P.f_vars[kp + 1]];
+    const double* pose = values + fr.s0;
+    const double* pt = values + fr.s1;
     double pr[12], p3[3], K[5], pi[2], e[2];
 #pragma unroll
     for (int k = 0; k < 12; ++k) pr[k] = pose[k];
@@ -504,29 +504,27 @@ __device__ inline double factor_error(const DevProblem& P, int f, const double* 
     }
     return whitened_half_sqnorm<2>(e, kind, np);
   }
-  const int v0 = P.f_vars[kp];
-  const int vt = P.var_type[v0];
+  const int vt = (fr.type_kind >> 24) & 0xff;
   if (type == GSX_F_BETWEEN && vt == GSX_VAR_POSE2) {
-    const P2 h = compose(inverse(load_pose2(values + P.var_state_off[v0])),
-                         load_pose2(values + P.var_state_off[P.f_vars[kp + 1]]));
+    const P2 h = compose(inverse(load_pose2(values + fr.s0)), load_pose2(values + fr.s1));
     const P2 zh = compose(inverse(load_pose2(z)), h);
     double e[3] = {zh.x, zh.y, theta(zh)};
     return whitened_half_sqnorm<3>(e, kind, np);
   }
   if (type == GSX_F_BETWEEN && vt == GSX_VAR_POSE3) {
-    const P3 h = between(load_pose3(values + P.var_state_off[v0]), load_pose3(values + P.var_state_off[P.f_vars[kp + 1]]));
+    const P3 h = between(load_pose3(values + fr.s0), load_pose3(values + fr.s1));
     double e[6];
     pose3_logmap(compose(inverse(load_pose3(z)), h), e);
     return whitened_half_sqnorm<6>(e, kind, np);
   }
   // generic: priors, vector between
-  const int m = P.f_rows[f];
+  const int m = fr.rows_dim & 0xffff;
   double e[9];
   if (type == GSX_F_PRIOR) {
-    local_coords(vt, P.var_dim[v0], values + P.var_state_off[v0], z, e);
+    local_coords(vt, fr.rows_dim >> 16, values + fr.s0, z, e);
   } else {
-    const double* x1 = values + P.var_state_off[v0];
-    const double* x2 = values + P.var_state_off[P.f_vars[kp + 1]];
+    const double* x1 = values + fr.s0;
+    const double* x2 = values + fr.s1;
     for (int r = 0; r < m; ++r) e[r] = (x2[r] - x1[r]) - z[r];
   }
   const int base = kind & GSX_NOISE_BASE_MASK, loss = kind >> 4;

@@ -114,6 +114,7 @@ struct gsx_context {
       d_f_noise_kind, d_f_cols;
   DevBuf<i64> d_f_meas_off, d_f_noise_off, d_f_jac_off;
   DevBuf<double> d_meas, d_noise;
+  DevBuf<FactorRec> d_frec;
   DevBuf<int> d_type_list[6];
   int type_count[6] = {0, 0, 0, 0, 0, 0};
   DevProblem DP{};
@@ -403,9 +404,27 @@ gsx_status upload_problem(gsx_context* c) {
       HIPCHK(c, hipStreamSynchronize(st));
     }
   }
+  {
+    // one 32-byte record per factor (kernels.h: FactorRec)
+    if (P.meas.size() >= (size_t)INT32_MAX || P.noise.size() >= (size_t)INT32_MAX || P.state_size >= INT32_MAX) {
+      c->err = "problem too large for 32-bit measurement / noise / state offsets";
+      return GSX_E_INVALID;
+    }
+    std::vector<FactorRec> fr(std::max(P.n_factors, 1));
+    for (int f = 0; f < P.n_factors; ++f) {
+      const int kp = P.f_key_ptr[f], nk = P.f_key_ptr[f + 1] - kp;
+      const int v0 = nk > 0 ? P.f_vars[kp] : -1, v1 = nk > 1 ? P.f_vars[kp + 1] : -1;
+      fr[f] = FactorRec{(i64)P.f_jac_off[f], v0 >= 0 ? P.state_off[v0] : -1, v1 >= 0 ? P.state_off[v1] : -1,
+                        (int)P.f_meas_ptr[f], (int)P.f_noise_ptr[f],
+                        P.f_type[f] | (P.f_noise_kind[f] << 8) | ((v0 >= 0 ? P.types[v0] : 0) << 24),
+                        P.f_rows[f] | ((v0 >= 0 ? P.dims[v0] : 0) << 16)};
+    }
+    HIPCHK(c, c->d_frec.upload(fr, st));
+  }
   DevProblem& D = c->DP;
   D.n_vars = P.n_vars;
   D.n_factors = P.n_factors;
+  D.frec = c->d_frec.p;
   D.var_type = c->d_var_type.p; D.var_dim = c->d_var_dim.p;
   D.var_state_off = c->d_var_state_off.p; D.var_tan_off = c->d_var_tan_off.p;
   D.f_type = c->d_f_type.p; D.f_rows = c->d_f_rows.p; D.f_key_ptr = c->d_f_key_ptr.p; D.f_vars = c->d_f_vars.p;
