@@ -10,6 +10,7 @@ import collections
 import csv
 import glob
 import json
+import re
 import sys
 
 
@@ -17,7 +18,7 @@ def load(d):
     f = glob.glob(d + "/*/*counter_collection.csv")[0]
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(f)):
-        n = r["Kernel_Name"].split("(")[0].replace("gsx::", "")
+        n = re.sub(r"<.*$", "", re.sub(r"^void\s+", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).split("(")[0].replace("gsx::", "")).strip()
         agg[n][r["Counter_Name"]] += float(r["Counter_Value"])
     return agg
 
