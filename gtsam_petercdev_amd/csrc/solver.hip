@@ -204,13 +204,6 @@ struct gsx_context {
     DevBuf<BigDesc> big;
     DevBuf<GatherSeg> segs;
   } ps;
-  // side streams: the size groups of one level are independent launches, each far from filling the GPU and bound by the
-  // latency of one front — they run side by side (fork from / join into the main stream with events)
-  static constexpr int kSide = 8;
-  hipStream_t side[kSide] = {};
-  hipEvent_t side_done[kSide] = {};
-  hipEvent_t side_start = nullptr;
-  bool side_ready = false;
   // the SIDE work of a factorization (Symbolic::side_*): a low-priority queue of its own
   hipStream_t bulk = nullptr;
   hipEvent_t bulk_go = nullptr, bulk_done = nullptr;
@@ -930,35 +923,6 @@ gsx_status upload_symbolic(gsx_context* c) {
   return GSX_OK;
 }
 
-// fork: side streams wait for everything queued on the main stream so far; join: the main stream waits for the first n
-bool side_fork(gsx_context* c) {
-  if (!c->side_ready) {
-    for (int i = 0; i < gsx_context::kSide; ++i) {
-      if (hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) != hipSuccess) return false;
-      if (hipEventCreateWithFlags(&c->side_done[i], hipEventDisableTiming) != hipSuccess) return false;
-    }
-    if (hipEventCreateWithFlags(&c->side_start, hipEventDisableTiming) != hipSuccess) return false;
-    c->side_ready = true;
-  }
-  hipEventRecord(c->side_start, c->stream);
-  return true;
-}
-hipStream_t side_stream(gsx_context* c, int i, unsigned* used) {
-  const int k = i % gsx_context::kSide;
-  if (!((*used >> k) & 1u)) {
-    hipStreamWaitEvent(c->side[k], c->side_start, 0);
-    *used |= 1u << k;
-  }
-  return c->side[k];
-}
-void side_join(gsx_context* c, unsigned used) {
-  for (int k = 0; k < gsx_context::kSide; ++k)
-    if ((used >> k) & 1u) {
-      hipEventRecord(c->side_done[k], c->side[k]);
-      hipStreamWaitEvent(c->stream, c->side_done[k], 0);
-    }
-}
-
 // in-place sum of device memory over the ranks of a sharded problem (gsx_set_shard); a failure is latched and reported
 // by the next readback
 void shard_allreduce(gsx_context* c, double* dptr, int64_t n) {
@@ -1195,17 +1159,15 @@ void dev_factorize(gsx_context* c, double lambda) {
   timer_end(c, PH_FACTORIZE);
 }
 
-// wf: ISAM2's partial back-substitution — the kernels skip the cliques no change reaches (DS.wf_*), and a bookkeeping pass
-// follows every level (nullptr: all cliques)
-// the level-by-level back-substitution over ALL fronts (the wildfire pass: its bookkeeping runs level by level)
+// The level-by-level back-substitution over ALL fronts.  wf: ISAM2's partial back-substitution — the kernels skip the
+// cliques no change reaches (DS.wf_*), and a bookkeeping pass follows every level (nullptr: all cliques).
 void dev_backsolve_levels(gsx_context* c, const WildfireArgs* wf) {
   const Symbolic& S = c->S;
   timer_begin(c, PH_BACKSOLVE);
   c->wf_delta_valid = false;  // (set again by the callers that leave a complete undamped solution behind)
-  const bool tree = false;
   for (int l = S.n_levels - 1; l >= 0; --l) {
     const int se = S.lvl_small_end[l];
-    struct {
+    const struct {
       int count;
     } B{S.lvl_ptr[l + 1] - se};
     const int le = S.lvl_leaf_end[l], n_rest = S.lvl_ptr[l + 1] - le;
@@ -1223,25 +1185,13 @@ void dev_backsolve_levels(gsx_context* c, const WildfireArgs* wf) {
                            c->d_status.p, c->stream);
       if (c->profiling > 0) timer_end(c, PH_K_BACKSOLVE);
     }
-    // the LDS-class fronts: their own kernels when every one of them has at most 64 frontal columns.  With the tree
-    // kernel only the ones that are not tree fronts are solved here (rest_launch: they sit above a blocked front).
+    // the LDS-class fronts: their own kernels when every one of them has at most 64 frontal columns
     const int* small_ids = c->d_sched.p + le;
-    int n_small = se - le;
+    const int n_small = se - le;
     int small_maxn = 0, small_maxF = 0;
-    if (tree) {
-      n_small = 0;
-      // (the level's ranges — whole-front-in-LDS ones, then medium ones — are consecutive in d_rest_ids)
-      if (!c->rest_launch[l].empty()) small_ids = c->d_rest_ids.p + c->rest_launch[l][0].begin;
-      for (const SmallLaunch& rl : c->rest_launch[l]) {
-        n_small += rl.count;
-        small_maxn = std::max(small_maxn, rl.max_n);
-        small_maxF = std::max(small_maxF, rl.max_F);
-      }
-    } else {
-      for (int k = le; k < se; ++k) {
-        small_maxn = std::max(small_maxn, S.N[S.sched[k]]);
-        small_maxF = std::max(small_maxF, S.F[S.sched[k]]);
-      }
+    for (int k = le; k < se; ++k) {
+      small_maxn = std::max(small_maxn, S.N[S.sched[k]]);
+      small_maxF = std::max(small_maxF, S.F[S.sched[k]]);
     }
     const bool small_own = n_small > 0 && backsolve_small_fits(small_maxn, small_maxF);
     if (small_own) {
@@ -1251,7 +1201,7 @@ void dev_backsolve_levels(gsx_context* c, const WildfireArgs* wf) {
       if (c->profiling > 0) timer_end(c, PH_K_BACKSOLVE);
     }
     const bool big_left = B.count > 0 && !big_own, small_left = n_small > 0 && !small_own;
-    if (!tree && big_left && small_left && n_rest <= 512 && n_rest > B.count) {
+    if (big_left && small_left && n_rest <= 512 && n_rest > B.count) {
       // few fronts: small and big ones of the level in ONE launch of the generic kernel
       int maxn = 0;
       for (int k = le; k < S.lvl_ptr[l + 1]; ++k) maxn = std::max(maxn, S.N[S.sched[k]]);
@@ -1275,19 +1225,6 @@ void dev_backsolve_levels(gsx_context* c, const WildfireArgs* wf) {
                          c->d_delta.p, c->d_status.p, c->stream);
         if (c->profiling > 0) timer_end(c, PH_K_BACKSOLVE);
       }
-    }
-    if (tree && l == 0) {
-      // every other front is solved: the tree fronts of all levels, one launch (their leaf-kernel children follow below)
-      hipMemsetAsync(c->d_bst_counters.p, 0, 2 * sizeof(int), c->stream);
-      if (++c->bst_epoch == 0) c->bst_epoch = 1;
-      if (c->profiling > 0) timer_begin(c, PH_K_BACKSOLVE);
-      launch_backsolve_tree(c->DS,
-                            BacksolveTreeArgs{c->d_bst_roots.p, c->bst_roots, c->bst_total, c->d_bst_child_ptr.p,
-                                              c->d_bst_children.p, c->d_bst_ready.p, c->d_bst_counters.p,
-                                              c->d_bst_counters.p + 1, c->bst_epoch},
-                            c->d_arena.p, c->d_delta.p, c->d_status.p, c->stream);
-      if (c->profiling > 0) timer_end(c, PH_K_BACKSOLVE);
-      debug_sync(c, "backsolve_tree", c->bst_roots, c->bst_total);
     }
     // all leaf-kernel cliques of the level in one launch (a wave each)
     if (S.lvl_leaf_end[l] > S.lvl_ptr[l])
@@ -1584,14 +1521,6 @@ gsx_status gsx_destroy(gsx_handle h) {
         hipEventDestroy(ev.first);
         hipEventDestroy(ev.second);
       }
-    }
-    if (h->side_ready) {
-      for (int i = 0; i < gsx_context::kSide; ++i) {
-        hipStreamSynchronize(h->side[i]);
-        hipStreamDestroy(h->side[i]);
-        hipEventDestroy(h->side_done[i]);
-      }
-      hipEventDestroy(h->side_start);
     }
     if (h->bulk) {
       hipStreamSynchronize(h->bulk);

@@ -1370,3 +1370,39 @@ def test_failed_factorization_is_not_reused(gpu):
     assert np.all(np.isfinite(be.solve(1e-3, False)))
     with pytest.raises(gt.IndeterminantLinearSystemException):
         be.solve(0.0, False)
+
+
+# ---- round 3: the dependency-driven launches against the level launches they replace ------------------------------------------
+@pytest.mark.parametrize("name,maker", [
+    ("pose3_1500", lambda: datasets.synth_manhattan_pose3(1500, seed=9)),
+    ("pose2_5000", lambda: datasets.synth_manhattan_pose2(5000, seed=9)),
+    ("pose3_small", lambda: PROBLEMS["pose3"]),
+    ("pose2_small", lambda: PROBLEMS["pose2"]),
+])
+def test_tree_kernels_against_the_level_launches(gpu, name, maker, monkeypatch):
+    """front_tree_kernel (a workgroup climbs from a front to its parent when it was the last child to arrive) and
+    backsolve_tree_kernel (ticket list, top-down) run the same front bodies as the level-by-level launches, whatever
+    workgroup arrives when: the damped step is the same BITS from run to run, and equals the step with the tree kernels
+    switched off (GSX_TREE_TIERS=0: no tree fronts, every LDS front in its level's launch) to rounding — the two
+    schedules give a front other workgroup sizes, so the panel updates sum in other shapes (measured: not bit-equal)."""
+    arr = maker()
+    steps = {}
+    for mode in ("tree", "levels"):
+        if mode == "levels":
+            monkeypatch.setenv("GSX_TREE_TIERS", "0")
+        be = gpu.product_backend(arr)
+        be.set_amalgamation(0.5, 32)
+        be.set_ordering(be.compute_ordering(A.ORDER_ND))
+        st = be.stats()
+        assert (st["n_tree_fronts"] > 0) == (mode == "tree"), (name, mode, st["n_tree_fronts"])
+        # (graphs without blocked fronts: with them, switching the tree fronts off also moves LDS fronts into the blocked
+        #  launches of their level — other kernels, other rounding)
+        assert st["n_big_fronts"] == 0
+        be.linearize()
+        d1 = be.solve(1e-3, False)
+        d2 = be.solve(1e-3, False)
+        assert np.array_equal(d1, d2)
+        steps[mode] = (d1, be.solve(1e-2, True), be.hessian_diagonal())
+        be.close()
+    for a, b in zip(steps["tree"], steps["levels"]):
+        assert np.allclose(a, b, rtol=1e-9, atol=1e-11 * np.abs(b).max()), (name, np.abs(a - b).max())
