@@ -19,7 +19,7 @@ GSX_OK, GSX_E_INVALID, GSX_E_NO_DEVICE, GSX_E_BAD_ORDERING, GSX_E_INDETERMINATE,
 VAR_VECTOR, VAR_POSE2, VAR_POSE3, VAR_CAMERA = range(4)
 F_LINEAR, F_PRIOR, F_BETWEEN, F_SFM, F_PROJECTION, F_BEARINGRANGE = range(6)
 NOISE_FORMAT_G2O, NOISE_FORMAT_TORO, NOISE_FORMAT_GRAPH, NOISE_FORMAT_COV, NOISE_FORMAT_AUTO = range(5)
-NOISE_UNIT, NOISE_ISOTROPIC, NOISE_DIAGONAL, NOISE_GAUSSIAN = range(4)
+NOISE_UNIT, NOISE_ISOTROPIC, NOISE_DIAGONAL, NOISE_GAUSSIAN, NOISE_CONSTRAINED = range(5)
 NOISE_ROBUST_HUBER, NOISE_ROBUST_TUKEY, NOISE_ROBUST_CAUCHY, NOISE_BASE_MASK = 1 << 4, 2 << 4, 3 << 4, 15
 ORDER_NATURAL, ORDER_MINDEGREE, ORDER_ND, ORDER_SCHUR, ORDER_SCHUR_ND = range(5)
 

@@ -275,7 +275,9 @@ class noiseModel:
         @staticmethod
         def Sigmas(sigmas, smart=True):
             s = np.asarray(sigmas, dtype=float).reshape(-1)
-            # NoiseModel.cpp:284-309: all sigmas equal -> Isotropic
+            # NoiseModel.cpp:292-309: a (near-)zero sigma makes the model Constrained; all sigmas equal -> Isotropic
+            if smart and s.size > 0 and np.any(s < 1e-8):
+                return noiseModel.Constrained.MixedSigmas(s)
             if smart and s.size > 0 and np.all(np.abs(s - s[0]) < 1e-9):
                 return noiseModel.Isotropic.Sigma(s.size, float(s[0]), True)
             return _Noise(A.NOISE_DIAGONAL, s.size, s)
@@ -287,6 +289,24 @@ class noiseModel:
         @staticmethod
         def Precisions(precisions, smart=True):
             return noiseModel.Diagonal.Sigmas(1.0 / np.sqrt(np.asarray(precisions, dtype=float)), smart)
+
+    class Constrained:
+        """noiseModel::Constrained (gtsam/linear/NoiseModel.h:389-500): rows with sigma == 0 are hard constraints (eliminated
+        by constraint pivots instead of Cholesky, NoiseModel.cpp:503-620); mu weighs their violation in the error functions."""
+
+        @staticmethod
+        def MixedSigmas(*args):
+            if len(args) == 1:
+                sigmas = np.asarray(args[0], dtype=float).reshape(-1)
+                mu = np.full(sigmas.size, 1000.0)
+            else:
+                sigmas = np.asarray(args[1], dtype=float).reshape(-1)
+                mu = np.broadcast_to(np.asarray(args[0], dtype=float), sigmas.shape).astype(float)
+            return _Noise(A.NOISE_CONSTRAINED, sigmas.size, np.concatenate([sigmas, mu]))
+
+        @staticmethod
+        def All(dim, mu=1000.0):
+            return noiseModel.Constrained.MixedSigmas(mu, np.zeros(int(dim)))
 
     class Gaussian:
         @staticmethod

@@ -119,9 +119,16 @@ enum {
 enum {
   GSX_NOISE_UNIT = 0,       /* no parameters                                     */
   GSX_NOISE_ISOTROPIC = 1,  /* 1 parameter: sigma                                */
-  GSX_NOISE_DIAGONAL = 2,   /* m parameters: sigmas                              */
+  GSX_NOISE_DIAGONAL = 2,   /* m parameters: sigmas.  A sigma of exactly 0 makes
+                               the row a HARD CONSTRAINT — noiseModel::Constrained::
+                               MixedSigmas(sigmas), mu = 1000 (NoiseModel.h:389-500) */
   GSX_NOISE_GAUSSIAN = 3,   /* m*m parameters: upper-triangular sqrt information R,
                                row-major (whitened = R * unwhitened)             */
+  GSX_NOISE_CONSTRAINED = 4,/* 2m parameters: sigmas (0 = hard constraint), then the
+                               weights mu the violated constraint rows get in the
+                               error functions — Constrained::MixedSigmas(mu, sigmas)
+                               (NoiseModel.cpp:371-381,438-444).  See "Hard
+                               constraints" below.                                */
   /* noiseModel::Robust (gtsam/linear/NoiseModel.cpp:709-735, LossFunctions.cpp): OR one of these onto the base
    * kind above and append ONE parameter (k / c) after the base model's parameters.  Linearization whitens with
    * the base model and then scales [A b] by sqrt(weight(|b|)) (Block reweighting); the factor's error is

@@ -65,6 +65,10 @@ struct Factor {
   int type, rows, noise_kind;
   vector<int> vars;
   Vec meas, noise;
+  // noiseModel::Constrained (gtsam/linear/NoiseModel.h:389-500): rows with sigma == 0 are hard constraints; mu is the
+  // weight their violation gets in the ERROR functions (default 1000, NoiseModel.cpp:365-368).  Empty: no such row.
+  Vec mu;
+  bool constrained(int r) const { return !mu.empty() && noise[r] == 0.0; }
 };
 
 // A linear factor of the GaussianFactorGraph: either Jacobian [A b] or Hessian.
@@ -74,6 +78,14 @@ struct LinFactor {
   vector<int> dims;   // tangent dims per variable
   int rows = 0;       // Jacobian: m
   Vec M;              // Jacobian: m x (sum d + 1) col-major; Hessian: (sum d + 1)^2 col-major (upper)
+  // Jacobian with a noise model (JacobianFactor::model_): per-row sigmas — 0 = hard constraint — and the constraint
+  // weights mu of Constrained::unit() (NoiseModel.cpp:470-476).  Empty: no model (whitened, unit).
+  Vec sigmas, mu;
+  bool has_constraints() const {
+    for (double sg : sigmas)
+      if (sg == 0.0) return true;
+    return false;
+  }
   int cols() const {
     int c = 1;
     for (int d : dims) c += d;
@@ -172,9 +184,11 @@ static void whiten_rows_base(const Factor& f0, double* M, int m, int ncols) {
   if (f.noise_kind == GSX_NOISE_ISOTROPIC) {
     const double inv = 1.0 / f.noise[0];
     for (int i = 0; i < m * ncols; ++i) M[i] *= inv;
-  } else if (f.noise_kind == GSX_NOISE_DIAGONAL) {
+  } else if (f.noise_kind == GSX_NOISE_DIAGONAL || f.noise_kind == GSX_NOISE_CONSTRAINED) {
+    // (Constrained::Whiten / whiten — NoiseModel.cpp:395-410,447-468: a row with sigma 0 is left as it is)
     for (int c = 0; c < ncols; ++c)
-      for (int r = 0; r < m; ++r) M[c * m + r] *= (1.0 / f.noise[r]);
+      for (int r = 0; r < m; ++r)
+        if (f.noise[r] != 0.0) M[c * m + r] *= (1.0 / f.noise[r]);
   } else {  // GAUSSIAN: R (m x m row-major upper) * M
     Vec col(m);
     for (int c = 0; c < ncols; ++c) {
@@ -343,7 +357,8 @@ static double factor_error(const Problem& P, const Factor& f, const double* valu
   eval_factor(P, f, values, e, nullptr);
   whiten_rows_base(f, e, f.rows, 1);  // squaredMahalanobisDistance of the base model
   double s = 0;
-  for (int i = 0; i < f.rows; ++i) s += e[i] * e[i];
+  // (Constrained::squaredMahalanobisDistance — NoiseModel.cpp:438-444: v_i sqrt(mu_i) on the constrained rows)
+  for (int i = 0; i < f.rows; ++i) s += e[i] * e[i] * (f.constrained(i) ? f.mu[i] : 1.0);
   const int loss = f.noise_kind >> 4;
   if (loss) return robust_loss(loss, f.noise.back(), std::sqrt(s));  // Robust::loss — NoiseModel.h
   return 0.5 * s;
@@ -385,6 +400,12 @@ static void linearize(Problem& P) {
       L.rows = f.rows;
       const int m = f.rows, nc = L.cols();
       L.M.assign((size_t)m * nc, 0.0);
+      if (!f.mu.empty()) {  // NoiseModelFactor::linearize returns JacobianFactor(terms, b, constrained->unit()) (:176-180)
+        L.sigmas.assign(m, 1.0);
+        L.mu = f.mu;
+        for (int r = 0; r < m; ++r)
+          if (f.constrained(r)) L.sigmas[r] = 0.0;
+      }
       if (f.type == GSX_F_LINEAR) {
         L.M = f.meas;  // already [A b]
         whiten_rows(f, L.M.data(), m, nc);
@@ -419,7 +440,12 @@ static double linear_error(const Problem& P, const vector<LinFactor>& gfg, const
           for (int r = 0; r < m; ++r) e[r] += L.M[(size_t)col * m + r] * x[c];
     }
     double s = 0;
-    for (int r = 0; r < m; ++r) s += e[r] * e[r];
+    // (with a model: 0.5 * model->squaredMahalanobisDistance(unweighted_error) — JacobianFactor.cpp:508-513)
+    for (int r = 0; r < m; ++r) {
+      double w = 1.0;
+      if (!L.sigmas.empty()) w = L.sigmas[r] == 0.0 ? L.mu[r] : 1.0 / (L.sigmas[r] * L.sigmas[r]);
+      s += w * e[r] * e[r];
+    }
     total += 0.5 * s;
   }
   return total;
@@ -434,7 +460,12 @@ static void hessian_diagonal(const Problem& P, const vector<LinFactor>& gfg, dou
     for (size_t k = 0; k < L.vars.size(); ++k)
       for (int c = 0; c < L.dims[k]; ++c, ++col) {
         double s = 0;
-        for (int r = 0; r < m; ++r) s += L.M[(size_t)col * m + r] * L.M[(size_t)col * m + r];
+        // (JacobianFactor::hessianDiagonalAdd whitens the column with the model, :548-556; Constrained::whiten leaves
+        //  the rows of sigma 0 as they are)
+        for (int r = 0; r < m; ++r) {
+          const double w = (L.sigmas.empty() || L.sigmas[r] == 0.0) ? 1.0 : 1.0 / L.sigmas[r];
+          s += w * w * L.M[(size_t)col * m + r] * L.M[(size_t)col * m + r];
+        }
         d[P.tan_off[L.vars[k]] + c] += s;
       }
   }
@@ -633,13 +664,233 @@ struct JTBuilder {
 };
 
 // ---------------------------------------------------------------------------
+// Constrained::QR — gtsam/linear/NoiseModel.cpp:478-620 (check_if_constraint :483-501).
+// Ab: m x (n + 1) ROW-major, overwritten with the rows of [R d] (row i starts at column lead[i]); returns the
+// precisions of the rows (infinity: still a hard constraint).
+// ---------------------------------------------------------------------------
+static void constrained_qr(Vec& Ab, int m_in, int n, const Vec& sigmas, vector<int>& lead, Vec& precisions) {
+  const double kInf = std::numeric_limits<double>::infinity();
+  const int n1 = n + 1;
+  int m = m_in;
+  const size_t maxRank = (size_t)std::min(m, n);
+  Vec invsigmas(m), weights(m);
+  for (int i = 0; i < m; ++i) {
+    invsigmas[i] = 1.0 / sigmas[i];
+    weights[i] = invsigmas[i] * invsigmas[i];
+  }
+  vector<Vec> Rd;
+  vector<int> Rj;
+  Vec Rp;
+  Vec rd(n1, 0.0);
+  for (int j = 0; j < n; ++j) {
+    // the constrained row with the largest entry in column j, if that exceeds 1e-9
+    int crow = -1;
+    double max_element = 1e-9;
+    for (int i = 0; i < m; ++i) {
+      if (!std::isinf(invsigmas[i])) continue;
+      const double a = std::abs(Ab[(size_t)i * n1 + j]);
+      if (a > max_element) {
+        max_element = a;
+        crow = i;
+      }
+    }
+    if (crow >= 0) {
+      for (int c = 0; c < n1; ++c) rd[c] = Ab[(size_t)crow * n1 + c];   // the row itself: [R|d] is the row of [A|b]
+      Rd.push_back(rd);
+      Rj.push_back(j);
+      Rp.push_back(kInf);
+      if (Rd.size() >= maxRank) break;
+      // swap the last valid row in, one row fewer
+      m -= 1;
+      if (crow != m) {
+        for (int c = 0; c < n1; ++c) Ab[(size_t)crow * n1 + c] = Ab[(size_t)m * n1 + c];
+        weights[crow] = weights[m];
+        invsigmas[crow] = invsigmas[m];
+      }
+      const double inv = 1.0 / rd[j];
+      for (int i = 0; i < m; ++i) {
+        const double a = Ab[(size_t)i * n1 + j] * inv;
+        Ab[(size_t)i * n1 + j] = a;
+        for (int c = j + 1; c < n1; ++c) Ab[(size_t)i * n1 + c] -= a * rd[c];
+      }
+    } else {
+      // Gram-Schmidt with the weighted pseudo-inverse of the column
+      double precision = 0;
+      Vec pseudo(m);
+      for (int i = 0; i < m; ++i) {
+        const double ai = Ab[(size_t)i * n1 + j];
+        if (std::abs(ai) > 1e-9) {
+          pseudo[i] = weights[i] * ai;
+          precision += pseudo[i] * ai;
+        } else {
+          pseudo[i] = 0;
+        }
+      }
+      if (precision > 1e-8) {
+        for (int i = 0; i < m; ++i) pseudo[i] /= precision;
+        rd[j] = 1.0;
+        for (int c = j + 1; c < n1; ++c) {
+          double sacc = 0;
+          for (int i = 0; i < m; ++i) sacc += pseudo[i] * Ab[(size_t)i * n1 + c];
+          rd[c] = sacc;
+        }
+        Rd.push_back(rd);
+        Rj.push_back(j);
+        Rp.push_back(precision);
+      } else {
+        continue;  // no information on this column
+      }
+      if (Rd.size() >= maxRank) break;
+      for (int i = 0; i < m; ++i) {
+        const double a = Ab[(size_t)i * n1 + j];
+        for (int c = j + 1; c < n1; ++c) Ab[(size_t)i * n1 + c] -= a * rd[c];
+      }
+    }
+  }
+  std::fill(Ab.begin(), Ab.end(), 0.0);
+  lead = Rj;
+  precisions = Rp;
+  for (size_t i = 0; i < Rd.size(); ++i)
+    for (int c = Rj[i]; c < n1; ++c) Ab[i * n1 + c] = Rd[i][c];
+}
+
+// choleskyCareful on the whole matrix — gtsam/base/cholesky.cpp:36-105 (A: n x n col-major, UPPER triangle used / written)
+static std::pair<int, bool> cholesky_careful(double* A, int n) {
+  int maxrank = 0;
+  for (int k = 0; k < n; ++k) {
+    double alpha = A[(size_t)k * n + k];
+    if (alpha < -1e-1) return {maxrank, false};
+    if (alpha < 0.0) alpha = 0.0;
+    const double beta = std::sqrt(alpha);
+    if (beta > 1e-6) {
+      const double betainv = 1.0 / beta;
+      A[(size_t)k * n + k] = beta;
+      for (int c = k + 1; c < n; ++c) A[(size_t)c * n + k] *= betainv;
+      for (int c = k + 1; c < n; ++c)
+        for (int r = k + 1; r <= c; ++r) A[(size_t)c * n + r] -= A[(size_t)r * n + k] * A[(size_t)c * n + k];
+      maxrank = k + 1;
+    } else {
+      A[(size_t)k * n + k] = 1e-5;
+      for (int c = k + 1; c < n; ++c) A[(size_t)c * n + k] = 0.0;
+    }
+  }
+  return {maxrank, true};
+}
+
+static bool has_constraints(const vector<const LinFactor*>& factors) {  // GaussianFactorGraph.cpp:442-451
+  for (const LinFactor* f : factors)
+    if (!f->hessian && f->has_constraints()) return true;
+  return false;
+}
+
+// ---------------------------------------------------------------------------
 // EliminateCholesky on one clique — gtsam/linear/HessianFactor.cpp:515-535,
 // Scatter (gtsam/linear/Scatter.cpp:39-73), HessianFactor merge ctor
 // (HessianFactor.cpp:240-253), updateHessian (JacobianFactor.cpp:586-624,
 // HessianFactor.cpp:349-373), eliminateCholesky (HessianFactor.cpp:458-486).
 // ---------------------------------------------------------------------------
+// EliminateQR on one clique with a constrained noise model — gtsam/linear/JacobianFactor.cpp:804-842 (EliminateQR),
+// :224-311 (the combined JacobianFactor: rows stacked in factor order, sigmas copied, model Constrained::MixedSigmas),
+// :86-112 (JacobianFactor(HessianFactor): choleskyCareful of the whole augmented matrix), :845-897 (splitConditional).
+static void eliminate_qr(const Problem& P, const vector<const LinFactor*>& factors, const vector<int>& frontals,
+                         Conditional& cond, LinFactor& remaining) {
+  vector<int> slots_var = frontals;
+  {
+    std::set<int> rest;
+    for (const LinFactor* f : factors)
+      for (int v : f->vars) rest.insert(v);
+    for (int v : frontals) rest.erase(v);
+    slots_var.insert(slots_var.end(), rest.begin(), rest.end());
+  }
+  const int nslots = (int)slots_var.size();
+  vector<int> off(nslots + 1, 0);
+  for (int s = 0; s < nslots; ++s) off[s + 1] = off[s] + P.dims[slots_var[s]];
+  const int n = off[nslots], n1 = n + 1;
+  std::map<int, int> slot_of;
+  for (int s = 0; s < nslots; ++s) slot_of[slots_var[s]] = s;
+  // every factor as a Jacobian
+  struct Rows {
+    int m;
+    Vec M;       // m x cols col-major over the factor's own variables + rhs
+    Vec sigmas;  // empty: no model
+    const LinFactor* f;
+  };
+  vector<Rows> jac;
+  for (const LinFactor* f : factors) {
+    Rows R;
+    R.f = f;
+    if (!f->hessian) {
+      R.m = f->rows;
+      R.M = f->M;
+      R.sigmas = f->sigmas;
+    } else {
+      const int c = f->cols();
+      Vec A = f->M;  // upper triangle holds the information matrix
+      const auto res = cholesky_careful(A.data(), c);
+      if (!(res.second || res.first == c - 1)) throw IndeterminantLinearSystem{P.keys[f->vars.front()]};
+      R.m = res.first;
+      R.M.assign((size_t)R.m * c, 0.0);
+      for (int col = 0; col < c; ++col)
+        for (int r = 0; r < R.m && r <= col; ++r) R.M[(size_t)col * R.m + r] = A[(size_t)col * c + r];
+    }
+    jac.push_back(std::move(R));
+  }
+  int m = 0;
+  for (const Rows& R : jac) m += R.m;
+  Vec Ab((size_t)m * n1, 0.0), sigmas(m, 1.0);  // row-major
+  int row0 = 0;
+  for (const Rows& R : jac) {
+    if (R.m == 0) continue;
+    int col = 0;
+    const LinFactor* f = R.f;
+    for (size_t k = 0; k <= f->vars.size(); ++k) {
+      const int d = k < f->vars.size() ? f->dims[k] : 1;
+      const int dst = k < f->vars.size() ? off[slot_of.at(f->vars[k])] : n;
+      for (int c = 0; c < d; ++c, ++col)
+        for (int r = 0; r < R.m; ++r) Ab[(size_t)(row0 + r) * n1 + dst + c] = R.M[(size_t)col * R.m + r];
+    }
+    if (!R.sigmas.empty())
+      for (int r = 0; r < R.m; ++r) sigmas[row0 + r] = R.sigmas[r];
+    row0 += R.m;
+  }
+  vector<int> lead;
+  Vec precisions;
+  constrained_qr(Ab, m, n, sigmas, lead, precisions);
+  const int rank = (int)lead.size();
+  int nfs = 0;
+  for (int v : frontals) nfs += P.dims[v];
+  if (rank < nfs) throw IndeterminantLinearSystem{P.keys[frontals.front()]};  // (model_->dim() < frontalDim, :860-863)
+  cond.frontals = frontals;
+  cond.parents.assign(slots_var.begin() + frontals.size(), slots_var.end());
+  cond.nf = nfs;
+  cond.ncols = n1;
+  cond.RSd.assign((size_t)nfs * n1, 0.0);
+  for (int r = 0; r < nfs; ++r)
+    for (int c = 0; c < n1; ++c) cond.RSd[(size_t)c * nfs + r] = Ab[(size_t)r * n1 + c];
+  const int rem = std::min(rank - nfs, std::min(n1, m) - nfs);
+  remaining.hessian = false;
+  remaining.vars = cond.parents;
+  remaining.dims.clear();
+  for (int v : remaining.vars) remaining.dims.push_back(P.dims[v]);
+  remaining.rows = std::max(rem, 0);
+  const int c2 = n1 - nfs;
+  remaining.M.assign((size_t)remaining.rows * c2, 0.0);
+  remaining.sigmas.assign(remaining.rows, 1.0);
+  remaining.mu.assign(remaining.rows, 1000.0);  // (MixedSigmas(sigmas) of splitConditional :889-890: the default mu)
+  for (int r = 0; r < remaining.rows; ++r) {
+    for (int c = 0; c < c2; ++c) remaining.M[(size_t)c * remaining.rows + r] = Ab[(size_t)(nfs + r) * n1 + nfs + c];
+    const double pr = precisions[nfs + r];
+    remaining.sigmas[r] = std::isinf(pr) ? 0.0 : 1.0 / std::sqrt(pr);
+  }
+}
+
 static void eliminate_clique(const Problem& P, const vector<const LinFactor*>& factors,
                              const vector<int>& frontals, Conditional& cond, LinFactor& remaining) {
+  // EliminatePreferCholesky — gtsam/linear/HessianFactor.cpp:538-551
+  if (has_constraints(factors)) {
+    eliminate_qr(P, factors, frontals, cond, remaining);
+    return;
+  }
   // Scatter: frontals first (given order), then the other variables sorted by key
   // (variables are indexed in ascending key order, so sort by index).
   vector<int> slots_var = frontals;
@@ -674,7 +925,13 @@ static void eliminate_clique(const Problem& P, const vector<const LinFactor*>& f
     if (!f->hessian) {
       const int m = f->rows;
       if (m == 0) continue;
-      const double* A = f->M.data();
+      Vec whitened;
+      if (!f->sigmas.empty()) {  // HessianFactor(JacobianFactor) whitens with the model (HessianFactor.cpp:210-229)
+        whitened = f->M;
+        for (int c = 0; c < f->cols(); ++c)
+          for (int r = 0; r < m; ++r) whitened[(size_t)c * m + r] /= f->sigmas[r];
+      }
+      const double* A = whitened.empty() ? f->M.data() : whitened.data();
       for (int j = 0; j <= nb; ++j) {
         const int J = fs[j];
         for (int i = 0; i <= j; ++i) {
@@ -1322,6 +1579,18 @@ static Problem* build_problem(const gsx_problem_desc* d, std::string& err) {
     f.vars.assign(d->f_vars + d->f_key_ptr[i], d->f_vars + d->f_key_ptr[i + 1]);
     f.meas.assign(d->meas + d->f_meas_ptr[i], d->meas + d->f_meas_ptr[i + 1]);
     f.noise.assign(d->noise + d->f_noise_ptr[i], d->noise + d->f_noise_ptr[i + 1]);
+    if (f.noise_kind == GSX_NOISE_CONSTRAINED) {  // sigmas, then mu
+      if ((int)f.noise.size() != 2 * f.rows) {
+        err = "constrained noise model: 2 m parameters";
+        return nullptr;
+      }
+      f.mu.assign(f.noise.begin() + f.rows, f.noise.end());
+      f.noise.resize(f.rows);
+    } else if (f.noise_kind == GSX_NOISE_DIAGONAL) {
+      bool any = false;
+      for (double sg : f.noise) any = any || sg == 0.0;
+      if (any) f.mu.assign(f.rows, 1000.0);  // Constrained(sigmas) — NoiseModel.cpp:365-368
+    }
     int cols = 1;
     for (int v : f.vars) {
       if (v < 0 || v >= d->n_vars) {
@@ -1632,6 +1901,21 @@ int orc_get_conditional(void* h, int32_t c, int32_t* nf, int32_t* ncols, double*
   if (nf) *nf = cd.nf;
   if (ncols) *ncols = cd.ncols;
   if (out) std::memcpy(out, cd.RSd.data(), cd.RSd.size() * sizeof(double));
+  return GSX_OK;
+}
+// Constrained::QR on a dense [A b] (m x (n + 1) ROW-major, overwritten by the rows of [R d]); lead / precisions: min(m, n)
+// entries (infinity = hard constraint).  For the known-answer tests of gtsam/linear/tests/testNoiseModel.cpp:225-390.
+int orc_constrained_qr(double* Ab, int32_t m, int32_t n, const double* sigmas, int32_t* lead, double* precisions,
+                       int32_t* rank) {
+  orc::Vec M(Ab, Ab + (size_t)m * (n + 1)), sg(sigmas, sigmas + m), pr;
+  std::vector<int> ld;
+  orc::constrained_qr(M, m, n, sg, ld, pr);
+  std::copy(M.begin(), M.end(), Ab);
+  *rank = (int32_t)ld.size();
+  for (size_t i = 0; i < ld.size(); ++i) {
+    lead[i] = ld[i];
+    precisions[i] = pr[i];
+  }
   return GSX_OK;
 }
 int orc_cholesky_partial(double* abc, int32_t n, int32_t nfrontal, int32_t* ok) {

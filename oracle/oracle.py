@@ -88,6 +88,25 @@ def cholesky_partial(abc: np.ndarray, nfrontal: int):
     return m, bool(ok.value)
 
 
+def constrained_qr(Ab: np.ndarray, sigmas):
+    """noiseModel::Constrained::QR restatement (gtsam/linear/NoiseModel.cpp:478-620) on an (m, n+1) array: returns
+    (Rd with rank rows — zeros below, sigmas of the rows: 0 = still a hard constraint, leading columns)."""
+    M = np.ascontiguousarray(Ab, dtype=np.float64).copy()
+    m, n1 = M.shape
+    sg = np.ascontiguousarray(sigmas, dtype=np.float64)
+    k = min(m, n1 - 1)
+    lead = np.zeros(max(k, 1), np.int32)
+    prec = np.zeros(max(k, 1))
+    rank = C.c_int32()
+    load().orc_constrained_qr(M.ctypes.data_as(C.POINTER(C.c_double)), C.c_int32(m), C.c_int32(n1 - 1),
+                              sg.ctypes.data_as(C.POINTER(C.c_double)), lead.ctypes.data_as(C.POINTER(C.c_int32)),
+                              prec.ctypes.data_as(C.POINTER(C.c_double)), C.byref(rank))
+    r = rank.value
+    with np.errstate(divide="ignore"):
+        out_sigmas = np.where(np.isinf(prec[:r]), 0.0, 1.0 / np.sqrt(prec[:r]))
+    return M, out_sigmas, lead[:r].copy()
+
+
 # ---- the reference's own CCOLAMD, compiled from its C sources (oracle/Makefile) ----------------
 def have_ref_colamd() -> bool:
     return os.path.exists(REF_COLAMD_PATH)

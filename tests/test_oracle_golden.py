@@ -943,3 +943,148 @@ def test_oracle_threads_are_bitwise_identical_to_serial(oracle, kind):
     assert a[2] == b[2] and all(np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) for x, y in zip(a[3], b[3]))
     assert all(np.array_equal(x, y) for x, y in zip(a[4], b[4]))
     assert a[5] == b[5]
+
+
+# ---- hard constraints: noiseModel::Constrained and the QR elimination of a clique that holds one -------------------------------
+def _linear_dependent_rows(expected, actual, tol):
+    """assert the rows of the two matrices are pairwise parallel (linear_dependent of gtsam/base/Matrix.cpp: what the
+    reference's tests compare the constrained QR with — a constraint row keeps its own scale)."""
+    expected, actual = np.asarray(expected, float), np.asarray(actual, float)
+    assert expected.shape == actual.shape
+    for e, a in zip(expected, actual):
+        if np.allclose(e, 0, atol=tol):
+            assert np.allclose(a, 0, atol=tol)
+            continue
+        k = np.argmax(np.abs(e))
+        assert abs(a[k]) > tol, (e, a)
+        assert np.allclose(a * (e[k] / a[k]), e, atol=10 * tol), (e, a)
+
+
+def test_NoiseModel_constrained_QR(orc):
+    """gtsam/linear/tests/testNoiseModel.cpp:225-248 (the Constrained half of QR on exampleQR::Ab, :205-222)."""
+    Ab = np.array([[-1., 0., 1., 0., 0., 0., -0.2],
+                   [0., -1., 0., 1., 0., 0., 0.3],
+                   [1., 0., 0., 0., -1., 0., 0.2],
+                   [0., 1., 0., 0., 0., -1., -0.1]])
+    Rd, sigmas, _ = orc.constrained_qr(Ab, [0.2, 0.2, 0.1, 0.1])
+    assert np.allclose(sigmas, [0.0894427, 0.0894427, 0.223607, 0.223607], atol=1e-6)
+    expected = np.array([[1., 0., -0.2, 0., -0.8, 0., 0.2],
+                         [0., 1., 0., -0.2, 0., -0.8, -0.14],
+                         [0., 0., 1., 0., -1., 0., 0.0],
+                         [0., 0., 0., 1., 0., -1., 0.2]])
+    _linear_dependent_rows(expected, Rd, 1e-6)
+
+
+def test_NoiseModel_OverdeterminedQR(orc):
+    """testNoiseModel.cpp:251-282 (Constrained version on unit sigmas: rows not divided by sigma)."""
+    Ab = np.vstack([[0, 1, 0, 0], [0, 0, 1, 0], np.ones((7, 4))]).astype(float)
+    Rd, sigmas, _ = orc.constrained_qr(Ab, np.ones(9))
+    assert np.allclose(sigmas, [0.377964473, 1, 1], atol=1e-6)
+    expected = np.zeros((9, 4))
+    expected[0] = np.array([2.64575131] * 4) * 0.377964473
+    expected[1, 1] = 1
+    expected[2, 2] = 1
+    assert np.allclose(Rd, expected, atol=1e-6)
+
+
+def test_NoiseModel_MixedQR(orc):
+    """testNoiseModel.cpp:285-315."""
+    Ab = np.array([[1, 0, 0, 0, 0, 1, 0],
+                   [0, 0, 0, 0, 1, 0, 0],
+                   [0, 0, 1, 1, 0, 0, 0],
+                   [0, 1, 0, 0, 0, 0, 0],
+                   [0, 0, 0, 0, 0, 1, 0]], float)
+    Rd, sigmas, _ = orc.constrained_qr(Ab, [0, 1, 0, 1, 1])
+    assert np.allclose(sigmas, [0, 1, 0, 1, 1], atol=1e-6)
+    expected = np.array([[1, 0, 0, 0, 0, 1, 0],
+                         [0, 1, 0, 0, 0, 0, 0],
+                         [0, 0, 1, 1, 0, 0, 0],
+                         [0, 0, 0, 0, 1, 0, 0],
+                         [0, 0, 0, 0, 0, 1, 0]], float)
+    _linear_dependent_rows(expected, Rd, 1e-6)
+
+
+def test_NoiseModel_MixedQR2(orc):
+    """testNoiseModel.cpp:318-354: x = z and y = z — all the measurements are measurements of z."""
+    rows = [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [-1, 0, 1, 0], [1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0],
+            [0, -1, 1, 0], [1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]]
+    sg = np.ones(11)
+    sg[3] = sg[7] = 0
+    Rd, sigmas, _ = orc.constrained_qr(np.array(rows, float), sg)
+    assert np.allclose(sigmas, [0, 0, 1.0 / 3], atol=1e-6)
+    expected = np.zeros((11, 4))
+    expected[0] = [-1, 0, 1, 0]
+    expected[1] = [0, -1, 1, 0]
+    expected[2] = [0, 0, 1, 0]
+    assert np.allclose(Rd, expected, atol=1e-6)
+
+
+def test_NoiseModel_FullyConstrained_and_QRNan(orc):
+    """testNoiseModel.cpp:357-390."""
+    Ab = np.array([[1, 0, 0, 0, 0, 1, 2], [0, 0, 1, 1, 0, 0, 4], [0, 1, 0, 1, 1, 1, 8]], float)
+    Rd, sigmas, _ = orc.constrained_qr(Ab, np.zeros(3))
+    assert np.array_equal(sigmas, [0, 0, 0])
+    _linear_dependent_rows([[1, 0, 0, 0, 0, 1, 2], [0, 1, 0, 1, 1, 1, 8], [0, 0, 1, 1, 0, 0, 4]], Rd, 1e-6)
+    Rd, sigmas, _ = orc.constrained_qr(np.array([[2, 4, 2, 4, 6], [2, 1, 2, 4, 4]], float), np.zeros(2))
+    assert np.array_equal(sigmas, [0, 0])
+    _linear_dependent_rows([[1, 2, 1, 2, 3], [0, 1, 0, 0, 2.0 / 3]], Rd, 1e-9)
+
+
+def test_JacobianFactor_constraint_eliminate(orc):
+    """gtsam/linear/tests/testJacobianFactor.cpp:588-641: constraint_eliminate1 (x = v), constraint_eliminate2 (R = [1 2; 0 1],
+    S = [1 2; 0 0] up to the scale of a constraint row)."""
+    fg = GaussianFactorGraph()
+    fg.add(JacobianFactor(1, np.eye(2), [1.2, 3.4], noiseModel.Constrained.All(2)))
+    be = orc.oracle_backend(fg.to_arrays())
+    be.set_ordering([1])
+    be.linearize()
+    assert np.allclose(be.solve(0.0, False), [1.2, 3.4], atol=1e-12)
+    _linear_dependent_rows([[1, 0, 1.2], [0, 1, 3.4]], be.conditional(0), 1e-12)
+    fg = GaussianFactorGraph()
+    fg.add(JacobianFactor(1, [[2, 4], [2, 1]], 2, [[2, 4], [2, 4]], [3.0, 4.0], noiseModel.Constrained.All(2)))
+    fg.add(JacobianFactor(2, np.eye(2), [0.0, 0.0], noiseModel.Unit.Create(2)))   # (so that the graph can be solved)
+    be = orc.oracle_backend(fg.to_arrays())
+    be.set_ordering([1, 2])
+    be.linearize()
+    be.solve(0.0, False)
+    # (the unit prior joins the clique: the first two rows of its conditional are the constraint's.  GaussianConditional::
+    #  equals compares the rows of [R S] only, up to scale — gtsam/linear/GaussianConditional.cpp:132-169 — so d is not
+    #  part of the golden; NoiseModel QRNan above pins the same elimination with its right-hand side.)
+    _linear_dependent_rows([[1, 2, 1, 2], [0, 1, 0, 0]], be.conditional(0)[:2, :4], 1e-9)
+
+
+_X_, _Y_, _Z_ = 0, 1, 2   # tests/smallExample.h: _x_ = 0, _y_ = 1, _z_ = 2
+
+
+def constrained_linear_graphs():
+    """createSimpleConstraintGraph / createSingleConstraintGraph / createMultiConstraintGraph with their solutions
+    (tests/smallExample.h:471-607), solved by tests/testGaussianFactorGraphB.cpp:300-340."""
+    s01 = noiseModel.Isotropic.Sigma(2, 0.1)
+    con = noiseModel.Constrained.All(2)
+    I = np.eye(2)
+    simple = GaussianFactorGraph()
+    simple.add(JacobianFactor(_X_, I, [1.0, -1.0], s01))
+    simple.add(JacobianFactor(_X_, I, _Y_, -I, [0.0, 0.0], con))
+    single = GaussianFactorGraph()
+    single.add(JacobianFactor(_X_, I, [1.0, -1.0], s01))
+    single.add(JacobianFactor(_X_, [[1, 2], [2, 1]], _Y_, 10 * I, [1.0, 2.0], con))
+    multi = GaussianFactorGraph()
+    multi.add(JacobianFactor(_X_, I, [-2.0, 2.0], s01))
+    multi.add(JacobianFactor(_X_, [[1, 2], [2, 1]], _Y_, 10 * I, [1.0, 2.0], con))
+    multi.add(JacobianFactor(_X_, [[3, 4], [-1, -2]], _Z_, [[1, 1], [1, 2]], [3.0, 4.0], con))
+    return [("simple", simple, {_X_: [1.0, -1.0], _Y_: [1.0, -1.0]}),
+            ("single", single, {_X_: [1.0, -1.0], _Y_: [0.2, 0.1]}),
+            ("multi", multi, {_X_: [-2.0, 2.0], _Y_: [-0.1, 0.4], _Z_: [-4.0, 5.0]})]
+
+
+def constrained_linear_check(backend_factory):
+    import itertools
+    for name, fg, expected in constrained_linear_graphs():
+        for ordering in itertools.permutations(sorted(expected)):
+            actual = fg.optimize(list(ordering), backend_factory=backend_factory)
+            for k, v in expected.items():
+                assert np.allclose(actual[k], v, atol=1e-9), (name, ordering, k, actual[k], v)
+
+
+def test_GaussianFactorGraph_constrained(orc):
+    constrained_linear_check(orc.oracle_backend)
