@@ -97,7 +97,8 @@ class Stats(C.Structure):
                                      "ms_linear_error", "ms_retract", "ms_error")]
         + [(n, C.c_int64) for n in ("n_linearize", "n_factorize", "n_backsolve", "n_error", "n_cheirality")]
         + [("amalgamation_relax", C.c_double), ("amalgamation_max_frontal_dim", C.c_int64),
-           ("n_medium_fronts", C.c_int64), ("n_tree_fronts", C.c_int64), ("n_upper_levels", C.c_int64)]
+           ("n_medium_fronts", C.c_int64), ("n_tree_fronts", C.c_int64), ("n_upper_levels", C.c_int64),
+           ("n_constraint_rows", C.c_int64), ("n_constrained_fronts", C.c_int64)]
     )
 
     def as_dict(self):

@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "libgsx.so")
-SOURCES = ["problem.cpp", "ordering.cpp", "nd.cpp", "symbolic.cpp", "io.cpp", "lm_policy.cpp", "kernels.hip", "bigfront.hip", "solver.hip"]
+SOURCES = ["problem.cpp", "ordering.cpp", "nd.cpp", "symbolic.cpp", "io.cpp", "lm_policy.cpp", "kernels.hip", "bigfront.hip", "constraint.hip", "solver.hip"]
 HEADERS = ["gsx_internal.h", "kernels.h", "device_geometry.h", os.path.join("..", "..", "include", "gsx.h")]
 
 

@@ -33,6 +33,10 @@ struct HostProblem {
   std::vector<int64_t> f_meas_ptr, f_noise_ptr, f_jac_off;
   std::vector<double> meas, noise;
   std::vector<int> f_cols;           // sum d + 1
+  // hard-constraint rows (zero sigma), by (factor, row) in graph order, with the weight mu of the error functions; on the
+  // device they are rows of sigma 1 / sqrt(mu) (problem.cpp) that the factorization eliminates by constraint pivots
+  std::vector<int> con_factor, con_row;
+  std::vector<double> con_mu;
 };
 
 // Symbolic factorization for one ordering.
@@ -126,6 +130,24 @@ struct Symbolic {
   // for partial re-elimination (gsx_relinearize_partial): variable -> factors CSR, gather task -> destination front
   std::vector<int> vf_ptr, vf;
   std::vector<int> gt_front;
+  // HARD CONSTRAINTS (HostProblem::con_*; EliminatePreferCholesky -> EliminateQR, HessianFactor.cpp:538-551,
+  // Constrained::QR, NoiseModel.cpp:503-620).  A constraint row lives in the front where the first-eliminated variable of
+  // its factor is frontal; there it is used as a PIVOT (one frontal scalar expressed by the others — no Cholesky step for
+  // it), or, when the front has fewer frontal scalars than rows, handed to the parent.  A front that takes rows in is
+  // always BLOCKED (cls 2): its assembled panel is in the arena, where the constraint kernels rewrite it into an
+  // unconstrained front with the same conditionals and the same Schur complement (solver.hip: constraint_*).
+  std::vector<char> con;               // front -> takes constraint rows in
+  std::vector<int> con_fronts;         // those fronts, children before parents
+  std::vector<int> con_index;          // front -> index in con_fronts, -1
+  std::vector<int> con_in, con_fwd;    // per constrained front: rows in (own + the children's), rows handed to the parent
+  std::vector<int> con_own_ptr;        // constrained front -> its own rows (CSR into con_own_*)
+  std::vector<int64_t> con_own_jac;    // own row -> offset of its first entry in the Jacobian store ([A b] + row)
+  std::vector<int> con_own_m;          // ... rows of its factor (the column stride)
+  std::vector<int> con_own_col_ptr;    // own row -> range in con_own_cols (size + 1)
+  std::vector<int> con_own_cols;       // per column of the factor's [A b]: the front's row (n - 1: the rhs)
+  std::vector<int> con_child_ptr, con_child;  // constrained front -> the constrained fronts below it whose leftover rows arrive here
+  std::vector<int> con_fwd_map_ptr, con_fwd_map;  // constrained front -> per separator + rhs row: the row of the front its
+                                                  // leftover rows go to (-1: a variable none of them holds)
   // sharding of ONE problem over the GPUs of a node (gsx_set_shard): the fronts whose subtree is cheaper than a share of
   // the whole tree form independent subtrees dealt to the ranks; the rest — the top of the tree, the "cap" — is
   // assembled from every rank's contributions with one all-reduce and factored by all ranks alike.

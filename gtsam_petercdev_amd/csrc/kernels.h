@@ -285,6 +285,33 @@ void launch_marginal_path(const DevSymbolic& S, const int* path, int npath, int 
                           double* out, double* Y, int64_t n_tan, hipStream_t st);
 void launch_joint_cross(const double* Ya, const double* Yb, int64_t n_tan, int dA, int dB, double* out, hipStream_t st);
 void launch_set_scalar(double* scalars, int slot, double v, hipStream_t st);
+// Hard constraints (constraint.hip): one record per constrained front (Symbolic::con_fronts order, children first)
+struct ConDesc {
+  i64 off;          // arena offset of the front's n x n panel
+  i64 work, fwd;    // doubles into the work buffer: 3 K n for the rows / B / Z; n_fwd (n - F) rows handed to the parent
+  i64 iwork;        // ints into the int work buffer: n + 2 K + 1
+  int N, F, K, n_fwd;
+  int own_begin, own_end;      // its own rows (ConTables::own_*)
+  int child_begin, child_end;  // ConTables::child_list: the fronts below whose leftover rows arrive here
+  int front;
+  int fwd_map;                 // ConTables::fwd_map + this: per separator + rhs row, the row of the front its leftovers go to
+};
+struct ConTables {
+  const ConDesc* descs;
+  const int *own_col_ptr, *own_cols, *own_m;
+  const i64* own_jac;
+  const int* child_list;
+  const int* fwd_map;
+  double* work;
+  int* iwork;
+};
+// the constrained fronts descs[first .. first + count), all of one level, after their gather and before their factorization
+void launch_constraint_fronts(const DevSymbolic& S, const ConTables& T, int first, int count, int max_n, const double* jac,
+                              double* arena, DevStatus* status, hipStream_t st);
+// hdiag[tan[i]] -= sum over k in ptr[i] .. ptr[i + 1] of w[k] jac[jidx[k]]^2 (the constraint rows' share of diag(J'J) at
+// the reference's weight)
+void launch_constraint_hdiag(int n, const int* tan, const int* ptr, const i64* jidx, const double* w, const double* jac,
+                             double* hdiag, hipStream_t st);
 constexpr int kTreeCursors = 8;  // cursors of the tree kernels' start lists, zeroed with the status words
 void launch_begin_factorization(double* scalars, double lambda, DevStatus* status, int* tree_cursors, hipStream_t st);
 // dense unit kernel for gsx_cholesky_partial: in-place lower partial Cholesky of an n x n

@@ -23,6 +23,9 @@ gsx_status lower_problem(const gsx_problem_desc* d, HostProblem& P, std::string&
   }
   P.n_vars = d->n_vars;
   P.n_factors = d->n_factors;
+  P.con_factor.clear();
+  P.con_row.clear();
+  P.con_mu.clear();
   P.keys.assign(d->var_keys, d->var_keys + d->n_vars);
   P.types.assign(d->var_types, d->var_types + d->n_vars);
   P.dims.assign(d->var_dims, d->var_dims + d->n_vars);
@@ -115,19 +118,31 @@ gsx_status lower_problem(const gsx_problem_desc* d, HostProblem& P, std::string&
         case GSX_NOISE_ISOTROPIC: ok = ok && nnoise == 1 + extra; break;
         case GSX_NOISE_DIAGONAL: ok = ok && nnoise == m + extra; break;
         case GSX_NOISE_GAUSSIAN: ok = ok && nnoise == (int64_t)m * m + extra; break;
+        case GSX_NOISE_CONSTRAINED: ok = ok && nnoise == 2 * (int64_t)m && !loss; break;
         default: ok = false;
       }
       if (loss && ok) ok = P.noise[P.f_noise_ptr[f + 1] - 1] > 0;
-      // a zero sigma is the reference's noiseModel::Constrained (NoiseModel.h:389-500): it needs the QR / constrained
-      // elimination path, which is not built — refused here instead of turning into infinities later
-      if (ok && ((kind & GSX_NOISE_BASE_MASK) == GSX_NOISE_ISOTROPIC || (kind & GSX_NOISE_BASE_MASK) == GSX_NOISE_DIAGONAL)) {
-        const int64_t ns = (kind & GSX_NOISE_BASE_MASK) == GSX_NOISE_ISOTROPIC ? 1 : m;
+      const int base = kind & GSX_NOISE_BASE_MASK;
+      if (ok && (base == GSX_NOISE_ISOTROPIC || base == GSX_NOISE_DIAGONAL || base == GSX_NOISE_CONSTRAINED)) {
+        const int64_t ns = base == GSX_NOISE_ISOTROPIC ? 1 : m;
         for (int64_t k = 0; k < ns; ++k) {
           const double sg = P.noise[P.f_noise_ptr[f] + k];
-          if (!(sg > 0) || !std::isfinite(sg)) {
+          // a sigma of exactly 0 in a diagonal model is a hard-constraint row (noiseModel::Constrained, NoiseModel.h:389-500)
+          const bool constraint = sg == 0.0 && base != GSX_NOISE_ISOTROPIC && !loss;
+          if (!constraint && (!(sg > 0) || !std::isfinite(sg))) {
             err = "factor " + std::to_string(f) + ": sigma " + std::to_string(sg) +
-                  " — constrained (zero-sigma) noise models need QR elimination, which this backend does not implement";
+                  " (a hard constraint is a sigma of exactly 0 in a GSX_NOISE_DIAGONAL / GSX_NOISE_CONSTRAINED model)";
             return GSX_E_INVALID;
+          }
+          if (constraint) {
+            const double mu = base == GSX_NOISE_CONSTRAINED ? P.noise[P.f_noise_ptr[f] + m + k] : 1000.0;
+            if (!(mu > 0) || !std::isfinite(mu)) {
+              err = "factor " + std::to_string(f) + ": constraint weight mu " + std::to_string(mu);
+              return GSX_E_INVALID;
+            }
+            P.con_factor.push_back(f);
+            P.con_row.push_back((int)k);
+            P.con_mu.push_back(mu);
           }
         }
       }
@@ -141,6 +156,38 @@ gsx_status lower_problem(const gsx_problem_desc* d, HostProblem& P, std::string&
     P.jac_size += (int64_t)m * cols;
   }
   P.f_jac_off[nf] = P.jac_size;
+  // Hard-constraint rows on the device: a DIAGONAL model whose constraint rows carry sigma = 1 / sqrt(mu).  Every kernel
+  // then treats them as ordinary rows — the graph error gets mu e^2 / 2 for a violated constraint
+  // (Constrained::squaredMahalanobisDistance, NoiseModel.cpp:438-444), the linearized error likewise
+  // (JacobianFactor::error with the unit() model, JacobianFactor.cpp:508-513), and J'J a penalty term that is constant on
+  // the feasible set — and the factorization eliminates the rows EXACTLY by constraint pivots (solver.hip: constraint_*).
+  if (!P.con_factor.empty() || std::find(P.f_noise_kind.begin(), P.f_noise_kind.end(), (int)GSX_NOISE_CONSTRAINED) !=
+                                   P.f_noise_kind.end()) {
+    std::vector<double> noise;
+    std::vector<int64_t> ptr(nf + 1, 0);
+    size_t ci = 0;
+    for (int f = 0; f < nf; ++f) {
+      const int base = P.f_noise_kind[f] & GSX_NOISE_BASE_MASK, m = P.f_rows[f];
+      const int64_t b = P.f_noise_ptr[f], e = P.f_noise_ptr[f + 1];
+      ptr[f] = (int64_t)noise.size();
+      if (base == GSX_NOISE_DIAGONAL || base == GSX_NOISE_CONSTRAINED) {
+        for (int k = 0; k < m; ++k) {
+          double sg = P.noise[b + k];
+          if (ci < P.con_factor.size() && P.con_factor[ci] == f && P.con_row[ci] == k) sg = 1.0 / std::sqrt(P.con_mu[ci++]);
+          noise.push_back(sg);
+        }
+        if (base == GSX_NOISE_DIAGONAL)
+          for (int64_t k = b + m; k < e; ++k) noise.push_back(P.noise[k]);   // (a robust model's parameter)
+        else
+          P.f_noise_kind[f] = GSX_NOISE_DIAGONAL;
+      } else {
+        noise.insert(noise.end(), P.noise.begin() + b, P.noise.begin() + e);
+      }
+    }
+    ptr[nf] = (int64_t)noise.size();
+    P.noise.swap(noise);
+    P.f_noise_ptr.swap(ptr);
+  }
   return GSX_OK;
 }
 

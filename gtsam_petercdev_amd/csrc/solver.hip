@@ -160,6 +160,23 @@ struct gsx_context {
   DevBuf<double> d_gscratch;
   GatherArgs GA{};
   std::vector<BigLevel> big_level;
+  // hard constraints (Symbolic::con_*, constraint.hip): descs in (upper level, front) order
+  struct ConLevel {
+    int first = 0, count = 0, max_n = 0;
+  };
+  std::vector<ConLevel> con_level;      // per upper level
+  std::vector<int> con_desc_of_front;   // front -> its record, -1
+  DevBuf<ConDesc> d_con_descs;
+  DevBuf<int> d_con_own_col_ptr, d_con_own_cols, d_con_own_m, d_con_child, d_con_fwd_map, d_con_iwork;
+  DevBuf<i64> d_con_own_jac;
+  DevBuf<double> d_con_work;
+  ConTables CT{};
+  // the constraint rows' entries by tangent scalar (constraint_hdiag_kernel): built with the problem tables
+  int con_hd_n = 0;
+  DevBuf<int> d_con_hd_tan, d_con_hd_ptr;
+  DevBuf<i64> d_con_hd_jidx;
+  DevBuf<double> d_con_hd_w;
+  bool constrained() const { return !S.con_fronts.empty(); }
   std::vector<BigDesc> big_descs;
   int big_max_n = 0, big_max_nfv = 0;
   struct HGroup {
@@ -368,6 +385,40 @@ gsx_status upload_problem(gsx_context* c) {
   }
   HIPCHK(c, c->d_meas.upload(P.meas, st));
   HIPCHK(c, c->d_noise.upload(P.noise, st));
+  c->con_hd_n = 0;
+  if (!P.con_factor.empty()) {
+    struct E {
+      int tan;
+      i64 jidx;
+      double w;
+    };
+    std::vector<E> es;
+    for (size_t i = 0; i < P.con_factor.size(); ++i) {
+      const int f = P.con_factor[i], m = P.f_rows[f];
+      int col = 0;
+      for (int q = P.f_key_ptr[f]; q < P.f_key_ptr[f + 1]; ++q)
+        for (int d = 0; d < P.dims[P.f_vars[q]]; ++d, ++col)
+          es.push_back(E{P.tan_off[P.f_vars[q]] + d, P.f_jac_off[f] + (i64)col * m + P.con_row[i], 1.0 - 1.0 / P.con_mu[i]});
+    }
+    std::stable_sort(es.begin(), es.end(), [](const E& a, const E& b) { return a.tan < b.tan; });
+    std::vector<int> tan, ptr;
+    std::vector<i64> jidx;
+    std::vector<double> w;
+    for (const E& e : es) {
+      if (tan.empty() || tan.back() != e.tan) {
+        tan.push_back(e.tan);
+        ptr.push_back((int)jidx.size());
+      }
+      jidx.push_back(e.jidx);
+      w.push_back(e.w);
+    }
+    ptr.push_back((int)jidx.size());
+    c->con_hd_n = (int)tan.size();
+    HIPCHK(c, c->d_con_hd_tan.upload(tan, st));
+    HIPCHK(c, c->d_con_hd_ptr.upload(ptr, st));
+    HIPCHK(c, c->d_con_hd_jidx.upload(jidx, st));
+    HIPCHK(c, c->d_con_hd_w.upload(w, st));
+  }
   gsx_status fl = upload_factor_lists(c, nullptr);
   if (fl != GSX_OK) return fl;
   HIPCHK(c, c->d_values.alloc(std::max<int64_t>(P.state_size, 1)));
@@ -788,6 +839,65 @@ gsx_status upload_symbolic(gsx_context* c) {
   }
   HIPCHK(c, c->d_usched.upload(S.usched, st));
   HIPCHK(c, c->d_rest_ids.upload(rest_ids, st));
+  // ---- hard constraints: the constrained fronts by upper level, their rows and work areas ----
+  c->con_level.assign(S.n_ulevels, gsx_context::ConLevel());
+  c->con_desc_of_front.assign(S.n_fronts, -1);
+  c->CT = ConTables{};
+  if (!S.con_fronts.empty()) {
+    const int nc = (int)S.con_fronts.size();
+    std::vector<int> perm(nc);   // desc position -> index in S.con_fronts
+    for (int k = 0; k < nc; ++k) perm[k] = k;
+    std::stable_sort(perm.begin(), perm.end(),
+                     [&](int a, int b) { return S.ulevel[S.con_fronts[a]] < S.ulevel[S.con_fronts[b]]; });
+    std::vector<int> where(nc);
+    for (int k = 0; k < nc; ++k) where[perm[k]] = k;
+    std::vector<ConDesc> descs(nc);
+    std::vector<int> child_list;
+    i64 work = 0, iwork = 0;
+    for (int k = 0; k < nc; ++k) {
+      const int q = perm[k], f = S.con_fronts[q], l = S.ulevel[f];
+      ConDesc& d = descs[k];
+      d.off = S.off[f];
+      d.N = S.N[f];
+      d.F = S.F[f];
+      d.K = S.con_in[q];
+      d.n_fwd = S.con_fwd[q];
+      d.work = work;
+      work += 3 * (i64)d.K * d.N;
+      d.fwd = work;
+      work += (i64)d.n_fwd * (d.N - d.F);
+      d.iwork = iwork;
+      iwork += d.N + 2 * d.K + 1;
+      d.own_begin = S.con_own_ptr[q];
+      d.own_end = S.con_own_ptr[q + 1];
+      d.child_begin = (int)child_list.size();
+      for (int e = S.con_child_ptr[q]; e < S.con_child_ptr[q + 1]; ++e) child_list.push_back(where[S.con_child[e]]);
+      d.child_end = (int)child_list.size();
+      d.front = f;
+      d.fwd_map = S.con_fwd_map_ptr[q];
+      c->con_desc_of_front[f] = k;
+      gsx_context::ConLevel& L = c->con_level[l];
+      if (!L.count) L.first = k;
+      L.count++;
+      L.max_n = std::max(L.max_n, d.N);
+    }
+    if (child_list.empty()) child_list.push_back(0);
+    HIPCHK(c, c->d_con_descs.upload(descs, st));
+    HIPCHK(c, c->d_con_own_col_ptr.upload(S.con_own_col_ptr, st));
+    HIPCHK(c, c->d_con_own_cols.upload(S.con_own_cols, st));
+    HIPCHK(c, c->d_con_own_m.upload(S.con_own_m, st));
+    std::vector<i64> oj(S.con_own_jac.begin(), S.con_own_jac.end());
+    if (oj.empty()) oj.push_back(0);
+    HIPCHK(c, c->d_con_own_jac.upload(oj, st));
+    HIPCHK(c, c->d_con_child.upload(child_list, st));
+    std::vector<int> fmap = S.con_fwd_map;
+    if (fmap.empty()) fmap.push_back(-1);
+    HIPCHK(c, c->d_con_fwd_map.upload(fmap, st));
+    HIPCHK(c, c->d_con_work.alloc(std::max<i64>(work, 1)));
+    HIPCHK(c, c->d_con_iwork.alloc(std::max<i64>(iwork, 1)));
+    c->CT = ConTables{c->d_con_descs.p, c->d_con_own_col_ptr.p, c->d_con_own_cols.p, c->d_con_own_m.p, c->d_con_own_jac.p,
+                      c->d_con_child.p, c->d_con_fwd_map.p, c->d_con_work.p, c->d_con_iwork.p};
+  }
   {
     c->tree_tiers.clear();
     const int nb = (int)S.tree_bounds.size();
@@ -985,6 +1095,9 @@ void dev_assemble_h(gsx_context* c) {
 void dev_hessian_diag(gsx_context* c) {
   if (c->hdiag_ready) return;
   launch_hessian_diag(c->DP, c->DS, c->d_H.p, c->d_hdiag.p, c->stream);
+  if (c->con_hd_n)
+    launch_constraint_hdiag(c->con_hd_n, c->d_con_hd_tan.p, c->d_con_hd_ptr.p, c->d_con_hd_jidx.p, c->d_con_hd_w.p,
+                            c->d_jac.p, c->d_hdiag.p, c->stream);
   if (c->sharded()) {
     // a subtree variable's diagonal lives on its owner, a cap variable's is the sum of every rank's terms
     launch_mask_copy(c->d_hdiag.p, c->d_sched_tan.p, c->P.tan_size, c->d_hdiag.p, c->stream);
@@ -1149,6 +1262,11 @@ void dev_factorize(gsx_context* c, double lambda) {
       // sharded: every rank's share of the cap (H terms, damping, its subtrees' Schur complements) is in; their sum
       // is the assembled cap, which all ranks now factor alike
       if (l == S.cap_ulevel0) shard_allreduce(c, c->d_arena.p + S.cap_begin, S.cap_end - S.cap_begin);
+      // hard constraints: the assembled fronts that hold constraint rows become unconstrained fronts with the same
+      // conditionals and Schur complement (constraint.hip)
+      if (c->con_level[l].count)
+        launch_constraint_fronts(c->DS, c->CT, c->con_level[l].first, c->con_level[l].count, c->con_level[l].max_n,
+                                 c->d_jac.p, c->d_arena.p, c->d_status.p, c->stream);
       dev_big_factor(c, c->d_big.p + B.begin, B.count, B.plan, c->stream, prof);
       if (prof) timer_end(c, PH_FACTOR_BIG);
     }
@@ -1309,7 +1427,9 @@ void dev_backsolve(gsx_context* c, const WildfireArgs* wf = nullptr) {
 // come from the right-hand sides and the step (kernels.hip: lin0_kernel / model_error_kernel), no pass over [A b];
 // otherwise (an arbitrary point: Dogleg, gsx_linear_error) the direct evaluation
 void dev_linear_error(gsx_context* c, bool solved_step = false) {
-  static const bool direct_only = std::getenv("GSX_LINERR_DIRECT") != nullptr;
+  // (hard constraints: the step solves the KKT system, not (H + lambda D) delta = g — the identity below does not hold)
+  static const bool direct_env = std::getenv("GSX_LINERR_DIRECT") != nullptr;
+  const bool direct_only = direct_env || c->constrained();
   timer_begin(c, PH_LINERR);
   if (solved_step && !direct_only && c->h_ready) {
     if (!c->lin0_ready) {
@@ -2413,6 +2533,12 @@ gsx_status partial_factor(gsx_handle h, std::vector<int>& dfr) {
       if (L.big_count) {
         for (const LevelPlan::GroupPlan& G : L.groups)
           if (G.nseg) launch_big_gather(GA, G.seg0, G.nseg, G.m0, G.nm, h->d_arena.p, sm);
+        if (h->constrained())   // (the clean children's leftover rows are still in the work area)
+          for (int k = L.big_begin; k < L.big_begin + L.big_count; ++k) {
+            const int cd = h->con_desc_of_front[big[k].front];
+            if (cd >= 0)
+              launch_constraint_fronts(h->DS, h->CT, cd, 1, big[k].N, h->d_jac.p, h->d_arena.p, h->d_status.p, sm);
+          }
         dev_big_factor(h, ps.big.p + L.big_begin, L.big_count, L.big_plan, sm, false);
       }
     }
@@ -2787,6 +2913,11 @@ gsx_status gsx_joint_marginal_covariance(gsx_handle h, const uint64_t* keys, int
   gsx_status st = marginals_prepare(h);
   if (st != GSX_OK) return st;
   const Symbolic& S = h->S;
+  if (h->constrained()) {
+    // (the rewritten fronts give a constraint pivot unit variance where the reference's conditional has sigma 0)
+    h->err = "marginal covariances are not available on a problem with hard constraints";
+    return GSX_E_STATE;
+  }
   // column groups: a variable's unit columns go through the path kernel at most 16 at a time (fewer when the cliques on its
   // path to the root are tall: the kernel keeps two (rows x columns) panels in LDS) — Marginals.cpp:107-136 has no limit on
   // the dimension of a variable, and neither has this entry point
@@ -2866,6 +2997,10 @@ gsx_status gsx_marginal_covariance(gsx_handle h, uint64_t key, double* out, int6
   gsx_status st = marginals_prepare(h);
   if (st != GSX_OK) return st;
   const Symbolic& S = h->S;
+  if (h->constrained()) {
+    h->err = "marginal covariances are not available on a problem with hard constraints";
+    return GSX_E_STATE;
+  }
   std::vector<int> path;
   int max_n = 0;
   for (int f = S.front_of_var[v]; f >= 0; f = S.parent[f]) {
@@ -3102,11 +3237,13 @@ gsx_status gsx_get_stats(gsx_handle h, gsx_stats* out) {
       out->n_medium_fronts += S.med[f] && S.cls[f] == 1;
       out->n_tree_fronts += S.tree_tier[f] >= 0;
     }
+    out->n_constrained_fronts = (int64_t)S.con_fronts.size();
     out->factor_flops = S.flops;
     out->front_bytes = S.front_bytes;
     out->lpanel_bytes = S.lpanel_bytes;
     out->hessian_bytes = 8.0 * (double)S.h_size;
   }
+  out->n_constraint_rows = (int64_t)h->P.con_factor.size();
   out->jacobian_bytes = 8.0 * (double)h->P.jac_size;
   out->total_dim = (double)h->P.tan_size;
   if (h->has_device) {

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <algorithm>
+#include <iterator>
 #include <numeric>
 
 #include "gsx_internal.h"
@@ -477,6 +478,140 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
       const int o = first < 0 ? -1 : S.owner[S.front_of_var[first]];
       S.f_owned[f] = o < 0 ? S.shard_rank == 0 : o == S.shard_rank;  // (factors of cap variables only: rank 0)
     }
+  // ---- hard constraints: which fronts take constraint rows in, how many they hand on -------------------------------
+  S.con.assign(nfr, 0);
+  S.con_index.assign(nfr, -1);
+  S.con_fronts.clear();
+  S.con_in.clear();
+  S.con_fwd.clear();
+  S.con_own_ptr.assign(1, 0);
+  S.con_own_jac.clear();
+  S.con_own_m.clear();
+  S.con_own_col_ptr.assign(1, 0);
+  S.con_own_cols.clear();
+  S.con_child_ptr.assign(1, 0);
+  S.con_child.clear();
+  S.con_fwd_map_ptr.clear();
+  S.con_fwd_map.clear();
+  if (!P.con_factor.empty()) {
+    if (S.shard_world > 1) {
+      err = "hard constraints (zero-sigma rows) are not supported on a sharded handle";
+      return GSX_E_INVALID;
+    }
+    std::vector<std::vector<int>> own(nfr);  // front -> constraint rows (indices into P.con_*)
+    for (size_t i = 0; i < P.con_factor.size(); ++i) {
+      const int f = P.con_factor[i];
+      int first = -1;
+      for (int q = P.f_key_ptr[f]; q < P.f_key_ptr[f + 1]; ++q)
+        if (first < 0 || S.pos[P.f_vars[q]] < S.pos[first]) first = P.f_vars[q];
+      own[S.front_of_var[first]].push_back((int)i);
+    }
+    // Symbolic pass, children before parents.  A row is a set of variables; in a front the frontal variables are taken
+    // in order: of the rows that hold the variable, as many as it has scalars become pivots (generic rank), the others
+    // take the union of those rows' variables without it.  What is left goes — all rows of the front together, each with
+    // the union of their variables — to the front where the first of those variables is frontal: an ancestor whose front
+    // holds all of them (they are a clique of the filled graph), possibly far up; the fronts in between never see the rows
+    // (Constrained::QR leaves a row without an entry in the column alone, NoiseModel.cpp:566-590).
+    struct Arrival {
+      int src;                 // constrained-front index of the sender
+      int rows;
+      std::vector<int> vars;   // sorted by position
+    };
+    std::vector<std::vector<Arrival>> arrive(nfr);
+    std::vector<int> loc(n, -1);
+    for (int f = 0; f < nfr; ++f) {  // children have smaller ids
+      if (own[f].empty() && arrive[f].empty()) continue;
+      std::vector<std::vector<int>> rows;   // variable sets (by position order)
+      for (int i : own[f]) {
+        const int fac = P.con_factor[i];
+        std::vector<int> vs(P.f_vars.begin() + P.f_key_ptr[fac], P.f_vars.begin() + P.f_key_ptr[fac + 1]);
+        std::sort(vs.begin(), vs.end(), [&](int a, int b) { return S.pos[a] < S.pos[b]; });
+        rows.push_back(std::move(vs));
+      }
+      for (const Arrival& a : arrive[f])
+        for (int r = 0; r < a.rows; ++r) rows.push_back(a.vars);
+      const int in = (int)rows.size();
+      if (in > 1024) {
+        err = "more than 1024 hard-constraint rows meet in one clique";
+        return GSX_E_INVALID;
+      }
+      std::vector<char> used(in, 0);
+      auto by_pos = [&](int a, int b) { return S.pos[a] < S.pos[b]; };
+      for (int k = 0; k < nfv[f]; ++k) {
+        const int v = S.fvars[S.fvar_ptr[f] + k];
+        std::vector<int> touching, uni;
+        for (int r = 0; r < in; ++r)
+          if (!used[r] && std::binary_search(rows[r].begin(), rows[r].end(), v, by_pos)) {
+            touching.push_back(r);
+            std::vector<int> tmp;
+            std::set_union(uni.begin(), uni.end(), rows[r].begin(), rows[r].end(), std::back_inserter(tmp), by_pos);
+            uni.swap(tmp);
+          }
+        if (touching.empty()) continue;
+        uni.erase(std::lower_bound(uni.begin(), uni.end(), v, by_pos));
+        const int t = std::min<int>((int)touching.size(), P.dims[v]);
+        for (int q = 0; q < (int)touching.size(); ++q) {
+          if (q < t) used[touching[q]] = 1;
+          else rows[touching[q]] = uni;
+        }
+      }
+      int fwd = 0;
+      std::vector<int> uni;
+      for (int r = 0; r < in; ++r) {
+        if (used[r] || rows[r].empty()) continue;   // (an empty row says 0 = d: nothing left to enforce)
+        ++fwd;
+        std::vector<int> tmp;
+        std::set_union(uni.begin(), uni.end(), rows[r].begin(), rows[r].end(), std::back_inserter(tmp), by_pos);
+        uni.swap(tmp);
+      }
+      const int me = (int)S.con_fronts.size();
+      S.con[f] = 1;
+      S.con_index[f] = me;
+      S.con_fronts.push_back(f);
+      S.con_in.push_back(in);
+      S.con_fwd.push_back(fwd);
+      int o = 0;
+      for (int k = S.fvar_ptr[f]; k < S.fvar_ptr[f + 1]; ++k) {
+        loc[S.fvars[k]] = o;
+        o += P.dims[S.fvars[k]];
+      }
+      for (int i : own[f]) {
+        const int fac = P.con_factor[i];
+        S.con_own_jac.push_back(P.f_jac_off[fac] + P.con_row[i]);
+        S.con_own_m.push_back(P.f_rows[fac]);
+        for (int q = P.f_key_ptr[fac]; q < P.f_key_ptr[fac + 1]; ++q)
+          for (int d = 0; d < P.dims[P.f_vars[q]]; ++d) S.con_own_cols.push_back(loc[P.f_vars[q]] + d);
+        S.con_own_cols.push_back(S.N[f] - 1);
+        S.con_own_col_ptr.push_back((int)S.con_own_cols.size());
+      }
+      S.con_own_ptr.push_back((int)S.con_own_jac.size());
+      for (const Arrival& a : arrive[f]) S.con_child.push_back(a.src);
+      S.con_child_ptr.push_back((int)S.con_child.size());
+      // where the leftover rows go, and the map of this front's separator + rhs rows into that front's rows
+      S.con_fwd_map_ptr.push_back((int)S.con_fwd_map.size());
+      if (fwd > 0) {
+        const int dest = S.front_of_var[uni.front()];
+        arrive[dest].push_back(Arrival{me, fwd, uni});
+        std::vector<int> dloc(0);
+        int od = 0;
+        std::vector<std::pair<int, int>> dvars;   // (variable, offset) of the destination front
+        for (int k = S.fvar_ptr[dest]; k < S.fvar_ptr[dest + 1]; ++k) {
+          dvars.push_back({S.fvars[k], od});
+          od += P.dims[S.fvars[k]];
+        }
+        for (int k = S.fvar_ptr[f] + nfv[f]; k < S.fvar_ptr[f + 1]; ++k) {
+          const int u = S.fvars[k];
+          int at = -1;
+          if (std::binary_search(uni.begin(), uni.end(), u, by_pos))
+            for (const auto& dv : dvars)
+              if (dv.first == u) at = dv.second;
+          for (int d = 0; d < P.dims[u]; ++d) S.con_fwd_map.push_back(at < 0 ? -1 : at + d);
+        }
+        S.con_fwd_map.push_back(S.N[dest] - 1);   // the rhs
+      }
+    }
+    S.con_fwd_map_ptr.push_back((int)S.con_fwd_map.size());
+  }
   // Size class of a front: 0 = leaf kernel (no children, few frontal scalars: only the n x F panel lives in LDS),
   // 1 = small (whole front in LDS), 2 = big (blocked path in HBM; every cap front, whatever its size, because its
   // assembled state must exist in HBM for the exchange).  A leaf is LEAN when its parent is big and every
@@ -493,7 +628,7 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
   // 1.65 -> 1.99 ms with the medium tier on.
   const bool med_off = std::getenv("GSX_MEDIUM") == nullptr;
   for (int f = 0; f < nfr; ++f) {   // medium fronts first: a leaf's leanness depends on its parent's class
-    if (cap[f] || S.N[f] <= kSmallMaxN || S.N[f] > kMedMaxN || (int64_t)S.N[f] * S.F[f] > kMedMaxPanel || med_off) continue;
+    if (cap[f] || S.con[f] || S.N[f] <= kSmallMaxN || S.N[f] > kMedMaxN || (int64_t)S.N[f] * S.F[f] > kMedMaxPanel || med_off) continue;
     int leaf_kids = 0;
     for (int c = S.child_ptr[f]; c < S.child_ptr[f + 1]; ++c) {
       const int ch = S.children[c];
@@ -506,13 +641,14 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
   for (int f = 0; f < nfr; ++f) {
     const bool childless = S.child_ptr[f + 1] == S.child_ptr[f];
     const int par = S.parent[f];
-    bool lean = !cap[f] && childless && S.F[f] <= kLeafMaxF && S.F[f] > 0 && par >= 0 &&
-                ((S.N[par] > kSmallMaxN && !S.med[par]) || cap[par]) && (int64_t)S.N[f] * S.F[f] <= kLeafMaxPanel;
+    bool lean = !cap[f] && !S.con[f] && childless && S.F[f] <= kLeafMaxF && S.F[f] > 0 && par >= 0 &&
+                ((S.N[par] > kSmallMaxN && !S.med[par]) || cap[par] || S.con[par]) &&
+                (int64_t)S.N[f] * S.F[f] <= kLeafMaxPanel;
     if (lean)
       for (int k = S.fvar_ptr[f] + nfv[f]; k < S.fvar_ptr[f + 1]; ++k) lean = lean && P.dims[S.fvars[k]] <= 16;
     S.lean[f] = lean;
     if (lean) S.cls[f] = 0;
-    else if ((S.N[f] > kSmallMaxN && !S.med[f]) || cap[f]) S.cls[f] = 2;
+    else if ((S.N[f] > kSmallMaxN && !S.med[f]) || cap[f] || S.con[f]) S.cls[f] = 2;
     else if (childless && S.F[f] <= kLeafMaxF) S.cls[f] = 0;
     if (S.cls[f] == 2) S.n_big++; else S.n_small++;
     int64_t sz = lean ? (int64_t)S.N[f] * S.F[f] : (int64_t)S.N[f] * S.N[f];

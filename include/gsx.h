@@ -235,6 +235,8 @@ typedef struct gsx_stats {
   int64_t n_medium_fronts;       /* of the LDS fronts: frontal panel in LDS, trailing block in HBM */
   int64_t n_tree_fronts;         /* fronts eliminated dependency-driven, one launch per tier, instead of level by level */
   int64_t n_upper_levels;        /* launch rounds of the fronts that are neither: levelled among themselves (longest chain) */
+  int64_t n_constraint_rows;     /* hard-constraint (zero-sigma) rows of the graph */
+  int64_t n_constrained_fronts;  /* fronts that take constraint rows in (always blocked; constraint pivots before Cholesky) */
 } gsx_stats;
 
 /* ---- on-disk formats (host only) -------------------------
