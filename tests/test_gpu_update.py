@@ -42,7 +42,7 @@ def _scene(n_poses, n_points, seed):
     return rng, K, pts, poses
 
 
-def _grow(n_poses=9, n_points=60, seed=21, visible=0.55):
+def _grow(n_poses=9, n_points=60, seed=21, visible=0.55, hard_prior=False):
     """Yields (factors, values-dict) after each keyframe: factor objects are appended, so a factor keeps its identity."""
     rng, K, pts, poses = _scene(n_poses, n_points, seed)
     noise = noiseModel.Isotropic.Sigma(2, 1.0)
@@ -51,7 +51,10 @@ def _grow(n_poses=9, n_points=60, seed=21, visible=0.55):
     for i, (R, t) in enumerate(poses):
         init[X(i)] = Pose3(Rot3(R), Point3(*(t + rng.normal(0, 0.05, 3))))
         if i == 0:
-            factors.append(PriorFactor(X(0), Pose3(Rot3(R), Point3(*t)), noiseModel.Diagonal.Sigmas([0.1] * 3 + [0.3] * 3)))
+            # (hard_prior: the first pose is KNOWN — noiseModel::Constrained::All(6), a clique with constraint pivots)
+            factors.append(PriorFactor(X(0), Pose3(Rot3(R), Point3(*t)),
+                                       noiseModel.Constrained.All(6) if hard_prior
+                                       else noiseModel.Diagonal.Sigmas([0.1] * 3 + [0.3] * 3)))
         else:
             Rp, tp = poses[i - 1]
             factors.append(BetweenFactor(X(i - 1), X(i), Pose3(Rot3(Rp.T @ R), Point3(*(Rp.T @ (t - tp)))), odo))
@@ -87,8 +90,9 @@ def _new_states(arr, old_keys):
                           or [np.zeros(0)])
 
 
-def test_grow_keyframe_by_keyframe_matches_fresh_handles_and_the_batch_optimum(gpu, oracle):
-    steps = list(_grow())
+@pytest.mark.parametrize("hard_prior", [False, True])
+def test_grow_keyframe_by_keyframe_matches_fresh_handles_and_the_batch_optimum(gpu, oracle, hard_prior):
+    steps = list(_grow(hard_prior=hard_prior))
     cur_factors, cur_init = steps[1]            # VisualISAM2Example starts its first update with two poses
     arr = _arrays(cur_factors, cur_init)
     gb = gpu.product_backend(arr)
@@ -96,6 +100,7 @@ def test_grow_keyframe_by_keyframe_matches_fresh_handles_and_the_batch_optimum(g
     gb.set_ordering(gb.compute_ordering(A.ORDER_SCHUR_ND))
     gb.linearize()
     gb.solve(0.0, False)
+    assert gb.stats()["n_constraint_rows"] == (6 if hard_prior else 0)
     p1 = A.lm_params_legacy()
     p1.max_iterations = 1
     dropped = None

@@ -157,16 +157,62 @@ def test_malformed_description_is_rejected(lib):
     assert ei.value.status == A.GSX_E_INVALID
 
 
-def test_constrained_noise_model_is_refused_not_turned_into_infinities(lib):
-    """A zero sigma is the reference's noiseModel::Constrained (gtsam/linear/NoiseModel.h:389-500), which eliminates through
-    QR (not built).  gsx_create must say so instead of whitening with 1/0."""
+def test_zero_sigmas_are_hard_constraints_or_refused(lib):
+    """A zero sigma in a DIAGONAL model is the reference's noiseModel::Constrained (gtsam/linear/NoiseModel.h:389-500,
+    Diagonal::Sigmas :292-309): accepted, counted, and its clique scheduled as a constrained (blocked) front.  A zero or
+    negative sigma anywhere else — an Isotropic model, a negative entry, a non-positive mu — is refused at gsx_create
+    instead of turning into infinities in the whitening."""
     arr = PROBLEMS["pose2"]()
-    f = next(i for i in range(arr.n_factors)
-             if (int(arr.f_noise_kind[i]) & A.NOISE_BASE_MASK) in (A.NOISE_ISOTROPIC, A.NOISE_DIAGONAL))
-    arr.noise[int(arr.f_noise_ptr[f])] = 0.0
+    prior = int(np.flatnonzero(arr.f_type == A.F_PRIOR)[0])
+    assert (int(arr.f_noise_kind[prior]) & A.NOISE_BASE_MASK) == A.NOISE_DIAGONAL
+    arr.noise[int(arr.f_noise_ptr[prior]):int(arr.f_noise_ptr[prior + 1])] = 0.0   # Constrained::All(3) on the first pose
+    pb = _lib.ProductBackend(arr, host_only=True)
+    pb.set_amalgamation(0.0, 128)
+    for kind in (A.ORDER_NATURAL, A.ORDER_MINDEGREE, A.ORDER_ND):
+        pb.set_ordering(pb.compute_ordering(kind))
+        st = pb.stats()
+        # three rows, all absorbed in the clique of the first pose: no other front is touched
+        assert st["n_constraint_rows"] == 3 and st["n_constrained_fronts"] == 1
+        _, fronts = pb.get_tree()
+        v0 = int(arr.f_vars[arr.f_key_ptr[prior]])
+        c = next(i for i, (fv, _) in enumerate(fronts) if v0 in fv)
+        assert pb.front_classes()[c] == 2
+    arr = PROBLEMS["bal"]() if "bal" in PROBLEMS else PROBLEMS[next(iter(PROBLEMS))]()
+    iso = [i for i in range(arr.n_factors) if (int(arr.f_noise_kind[i]) & A.NOISE_BASE_MASK) == A.NOISE_ISOTROPIC]
+    assert iso
+    arr.noise[int(arr.f_noise_ptr[iso[0]])] = 0.0
     with pytest.raises(gt.GsxError) as ei:
         _lib.ProductBackend(arr, host_only=True)
-    assert ei.value.status == A.GSX_E_INVALID   # (the reason goes to stderr: "constrained (zero-sigma) noise models need QR elimination")
+    assert ei.value.status == A.GSX_E_INVALID
+    arr = PROBLEMS["pose2"]()
+    arr.noise[int(arr.f_noise_ptr[prior])] = -1.0
+    with pytest.raises(gt.GsxError):
+        _lib.ProductBackend(arr, host_only=True)
+
+
+def test_leftover_constraint_rows_go_to_the_front_of_their_first_variable(lib):
+    """Scalar chain; a 2-row constraint on (x0, x5, x11): the clique of x0 has one frontal scalar, so one row is a pivot
+    there and the other waits for x5 — in the clique where x5 is frontal, not in every clique in between."""
+    from gtsam_petercdev_amd.graph import GaussianFactorGraph, JacobianFactor, noiseModel
+    n = 16
+    fg = GaussianFactorGraph()
+    one = np.eye(1)
+    for i in range(n):
+        fg.add(JacobianFactor(i, one, [0.0], noiseModel.Unit.Create(1)))
+    for i in range(n - 1):
+        fg.add(JacobianFactor(i, -one, i + 1, one, [1.0], noiseModel.Unit.Create(1)))
+    fg.add(JacobianFactor(0, [[1.0], [2.0]], 5, [[1.0], [-1.0]], 11, [[3.0], [1.0]], [1.0, 2.0], noiseModel.Constrained.All(2)))
+    arr = fg.to_arrays(None)
+    arr.values = np.zeros(n)
+    pb = _lib.ProductBackend(arr, host_only=True)
+    pb.set_amalgamation(0.0, 128)
+    pb.set_ordering(np.arange(n, dtype=np.uint64))
+    st = pb.stats()
+    assert st["n_constraint_rows"] == 2 and st["n_constrained_fronts"] == 2
+    _, fronts = pb.get_tree()
+    cls = pb.front_classes()
+    con = [i for i in range(len(fronts)) if cls[i] == 2]
+    assert len(con) == 2 and 0 in fronts[con[0]][0] and 5 in fronts[con[1]][0]
 
 
 def test_schur_ordering_puts_landmarks_first(lib):
