@@ -59,6 +59,9 @@ def parse():
                     help="N=1: skip the pose-graph anchor (pose3_100k ms/step, the N=1 point of the sharded curve) that is "
                          "measured after the headline workload's timed region")
     ap.add_argument("--lam", type=float, default=1e-5)
+    ap.add_argument("--hard-prior", action="store_true",
+                    help="pose graphs: the prior on the first pose becomes noiseModel::Constrained::All (zero sigmas) — its "
+                         "clique is eliminated with constraint pivots (constraint.hip); a measurement of that path, not the headline")
     ap.add_argument("--amalgamation", default=None, metavar="RELAX,MAXF",
                     help="relaxed clique amalgamation (gsx_set_amalgamation); default: the library's own choice "
                          "(GSX_AMALGAMATION_AUTO, what a drop-in caller gets), 0,128 = the reference's cliques")
@@ -359,6 +362,11 @@ def main():
     if args.workload is None:
         args.workload = "pose3_100k" if (sharded and world > 1) else "bal1723"
     arrays, default_order = make_problem(args.workload, seed=42 if sharded else D.replica_seed(42))
+    if args.hard_prior:
+        from gtsam_petercdev_amd import _abi as _A
+        pf = int(np.flatnonzero(arrays.f_type == _A.F_PRIOR)[0])
+        assert (int(arrays.f_noise_kind[pf]) & _A.NOISE_BASE_MASK) == _A.NOISE_DIAGONAL, "the prior needs a diagonal model"
+        arrays.noise[int(arrays.f_noise_ptr[pf]):int(arrays.f_noise_ptr[pf + 1])] = 0.0
     be = _lib.product_backend(arrays, device=device)
     exchange = {"calls": 0, "doubles": 0, "seconds": 0.0}
     exchange_path = None
@@ -512,7 +520,8 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
         "scaling": "strong" if (sharded and world > 1) else "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": args.workload, "shape": arrays.meta, "ordering": ordering_name,
+        "config": {"workload": args.workload + ("+hard_prior" if args.hard_prior else ""), "shape": arrays.meta,
+                   "ordering": ordering_name,
                    "amalgamation": {"relax": relax, "max_frontal_dim": relax_maxf,
                                     "chosen_by": "caller" if args.amalgamation is not None else "library"}, "lambda": lam,
                    "replicas": 1 if sharded else world,

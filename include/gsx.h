@@ -139,6 +139,22 @@ enum {
   GSX_NOISE_BASE_MASK = 15
 };
 
+/* ---- Hard constraints ------------------------------------------------------
+ * A row of sigma 0 (GSX_NOISE_DIAGONAL / GSX_NOISE_CONSTRAINED) is a hard constraint: the linear step satisfies
+ * A_row delta = b_row exactly.  The reference eliminates a clique that holds such a row with EliminateQR and
+ * Constrained::QR instead of Cholesky (gtsam/linear/HessianFactor.cpp:538-551, JacobianFactor.cpp:804-842,
+ * NoiseModel.cpp:503-620); this library turns the row into a pivot of its clique before the clique's Cholesky
+ * (csrc/constraint.hip) — the same step delta, the same LM trace.  What a caller sees:
+ *   - gsx_error / gsx_linear_error weigh a violated constraint row by mu, as Constrained::squaredMahalanobisDistance does
+ *     (NoiseModel.cpp:438-444; mu = 1000 for GSX_NOISE_DIAGONAL);
+ *   - gsx_get_jacobians returns a constraint row scaled by sqrt(mu) (the reference keeps it unwhitened and applies mu in
+ *     its error functions); gsx_hessian_diagonal counts it unwhitened, as JacobianFactor::hessianDiagonalAdd does;
+ *   - gsx_stats.n_constraint_rows / n_constrained_fronts; a clique that takes constraint rows in is always a blocked front;
+ *   - NOT available on such a problem: marginal covariances (GSX_E_STATE) and sharding (gsx_set_ordering fails);
+ *   - a constraint row whose entries in its clique's frontal variables all vanish NUMERICALLY although its factor
+ *     holds them (a rank-deficient constraint Jacobian) is reported as GSX_E_INDETERMINATE by the solve — the reference
+ *     passes such a row on to the parent clique. */
+
 /* ---- ordering kinds for gsx_compute_ordering ----------------------------- */
 enum {
   GSX_ORDER_NATURAL = 0,    /* ascending key                                      */

@@ -112,9 +112,17 @@ inline bool lower_noise(const gtsam::SharedNoiseModel& model, int rows, int& kin
   if (!base || base->isUnit()) kind = GSX_NOISE_UNIT;
   else if (auto iso = std::dynamic_pointer_cast<Isotropic>(base)) kind = GSX_NOISE_ISOTROPIC, params = {iso->sigma()};
   else if (auto dg = std::dynamic_pointer_cast<Diagonal>(base)) {
-    if (std::dynamic_pointer_cast<Constrained>(base)) return false;  // constrained models: QR path of the reference, not lowered
     const gtsam::Vector s = dg->sigmas();
     kind = GSX_NOISE_DIAGONAL, params.assign(s.data(), s.data() + s.size());
+    if (auto con = std::dynamic_pointer_cast<Constrained>(base)) {
+      // zero sigmas = hard-constraint rows (constraint pivots on the device, constraint.hip), with their error weights mu
+      if (robust) return false;
+      for (int r = 0; r < s.size(); ++r)
+        if (s[r] != 0.0 && !std::isfinite(1.0 / s[r])) return false;  // (Constrained::constrained() of a denormal sigma)
+      const gtsam::Vector mu = con->mu();
+      kind = GSX_NOISE_CONSTRAINED;
+      params.insert(params.end(), mu.data(), mu.data() + mu.size());
+    }
   } else if (auto g = std::dynamic_pointer_cast<Gaussian>(base)) {
     const gtsam::Matrix R = g->R();  // upper-triangular sqrt information, row-major in the ABI
     kind = GSX_NOISE_GAUSSIAN;
@@ -243,15 +251,23 @@ class GsxLevenbergMarquardtOptimizer : public gtsam::LevenbergMarquardtOptimizer
     // [A b] blocks in graph order, noise folded in (JacobianFactor::whiten)
     std::vector<double> blocks;
     std::vector<JacobianFactor> white;
+    std::vector<std::vector<double>> unit_sigmas;   // per factor: empty, or Constrained::unit()'s sigmas (0 = hard constraint)
     white.reserve(gfg.size());
     for (const auto& f : gfg) {
       if (!f) continue;
       auto jf = std::dynamic_pointer_cast<JacobianFactor>(f);
+      unit_sigmas.emplace_back();
+      if (jf && jf->get_model() && jf->get_model()->isConstrained()) {
+        const Vector s = jf->get_model()->sigmas();
+        for (int r = 0; r < s.size(); ++r) unit_sigmas.back().push_back(s[r] == 0.0 ? 0.0 : 1.0);
+      }
+      // (whiten() leaves a constraint row as it is: Constrained::WhitenInPlace, NoiseModel.cpp:456-468)
       white.push_back(jf ? jf->whiten() : JacobianFactor(*f).whiten());  // (a HessianFactor is rare on this path)
       const Matrix Ab = white.back().augmentedJacobian();                // m x (sum d + 1), column-major
       blocks.insert(blocks.end(), Ab.data(), Ab.data() + Ab.size());
     }
-    if (!linear_ || white.size() != linear_factors_) build_linear_handle(gfg, white, params);
+    if (!linear_ || white.size() != linear_factors_ || unit_sigmas != linear_unit_sigmas_)
+      build_linear_handle(gfg, white, unit_sigmas, params);
     std::vector<double> delta(linear_dim_);
     uint64_t bad = 0;
     const gsx_status st = gsx_solve_gfg_h(linear_, blocks.data(), (int64_t)blocks.size(), delta.data(), (int64_t)delta.size(), &bad);
@@ -374,6 +390,7 @@ class GsxLevenbergMarquardtOptimizer : public gtsam::LevenbergMarquardtOptimizer
   }
 
   void build_linear_handle(const gtsam::GaussianFactorGraph& gfg, const std::vector<gtsam::JacobianFactor>& white,
+                           const std::vector<std::vector<double>>& unit_sigmas,
                            const gtsam::NonlinearOptimizerParams& params) const {
     using namespace gtsam;
     if (linear_) gsx_destroy(linear_);
@@ -382,12 +399,16 @@ class GsxLevenbergMarquardtOptimizer : public gtsam::LevenbergMarquardtOptimizer
     for (Key k : gfg.keys()) L.index[k] = (int)L.keys.size(), L.keys.push_back(k);
     L.types.assign(L.keys.size(), GSX_VAR_VECTOR);
     L.dims.assign(L.keys.size(), 0);
-    for (const JacobianFactor& w : white) {
+    for (size_t i = 0; i < white.size(); ++i) {
+      const JacobianFactor& w = white[i];
       const Matrix Ab = w.augmentedJacobian();
       for (auto it = w.begin(); it != w.end(); ++it) L.dims[L.index.at(*it)] = (int)w.getDim(it);
+      // a factor with hard-constraint rows: a diagonal model of sigmas 0 / 1 (the device eliminates the zero rows exactly)
       L.add_factor(GSX_F_LINEAR, (int)Ab.rows(), std::vector<Key>(w.begin(), w.end()),
-                   std::vector<double>(Ab.data(), Ab.data() + Ab.size()), GSX_NOISE_UNIT, {});
+                   std::vector<double>(Ab.data(), Ab.data() + Ab.size()),
+                   unit_sigmas[i].empty() ? GSX_NOISE_UNIT : GSX_NOISE_DIAGONAL, unit_sigmas[i]);
     }
+    linear_unit_sigmas_ = unit_sigmas;
     const gsx_problem_desc d = L.desc();
     check(gsx_create(&d, device, &linear_), nullptr, "gsx_create");
     const Ordering ordering = params.ordering ? *params.ordering : Ordering::Create(params.orderingType, gfg);
@@ -402,6 +423,7 @@ class GsxLevenbergMarquardtOptimizer : public gtsam::LevenbergMarquardtOptimizer
   mutable gsx_handle linear_ = nullptr;          // the L1 handle: built at the first solve(), kept for the run
   mutable std::vector<Key> linear_keys_;
   mutable std::vector<int32_t> linear_dims_;
+  mutable std::vector<std::vector<double>> linear_unit_sigmas_;
   mutable size_t linear_dim_ = 0, linear_factors_ = 0;
 };
 

@@ -315,3 +315,35 @@ def test_partial_reelimination_with_constraints_is_bit_identical(gpu, kind, n):
         df = F.solve(0.0, False)
         assert np.array_equal(P.jacobians(), F.jacobians()), round_
         assert np.array_equal(dp, df), (round_, float(np.max(np.abs(dp - df))))
+
+
+def test_linear_seam_on_a_kept_handle_with_constraints(gpu, oracle):
+    """gsx_solve_gfg_h (the NonlinearOptimizer::solve seam) on a graph with constraint rows: the structure — including which
+    rows are constraints — is analysed once, every call hands over new [A b] numbers."""
+    from tests.test_oracle_golden import constrained_linear_graphs
+    name, fg, expected = constrained_linear_graphs()[2]   # createMultiConstraintGraph
+    arrays = linear_arrays(fg)
+    be = gpu.product_backend(arrays)
+    be.set_ordering([0, 1, 2])
+    x = be.solve_gfg_h(None)
+    off = arrays.tangent_offsets()
+    for k, v in expected.items():
+        assert np.allclose(x[off[k]:off[k + 1]], v, atol=1e-9)
+    rng = np.random.default_rng(4)
+    for trial in range(3):
+        fg2 = GaussianFactorGraph()
+        blocks = []
+        for f in fg.factors:
+            m = f.rows
+            Ab = f.meas.reshape(-1, m).T + 0.3 * rng.normal(size=(m, f.meas.size // m))
+            blocks.append(Ab)
+            args = []
+            c = 0
+            for k, d in zip(f.keys_, f.block_dims):
+                args += [k, Ab[:, c:c + d]]
+                c += d
+            fg2.add(JacobianFactor(*args, Ab[:, -1], f.noise) if f.noise is not None else JacobianFactor(*args, Ab[:, -1]))
+        want = fg2.optimize([0, 1, 2], backend_factory=oracle.oracle_backend)
+        got = be.solve_gfg_h(blocks)
+        for k, v in want.items():
+            assert np.allclose(got[off[k]:off[k + 1]], v, rtol=1e-9, atol=1e-10), (trial, k)
