@@ -915,6 +915,82 @@ __global__ void assemble_h_kernel(DevProblem P, DevSymbolic S, const int* vars, 
     out[e] = s;
   }
 }
+// Variables whose factors are all NARROW — at most 16 columns with the rhs, at most 8 rows: every factor of a pose graph
+// (6 x 13, 3 x 7), priors, pose-landmark projections (2 x 10) — and that have at most 64 terms.  A wave per variable, four
+// variables a workgroup.  Per factor ONE matrix-core product G = [A b]'[A b] (16 x 16 tile, v_mfma_f64_16x16x4 per four
+// rows; the operand X[k][i] = entry (row k, column i) of the block is both the A and the B operand), loaded with one or two
+// loads a lane — the generic kernel above reads every entry of the block once per panel entry it contributes to, a
+// dozen dependent round trips per variable where this one has two: the term records, then the blocks of up to kTF factors
+// together.  The panel entries of the factor's terms are picked out of G and added to the LDS panel term by term in list
+// order: deterministic.  (JacobianFactor::updateHessian, gtsam/linear/JacobianFactor.cpp:586-624.)
+constexpr int kTF = 8;   // factors whose blocks are in flight together
+__global__ void __launch_bounds__(256) assemble_h_tile_kernel(DevProblem P, DevSymbolic S, const int* vars, int count,
+                                                              int panel_stride, const double* jac, double* H) {
+  extern __shared__ double lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int slot = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+  if (slot >= count) return;
+  const int v = vars[slot];
+  const int dA = P.var_dim[v], rows = S.h_rows[v], psize = rows * dA;
+  double* panel = lds + (size_t)wave * panel_stride;
+  for (int e = lane; e < psize; e += 64) panel[e] = 0;
+  const i64 tb0 = S.term_ptr[v];
+  const int nt = (int)(S.term_ptr[v + 1] - tb0);   // <= 64 (host)
+  TermRec rec{0, 0, 0, 0, 0, 0, 0};
+  if (lane < nt) rec = S.terms[tb0 + lane];
+  const int li = lane & 15, lk = lane >> 4;
+  int t = 0;
+  while (t < nt) {
+    // the next (up to kTF) factors: a factor's terms are consecutive and share its Jacobian offset; the rhs term is its last
+    int fbeg[kTF + 1];
+    double x0[kTF], x1[kTF];
+    int nf = 0, tt = t;
+#pragma unroll
+    for (int q = 0; q < kTF; ++q) {
+      fbeg[q] = tt;
+      if (tt < nt) {
+        const i64 jo = readlane_i64(rec.jac, tt);
+        int te = tt + 1;
+        while (te < nt && readlane_i64(rec.jac, te) == jo) ++te;
+        const int m = __builtin_amdgcn_readlane(rec.m, tt);
+        const int ncols = __builtin_amdgcn_readlane(rec.colB, te - 1) + 1;
+        const double* J = jac + jo;
+        const bool in = li < ncols;
+        x0[q] = (in && lk < m) ? J[li * m + lk] : 0.0;
+        x1[q] = (in && lk + 4 < m) ? J[li * m + lk + 4] : 0.0;
+        tt = te;
+        nf = q + 1;
+      } else {
+        x0[q] = x1[q] = 0.0;
+      }
+    }
+    fbeg[kTF] = tt;
+#pragma unroll
+    for (int q = 0; q < kTF; ++q) {
+      if (q >= nf) break;
+      v4d g = {0.0, 0.0, 0.0, 0.0};
+      g = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[q], x0[q], g, 0, 0, 0);
+      g = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[q], x1[q], g, 0, 0, 0);
+      const int te = fbeg[q + 1];
+      for (int k = fbeg[q]; k < te; ++k) {
+        const int colA = __builtin_amdgcn_readlane(rec.colA, k), colB = __builtin_amdgcn_readlane(rec.colB, k);
+        const int dB = __builtin_amdgcn_readlane(rec.dB, k), dst = __builtin_amdgcn_readlane(rec.dst, k);
+        const int j = li - colA;
+        if (j >= 0 && j < dA) {
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const int i = lk + 4 * r4 - colB;   // G[lk + 4 r4][li] = sum_k X[k][colB + i] X[k][colA + j]
+            if (i >= 0 && i < dB) panel[dst + i + j * rows] += g[r4];
+          }
+        }
+      }
+    }
+    t = tt;
+  }
+  double* out = H + S.h_off[v];
+  for (int e = lane; e < psize; e += 64) out[e] = panel[e];
+}
+
 // panels too large for LDS: one wave accumulates straight into the (zeroed) global panel
 __global__ void assemble_h_global_kernel(DevProblem P, DevSymbolic S, const int* vars, const double* jac, double* H) {
   const int v = vars[blockIdx.x];
@@ -1282,6 +1358,10 @@ void launch_assemble_h_group(const DevProblem& P, const DevSymbolic& S, const in
   }
   if (threads == -1) {  // (mode: star variables, a wave each)
     assemble_h_star_kernel<<<(count + 3) / 4, 256, 0, st>>>(P, S, vars, count, jac, H);
+    return;
+  }
+  if (threads == -2) {  // (mode: variables of narrow factors, a wave each; lds_bytes = four panels)
+    assemble_h_tile_kernel<<<(count + 3) / 4, 256, lds_bytes, st>>>(P, S, vars, count, lds_bytes / 32, jac, H);
     return;
   }
   if (global) assemble_h_global_kernel<<<count, 64, 0, st>>>(P, S, vars, jac, H);

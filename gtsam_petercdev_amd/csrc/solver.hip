@@ -598,7 +598,23 @@ gsx_status upload_symbolic(gsx_context* c) {
       int v, psize;
       int64_t terms;
     };
-    std::vector<VI> light, heavy, huge, diag, star;
+    std::vector<VI> light, heavy, huge, diag, star, tile;
+    // a "tile" variable: at most 64 terms, all from NARROW factors (<= 16 columns with the rhs, <= 8 rows): one matrix-core
+    // product per factor (assemble_h_tile_kernel).  GSX_H_TILE_OFF keeps the generic kernel (measurements).
+    static const bool tile_off = std::getenv("GSX_H_TILE_OFF") != nullptr;
+    auto is_tile = [&](int v) {
+      const int64_t tb = S.term_ptr[v], te = S.term_ptr[v + 1];
+      if (tile_off || te - tb < 2 || te - tb > 64 || (int64_t)S.h_rows[v] * P.dims[v] * 8 * 4 > 48 * 1024) return false;
+      int64_t t = tb;
+      while (t < te) {
+        int64_t e = t + 1;
+        while (e < te && S.t_jac[e] == S.t_jac[t]) ++e;
+        // the factor's last term is its rhs term: column index = number of columns - 1
+        if (S.t_m[t] > 8 || S.t_dB[e - 1] != 1 || S.t_dst[e - 1] != S.h_rows[v] - 1 || S.t_colB[e - 1] + 1 > 16) return false;
+        t = e;
+      }
+      return true;
+    };
     // a "star" variable: all its factors are binary with a later-eliminated partner, all of one shape (three terms
     // each: own block, partner block, rhs — with equal rows, columns and partner dimension)
     std::vector<int> star_dst;
@@ -629,6 +645,7 @@ gsx_status upload_symbolic(gsx_context* c) {
       }
       // no later neighbour through any factor (panel = own block + rhs) and many factors: the matrix-core kernel
       if (terms >= 64 && S.h_rows[v] == P.dims[v] + 1 && P.dims[v] <= 15) diag.push_back({v, psize, terms});
+      else if (is_tile(v)) tile.push_back({v, psize, terms});
       else if (terms >= 96 && (int64_t)psize * 4 * 8 <= 48 * 1024) heavy.push_back({v, psize, terms});
       else if ((int64_t)psize * 8 <= 48 * 1024) light.push_back({v, psize, terms});
       else huge.push_back({v, psize, terms});
@@ -651,6 +668,8 @@ gsx_status upload_symbolic(gsx_context* c) {
         i = j;
       }
     };
+    std::stable_sort(tile.begin(), tile.end(), by_psize);
+    emit(tile, -2, 4, false);   // (four waves a workgroup, a panel each)
     emit(light, 64, 1, false);
     emit(heavy, 256, 4, false);
     emit(huge, 64, 1, true);
@@ -2237,6 +2256,11 @@ gsx_status gsx_dogleg_optimize(gsx_handle h, double delta_initial, int32_t max_i
     h->err = "Dogleg is not available on a sharded handle";
     return GSX_E_STATE;
   }
+  if (h->constrained()) {
+    // (the steepest-descent leg of the dog leg knows nothing of the constraint rows: a blended step would violate them)
+    h->err = "Dogleg is not available on a problem with hard constraints";
+    return GSX_E_STATE;
+  }
   hipSetDevice(h->device);
   const int64_t nt = h->P.tan_size;
   if (!h->d_dlu.p) {
@@ -2424,7 +2448,12 @@ gsx_status partial_factor(gsx_handle h, std::vector<int>& dfr) {
       std::vector<std::array<int, 4>> leaf;   // begin, count, max_panel, threads
       std::vector<SmallLaunch> small;         // ranges of `ids`, with the launch shape of the full schedule's group
       int big_begin = 0, big_count = 0;
-      BigPlan big_plan;
+      std::vector<int> big_fronts;             // the level's dirty blocked fronts
+      // ... by UPPER level: a blocked front is factored with the plan (chunk width, kernel shapes) of its launch group in
+      // the full schedule — the group is an upper level — so that the same front takes the same rounds and the same
+      // kernels whatever else is dirty (found at config-5 size: a plan made for the dirty subset alone picked another
+      // chunk width, and the step differed from the full path's in the last bits)
+      std::vector<std::array<int, 3>> big_sub; // begin, count, upper level
       // the gather segments of the level's dirty blocked fronts by gather group (launched one group after the other, in
       // the full schedule's order: the side / lean group before the stored children's — same sums, same bits)
       struct GroupPlan {
@@ -2463,10 +2492,8 @@ gsx_status partial_factor(gsx_handle h, std::vector<int>& dfr) {
           L.small.back().count++;
           ids.push_back(f);
         } else {
-          if (!L.big_count) L.big_begin = (int)big.size();
           const BigDesc& d = h->big_descs[g];
-          big.push_back(d);
-          L.big_count++;
+          L.big_fronts.push_back(f);
           big_max_n = std::max(big_max_n, d.N);
           big_max_nfv = std::max(big_max_nfv, S.nfrontal_vars[f]);
           // its gather segments (sources: ALL its children, clean or not), at the level the full schedule runs them
@@ -2482,7 +2509,15 @@ gsx_status partial_factor(gsx_handle h, std::vector<int>& dfr) {
     }
     for (int l = 0; l < S.n_levels; ++l) {
       LevelPlan& L = plan[l];
-      plan_big_group(big.data() + L.big_begin, L.big_count, L.big_plan);
+      std::stable_sort(L.big_fronts.begin(), L.big_fronts.end(), [&](int a, int b) { return S.ulevel[a] < S.ulevel[b]; });
+      L.big_begin = (int)big.size();
+      L.big_count = (int)L.big_fronts.size();
+      for (int f : L.big_fronts) {
+        const int ul = S.ulevel[f];
+        if (L.big_sub.empty() || L.big_sub.back()[2] != ul) L.big_sub.push_back({(int)big.size(), 0, ul});
+        L.big_sub.back()[1]++;
+        big.push_back(h->big_descs[h->fr_group[f]]);
+      }
       // group order: the side group (index n_ulevels) and group 0 hold the lean leaves' sums — first, as in the full
       // schedule; inside a group no particular order is needed (every segment adds into its own destination block or its
       // own scratch slot)
@@ -2539,7 +2574,8 @@ gsx_status partial_factor(gsx_handle h, std::vector<int>& dfr) {
             if (cd >= 0)
               launch_constraint_fronts(h->DS, h->CT, cd, 1, big[k].N, h->d_jac.p, h->d_arena.p, h->d_status.p, sm);
           }
-        dev_big_factor(h, ps.big.p + L.big_begin, L.big_count, L.big_plan, sm, false);
+        for (const auto& sg : L.big_sub)
+          dev_big_factor(h, ps.big.p + sg[0], sg[1], h->big_level[sg[2]].plan, sm, false);
       }
     }
     // (all cliques: the clean ones' pivots are resident and unchanged, the test is two loads a clique)

@@ -150,7 +150,9 @@ enum {
  *   - gsx_get_jacobians returns a constraint row scaled by sqrt(mu) (the reference keeps it unwhitened and applies mu in
  *     its error functions); gsx_hessian_diagonal counts it unwhitened, as JacobianFactor::hessianDiagonalAdd does;
  *   - gsx_stats.n_constraint_rows / n_constrained_fronts; a clique that takes constraint rows in is always a blocked front;
- *   - NOT available on such a problem: marginal covariances (GSX_E_STATE) and sharding (gsx_set_ordering fails);
+ *   - gsx_get_conditional of a clique with constraint pivots gives an EQUIVALENT conditional (a pivot row has unit
+ *     diagonal and comes first in its clique's elimination), not the reference's row for row;
+ *   - NOT available on such a problem: marginal covariances and Dogleg (GSX_E_STATE), sharding (gsx_set_ordering fails);
  *   - a constraint row whose entries in its clique's frontal variables all vanish NUMERICALLY although its factor
  *     holds them (a rank-deficient constraint Jacobian) is reported as GSX_E_INDETERMINATE by the solve — the reference
  *     passes such a row on to the parent clique. */

@@ -279,6 +279,8 @@ def test_redundant_and_unsupported(gpu):
     assert np.allclose(be.solve(0.0, False), [1.0, -1.0, 1.5, -0.5], atol=1e-12)
     with pytest.raises(A.GsxError):
         be.marginal_covariance(0)
+    with pytest.raises(A.GsxError):
+        be.dogleg_optimize()
 
 
 @pytest.mark.parametrize("kind,n", [("pose2", 500), ("pose3", 400)])
@@ -346,4 +348,4 @@ def test_linear_seam_on_a_kept_handle_with_constraints(gpu, oracle):
         want = fg2.optimize([0, 1, 2], backend_factory=oracle.oracle_backend)
         got = be.solve_gfg_h(blocks)
         for k, v in want.items():
-            assert np.allclose(got[off[k]:off[k + 1]], v, rtol=1e-9, atol=1e-10), (trial, k)
+            assert np.allclose(got[off[k]:off[k + 1]], v, rtol=1e-7, atol=1e-9), (trial, k)

@@ -196,3 +196,68 @@ def test_reference_metis_ordering_through_the_hip_path(gpu, oracle, golden_dir, 
     assert np.allclose(rg["trace_lambda"], ro["trace_lambda"], rtol=1e-9)
     assert abs(rg["final_error"] - ro["final_error"]) <= 1e-6 * ro["final_error"]
     assert relerr(gb.get_values(), ob.get_values()) < 1e-6
+
+
+@pytest.mark.parametrize("K,M,OBS", [(2000, 200000, 900000), (10000, 1000000, 4500000)])
+def test_keyframe_update_at_config_5_size_matches_a_fresh_handle(gpu, K, M, OBS):
+    """BASELINE config 5 (VisualISAM2Example-style growth) at its stated size, 10 000 keyframes / 1 000 000 landmarks /
+    4 500 000 projections (and a fifth of it): a handle optimised up to keyframe K - 2 takes keyframe K - 1 through
+    gsx_update (its pose, the landmarks that become observable, their factors) and must then hold exactly what a fresh handle
+    on the grown graph holds at the same values and ordering — graph error, the kept and the new [A b], the Gauss-Newton
+    step — and one relinearize-partial round after it is bit for bit the handle's own full path.  (No oracle at this size: the two
+    sides are two independent routes through the product, and the route through a fresh handle is the one every other test
+    pins against the oracle.)"""
+    a1, id1 = datasets.synth_visual_slam(K, M, OBS, upto=K - 1)
+    a2, id2 = datasets.synth_visual_slam(K, M, OBS)
+    pos = {int(i): k for k, i in enumerate(id1)}
+    origin = np.array([pos.get(int(i), -1) for i in id2], dtype=np.int32)
+    so, old = a2.state_offsets(), set(int(k) for k in a1.var_keys)
+    new_idx = [i for i, k in enumerate(a2.var_keys) if int(k) not in old]
+    new_states = np.concatenate([a2.values[so[i]:so[i + 1]] for i in new_idx])
+    pb = gpu.product_backend(a1)
+    pb.set_ordering(pb.compute_ordering(A.ORDER_SCHUR_ND))
+    p = A.lm_params_legacy()
+    p.max_iterations = 2
+    pb.lm_optimize(p)
+    pb.linearize()
+    pb.solve(0.0, False, want_delta=False)
+    st = pb.update(a2, origin, new_states)
+    assert st["n_vars_added"] == len(new_idx) and st["n_factors_added"] == int(np.sum(origin < 0))
+    assert st["n_factors_removed"] == 0
+    fresh = datasets.synth_visual_slam(K, M, OBS)[0]
+    fresh.values = pb.get_values()
+    fb = gpu.product_backend(fresh)
+    fb.set_ordering(pb.get_ordering())
+    assert abs(pb.error() - fb.error()) <= 1e-12 * abs(fb.error())
+    fb.linearize()
+    jp, jf = pb.jacobians(), fb.jacobians()     # kept factors keep their blocks (copied), the new ones are linearized
+    assert np.max(np.abs(jp - jf)) <= 1e-12 * np.max(np.abs(jf))
+    del jp, jf
+    # the undamped system of a graph whose newest landmarks have two or three views is nearly singular (steps of 1e2): there
+    # the two handles are compared through what the step achieves — the linearized error at the step — and the steps
+    # themselves on the damped systems of an LM iteration
+    dp, df = pb.solve(0.0, False), fb.solve(0.0, False)
+    ep, ef = pb.linear_error(), fb.linear_error()
+    assert np.allclose(ep, ef, rtol=1e-9), (ep, ef)
+    for lam in (1e-3, 1.0):
+        dp, df = pb.solve(lam, False), fb.solve(lam, False)
+        assert relerr(dp, df) < 1e-8, (lam, relerr(dp, df))
+    pb.solve(0.0, False, want_delta=False)      # (gsx_relinearize_partial works on the undamped factorization)
+    # an iSAM2-style relinearization of the ten most recent keyframes on the updated handle: bit for bit the full path
+    so2 = a2.state_offsets()
+    idx = np.nonzero(a2.var_types == A.VAR_POSE3)[0][-10:]
+    cur = pb.get_values()
+    rng = np.random.default_rng(5)
+    states = np.concatenate([cur[so2[i]:so2[i + 1]] for i in idx])
+    for k in range(len(idx)):
+        states[12 * k + 9:12 * k + 12] += 1e-3 * rng.standard_normal(3)     # translations only
+        cur[so2[idx[k]] + 9:so2[idx[k]] + 12] = states[12 * k + 9:12 * k + 12]
+    stp = pb.relinearize_partial(a2.var_keys[idx], states)
+    assert 0 < stp["n_fronts_reeliminated"] < 0.05 * stp["n_fronts"]
+    dp = pb.solve(0.0, False)
+    assert np.array_equal(pb.get_values(), cur)
+    pb.linearize()                               # the full path on the same handle at the same values
+    assert np.array_equal(dp, pb.solve(0.0, False))
+    fb.set_values(cur)
+    fb.linearize()
+    assert relerr(pb.solve(1e-3, False), fb.solve(1e-3, False)) < 1e-8
