@@ -16,7 +16,7 @@ struct FactorRec {
   int s0, s1;                 // state offsets of the first two variables (-1: none)
   int meas_off, noise_off;    // doubles into meas / noise
   int type_kind;              // f_type | noise kind (with the robust bits) << 8 | type of the first variable << 24
-  int rows_dim;               // rows | dimension of the first variable << 16
+  int rows_dim;               // rows | dimension of the first variable (<= 255) << 8 | columns of [A b] << 16
 };
 // Immutable problem tables on the device (graph order).
 struct DevProblem {

@@ -518,10 +518,10 @@ __device__ inline double factor_error(const DevProblem& P, int f, const double* 
     return whitened_half_sqnorm<6>(e, kind, np);
   }
   // generic: priors, vector between
-  const int m = fr.rows_dim & 0xffff;
+  const int m = fr.rows_dim & 0xff;
   double e[9];
   if (type == GSX_F_PRIOR) {
-    local_coords(vt, fr.rows_dim >> 16, values + fr.s0, z, e);
+    local_coords(vt, (fr.rows_dim >> 8) & 0xff, values + fr.s0, z, e);
   } else {
     const double* x1 = values + fr.s0;
     const double* x2 = values + fr.s1;
@@ -724,8 +724,9 @@ __global__ void __launch_bounds__(256) lin0_kernel(DevProblem P, const double* j
   double acc = 0;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < P.n_active; k += gridDim.x * blockDim.x) {
     const int f = P.f_active ? P.f_active[k] : k;
-    const int m = P.f_rows[f];
-    const double* b = jac + P.f_jac_off[f] + (i64)m * (P.f_cols[f] - 1);
+    const FactorRec fr = P.frec[f];   // (one 32-byte record instead of three table lookups before the first load of b)
+    const int m = fr.rows_dim & 0xff;
+    const double* b = jac + fr.jac_off + (i64)m * (int)(((unsigned)fr.rows_dim >> 16) - 1u);
     double s = 0;
     for (int r = 0; r < m; ++r) s += b[r] * b[r];
     acc += 0.5 * s;

@@ -456,12 +456,16 @@ gsx_status upload_problem(gsx_context* c) {
     }
     std::vector<FactorRec> fr(std::max(P.n_factors, 1));
     for (int f = 0; f < P.n_factors; ++f) {
+      if (P.f_cols[f] >= 32768 || P.f_rows[f] > 255) {
+        c->err = "factor too wide for the packed factor record";
+        return GSX_E_INVALID;
+      }
       const int kp = P.f_key_ptr[f], nk = P.f_key_ptr[f + 1] - kp;
       const int v0 = nk > 0 ? P.f_vars[kp] : -1, v1 = nk > 1 ? P.f_vars[kp + 1] : -1;
       fr[f] = FactorRec{(i64)P.f_jac_off[f], v0 >= 0 ? P.state_off[v0] : -1, v1 >= 0 ? P.state_off[v1] : -1,
                         (int)P.f_meas_ptr[f], (int)P.f_noise_ptr[f],
                         P.f_type[f] | (P.f_noise_kind[f] << 8) | ((v0 >= 0 ? P.types[v0] : 0) << 24),
-                        P.f_rows[f] | ((v0 >= 0 ? P.dims[v0] : 0) << 16)};
+                        P.f_rows[f] | (std::min(v0 >= 0 ? P.dims[v0] : 0, 255) << 8) | (P.f_cols[f] << 16)};
     }
     HIPCHK(c, c->d_frec.upload(fr, st));
   }
