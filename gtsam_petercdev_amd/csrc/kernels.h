@@ -145,8 +145,9 @@ __host__ __device__ inline i64 big_panel_offset(int n) { return ((i64)n * n + 1)
 // ---- launches (all asynchronous on `st`) ---------------------------------------------------------
 void launch_linearize(const DevProblem& P, const int* const type_lists[6], const int type_counts[6],
                       const double* values, double* jac, DevStatus* status, hipStream_t st);
-void launch_error(const DevProblem& P, const double* values, double* partials, int n_partials_cap,
-                  double* scalars, int slot, hipStream_t st);
+// the graph error over the type lists of launch_linearize (a kernel per list, the factor type a compile-time constant)
+void launch_error(const DevProblem& P, const int* const type_lists[6], const int type_counts[6], const double* values,
+                  double* partials, int n_partials_cap, double* scalars, int slot, hipStream_t st);
 // slice > 0: the staged kernel (doubles of LDS per wave = the largest [A b] range of 64 consecutive factors); 0: the direct one
 void launch_linear_error(const DevProblem& P, const double* jac, const double* delta, double* partials,
                          int n_partials_cap, double* scalars, int slice, hipStream_t st);

@@ -459,9 +459,12 @@ void launch_linearize(const DevProblem& P, const int* const type_lists[6], const
 // ---------------------------------------------------------------------------------------------
 // graph error (NoiseModelFactor::error, gtsam/nonlinear/NonlinearFactor.cpp:138-149)
 // ---------------------------------------------------------------------------------------------
+// FT / FV >= 0: the factor type / the type of its first variable are known at compile time (the per-type kernels below:
+// the one-kernel-for-all form needed 247 registers, two waves a SIMD); -1: read from the record.
+template <int FT = -1, int FV = -1>
 __device__ inline double factor_error(const DevProblem& P, int f, const double* values) {
   const FactorRec fr = P.frec[f];
-  const int type = fr.type_kind & 0xff;
+  const int type = FT >= 0 ? FT : (fr.type_kind & 0xff);
   if (type == GSX_F_LINEAR) return 0.0;
   const int kind = (fr.type_kind >> 8) & 0xffff;
   const double* np = P.noise + fr.noise_off;
@@ -504,7 +507,7 @@ __device__ inline double factor_error(const DevProblem& P, int f, const double* 
     }
     return whitened_half_sqnorm<2>(e, kind, np);
   }
-  const int vt = (fr.type_kind >> 24) & 0xff;
+  const int vt = FV >= 0 ? FV : ((fr.type_kind >> 24) & 0xff);
   if (type == GSX_F_BETWEEN && vt == GSX_VAR_POSE2) {
     const P2 h = compose(inverse(load_pose2(values + fr.s0)), load_pose2(values + fr.s1));
     const P2 zh = compose(inverse(load_pose2(z)), h);
@@ -544,14 +547,6 @@ __device__ inline double factor_error(const DevProblem& P, int f, const double* 
   return 0.5 * s;
 }
 
-__global__ void __launch_bounds__(256) error_kernel(DevProblem P, const double* values, double* partials) {
-  double acc = 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n_active; i += gridDim.x * blockDim.x)
-    acc += factor_error(P, P.f_active ? P.f_active[i] : i, values);
-  const double s = block_sum(acc);
-  if (threadIdx.x == 0) partials[blockIdx.x] = s;
-}
-
 __global__ void __launch_bounds__(256) reduce_final_kernel(const double* partials, int n, int stride, double* scalars,
                                                            int slot) {
   double acc = 0;
@@ -569,12 +564,42 @@ __global__ void __launch_bounds__(256) reduce_final_pair_kernel(const double* pa
   if (threadIdx.x == 0) scalars[slot0 + blockIdx.x] = s;
 }
 
-void launch_error(const DevProblem& P, const double* values, double* partials, int cap, double* scalars, int slot,
-                  hipStream_t st) {
-  int nb = (P.n_active + 255) / 256;
-  nb = nb < 1 ? 1 : (nb > cap ? cap : nb);
-  error_kernel<<<nb, 256, 0, st>>>(P, values, partials);
-  reduce_final_kernel<<<1, 256, 0, st>>>(partials, nb, 1, scalars, slot);
+// the factors of one type list (the lists of launch_linearize), the type a compile-time constant
+template <int FT, int FV>
+__global__ void __launch_bounds__(256) error_list_kernel(DevProblem P, const int* list, int n, const double* values,
+                                                         double* partials) {
+  double acc = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    acc += factor_error<FT, FV>(P, list[i], values);
+  const double s = block_sum(acc);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+void launch_error(const DevProblem& P, const int* const type_lists[6], const int type_counts[6], const double* values,
+                  double* partials, int cap, double* scalars, int slot, hipStream_t st) {
+  // a launch per non-empty list, its blocks a share of the partial sums proportional to its factors; the sums are added in
+  // list order, block order: deterministic
+  long long total = 0;
+  for (int k = 0; k < 6; ++k) total += type_counts[k];
+  int off = 0;
+  for (int k = 0; k < 6; ++k) {
+    const int n = type_counts[k];
+    if (!n) continue;
+    int nb = (n + 255) / 256;
+    const int share = (int)std::max<long long>(1, (long long)(cap - 6) * n / std::max<long long>(total, 1));
+    nb = std::min(nb, share);
+    double* out = partials + off;
+    switch (k) {
+      case 0: error_list_kernel<GSX_F_SFM, GSX_VAR_CAMERA><<<nb, 256, 0, st>>>(P, type_lists[k], n, values, out); break;
+      case 1: error_list_kernel<GSX_F_BETWEEN, GSX_VAR_POSE2><<<nb, 256, 0, st>>>(P, type_lists[k], n, values, out); break;
+      case 2: error_list_kernel<GSX_F_BETWEEN, GSX_VAR_POSE3><<<nb, 256, 0, st>>>(P, type_lists[k], n, values, out); break;
+      case 4: error_list_kernel<GSX_F_PROJECTION, GSX_VAR_POSE3><<<nb, 256, 0, st>>>(P, type_lists[k], n, values, out); break;
+      case 5: error_list_kernel<GSX_F_BEARINGRANGE, GSX_VAR_POSE2><<<nb, 256, 0, st>>>(P, type_lists[k], n, values, out); break;
+      default: error_list_kernel<-1, -1><<<nb, 256, 0, st>>>(P, type_lists[k], n, values, out); break;
+    }
+    off += nb;
+  }
+  reduce_final_kernel<<<1, 256, 0, st>>>(partials, off, 1, scalars, slot);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1475,7 +1475,9 @@ void dev_retract(gsx_context* c, const double* d_delta) {
 }
 void dev_error(gsx_context* c, const double* d_vals, int slot) {
   timer_begin(c, PH_ERROR);
-  launch_error(c->DP, d_vals, c->d_partials.p, gsx_context::kPartials, c->d_scalars.p, slot, c->stream);
+  const int* lists[6] = {c->d_type_list[0].p, c->d_type_list[1].p, c->d_type_list[2].p, c->d_type_list[3].p,
+                         c->d_type_list[4].p, c->d_type_list[5].p};
+  launch_error(c->DP, lists, c->type_count, d_vals, c->d_partials.p, gsx_context::kPartials, c->d_scalars.p, slot, c->stream);
   c->sc_dirty |= 1u << slot;
   timer_end(c, PH_ERROR);
 }
