@@ -9,8 +9,8 @@
 // turned into an UNCONSTRAINED front with the same conditionals and the same Schur complement, which the blocked kernels
 // then factor as they factor every other front.  With y = (x, -1) (the rhs row of a front is its last row), M the front's
 // augmented Hessian and C y = 0 the rows:
-//   1. constraint_reduce_kernel: Gauss-Jordan on C with pivots in FRONTAL columns only (the row with the largest entry
-//      in the column, if that exceeds 1e-9 — check_if_constraint, NoiseModel.cpp:483-501).  Pivot columns P, the others
+//   1. constraint_reduce_kernel: Gauss-Jordan on C with pivots in FRONTAL columns only (complete pivoting among them; an
+//      entry counts if it exceeds 1e-9 — check_if_constraint, NoiseModel.cpp:483-501).  Pivot columns P, the others
 //      O (separator and rhs included):  y_P = -R y_O.  Rows that found no frontal pivot go to the front where the first
 //      of their variables is frontal (symbolic.cpp).
 //   2. the quadratic restricted to the constraint is  1/2 y_O' (E'ME) y_O  with E = [-R; I].  The front written back is
@@ -56,8 +56,9 @@ __global__ void __launch_bounds__(256) constraint_reduce_kernel(const ConDesc* d
   const double* A = arena + d.off;
   __shared__ double colj[kConMaxRows];
   __shared__ unsigned char used[kConMaxRows];
-  __shared__ int s_best, s_np, s_nfwd, s_fail;
+  __shared__ int s_np, s_nfwd, s_fail;
   __shared__ double s_red[256];
+  __shared__ int s_ri[256], s_rc[256];
 
   // ---- the rows: the front's own (from the Jacobian store), then the children's leftovers ----
   for (i64 e = tid; e < (i64)K * n; e += nt) C[e] = 0;
@@ -82,44 +83,67 @@ __global__ void __launch_bounds__(256) constraint_reduce_kernel(const ConDesc* d
   }
   __syncthreads();
 
-  // ---- Gauss-Jordan, pivots in the frontal columns ----
-  for (int j = 0; j < d.F; ++j) {
-    if (s_np >= K) break;   // (uniform: s_np changes only between barriers)
-    for (int i = tid; i < K; i += nt) colj[i] = C[(i64)i * n + j];
-    __syncthreads();
-    if (tid == 0) {
-      int best = -1;
-      double mx = 1e-9;
-      for (int i = 0; i < K; ++i) {
-        if (used[i]) continue;
-        const double a = fabs(colj[i]);
-        if (a > mx) {
-          mx = a;
-          best = i;
-        }
-      }
-      s_best = best;
-      if (best >= 0) {
-        used[best] = 1;
-        colpiv[j] = s_np;
-        prow[s_np] = best;
-        pcol[s_np] = j;
-        s_np = s_np + 1;
+  // ---- Gauss-Jordan, pivots in the frontal columns.  COMPLETE pivoting: each step takes the largest entry left among
+  //      the unused rows and the unused frontal columns (> 1e-9, the threshold of check_if_constraint).  Constrained::QR
+  //      walks the columns in order and takes the best row for each; a row it leaves without a frontal pivot that way
+  //      still finds one among the later columns of its staggered [R d] — here the frontal columns are all a row can use
+  //      before it must go to another front, so the choice must not strand a row that the frontal block could absorb
+  //      (a Pose3 between-constraint: its rotation rows are zero in the translation columns).  Any complete set of
+  //      pivots gives the same constrained minimiser. ----
+  const int max_steps = min(K, d.F);
+  for (int step = 0; step < max_steps; ++step) {
+    // the largest eligible entry: (value, row, column), ties to the smaller row, then column
+    double bv = 1e-9;
+    int bi = -1, bc = -1;
+    for (i64 e = tid; e < (i64)K * d.F; e += nt) {
+      const int i = (int)(e / d.F), c = (int)(e % d.F);
+      if (used[i] || colpiv[c] >= 0) continue;
+      const double a = fabs(C[(i64)i * n + c]);
+      if (a > bv) {
+        bv = a;
+        bi = i;
+        bc = c;
       }
     }
+    s_red[tid] = bv;
+    s_ri[tid] = bi;
+    s_rc[tid] = bc;
     __syncthreads();
-    const int best = s_best;
-    if (best >= 0) {
-      const double inv = 1.0 / colj[best];
-      for (int c = tid; c < n; c += nt) {
-        const double pr = C[(i64)best * n + c] * inv;
-        for (int i = 0; i < K; ++i) {
-          if (i == best) continue;
-          const double a = colj[i];
-          if (a != 0.0) C[(i64)i * n + c] -= a * pr;
+    for (int w = nt >> 1; w > 0; w >>= 1) {
+      if (tid < w) {
+        const double ov = s_red[tid + w];
+        const int oi = s_ri[tid + w], oc = s_rc[tid + w];
+        const bool better = oi >= 0 && (s_ri[tid] < 0 || ov > s_red[tid] ||
+                                        (ov == s_red[tid] && (oi < s_ri[tid] || (oi == s_ri[tid] && oc < s_rc[tid]))));
+        if (better) {
+          s_red[tid] = ov;
+          s_ri[tid] = oi;
+          s_rc[tid] = oc;
         }
-        C[(i64)best * n + c] = pr;
       }
+      __syncthreads();
+    }
+    const int best = s_ri[0], j = s_rc[0];
+    __syncthreads();
+    if (best < 0) break;   // (uniform)
+    for (int i = tid; i < K; i += nt) colj[i] = C[(i64)i * n + j];
+    if (tid == 0) {
+      used[best] = 1;
+      colpiv[j] = s_np;
+      prow[s_np] = best;
+      pcol[s_np] = j;
+      s_np = s_np + 1;
+    }
+    __syncthreads();
+    const double inv = 1.0 / colj[best];
+    for (int c = tid; c < n; c += nt) {
+      const double pr = C[(i64)best * n + c] * inv;
+      for (int i = 0; i < K; ++i) {
+        if (i == best) continue;
+        const double a = colj[i];
+        if (a != 0.0) C[(i64)i * n + c] -= a * pr;
+      }
+      C[(i64)best * n + c] = pr;
     }
     __syncthreads();
   }

@@ -946,6 +946,9 @@ gsx_status symbolic_analysis(const HostProblem& P, const std::vector<int>& order
       if (rtop[t] != t) continue;
       const int v = order[t], f = S.front_of_var[v];
       if (!S.scheduled.empty() && !S.scheduled[f]) continue;
+      // (a clique with constraint rows goes through EliminateQR in the reference: no conditioning test there, and the
+      //  rewritten front mixes unit pivots with those of the soft rows)
+      if (!S.con.empty() && S.con[f]) continue;
       const int d = P.dims[v];
       const int64_t ld = S.N[f];
       const int c1 = S.h_loc[v] + d - 1;

@@ -349,3 +349,44 @@ def test_linear_seam_on_a_kept_handle_with_constraints(gpu, oracle):
         got = be.solve_gfg_h(blocks)
         for k, v in want.items():
             assert np.allclose(got[off[k]:off[k + 1]], v, rtol=1e-7, atol=1e-9), (trial, k)
+
+
+@pytest.mark.parametrize("seed", range(96))
+def test_constraint_fuzz(gpu, oracle, seed):
+    """Random pose graphs, random factors made constraints (all rows or a random subset, random mu), random ordering and
+    amalgamation: the damped and undamped steps against the oracle's QR path."""
+    rng = np.random.default_rng(1000 + seed)
+    kind = "pose2" if seed % 2 == 0 else "pose3"
+    d = 3 if kind == "pose2" else 6
+    n = int(rng.integers(15, 160))
+    arr = (datasets.synth_manhattan_pose2 if kind == "pose2" else datasets.synth_manhattan_pose3)(n, seed=int(rng.integers(1, 1000)))
+    cand = np.flatnonzero((arr.f_type == A.F_PRIOR) | (arr.f_type == A.F_BETWEEN))
+    chosen = rng.choice(cand, size=int(rng.integers(1, 5)), replace=False)
+    models = {}
+    for f in chosen:
+        sig = rng.uniform(0.05, 0.5, d)
+        rows = rng.random(d) < 0.5
+        if not rows.any() or rng.random() < 0.4:
+            rows[:] = True
+        sig[rows] = 0.0
+        models[int(f)] = (sig, float(rng.choice([1.0, 50.0, 1000.0]))) if rng.random() < 0.5 else sig
+    arr = with_constraints(arr, models)
+    rows = constraint_rows(arr)
+    gb, ob = gpu.product_backend(arr), oracle.oracle_backend(arr)
+    which = int(rng.integers(0, 4))
+    if which == 0:
+        ordering = arr.var_keys.copy()
+    elif which == 1:
+        ordering = arr.var_keys[::-1].copy()
+    else:
+        ordering = gb.compute_ordering(A.ORDER_MINDEGREE if which == 2 else A.ORDER_ND)
+    gb.set_amalgamation(float(rng.choice([0.0, 0.5, 2.0])), int(rng.choice([16, 64, 128])))
+    gb.set_ordering(ordering)
+    ob.set_ordering(ordering)
+    assert gb.stats()["n_constraint_rows"] == len(rows)
+    gb.linearize()
+    ob.linearize()
+    for lam, diag in [(0.0, False), (1e-2, False), (1e-1, True)]:
+        dg, do = gb.solve(lam, diag), ob.solve(lam, diag)
+        assert np.linalg.norm(dg - do) <= 1e-7 * np.linalg.norm(do), (seed, lam, diag, np.linalg.norm(dg - do) / np.linalg.norm(do))
+        assert np.allclose(gb.linear_error(), ob.linear_error(), rtol=1e-6), (seed, lam)

@@ -7,6 +7,7 @@ for w in pose3_100k pose2_100k bal49; do timeout -k 10 300 python bench.py --wor
 timeout -k 10 300 python bench.py --ordering metis --no-cpu-baseline --no-secondary > $out/bal1723_metis_bench.json 2>/dev/null && echo bal metis ok
 timeout -k 10 300 python bench.py --workload pose3_100k --ordering metis --no-cpu-baseline > $out/pose3_100k_metis_bench.json 2>/dev/null && echo pose3 metis ok
 timeout -k 10 300 python bench.py --workload pose2_100k --ordering metis --no-cpu-baseline > $out/pose2_100k_metis_bench.json 2>/dev/null && echo pose2 metis ok
+for w in pose3_100k pose2_100k; do timeout -k 10 300 python bench.py --workload $w --hard-prior --no-cpu-baseline --no-secondary > $out/${w}_hard_prior.json 2>/dev/null && echo $w hard prior ok; done
 bash tools_prof.sh r03final/prof_bal1723 --steps 20 --warmup 3 --no-secondary > $out/prof_bal1723.txt 2>&1 && echo prof bal ok
 bash tools_prof.sh r03final/prof_pose3 --workload pose3_100k --steps 20 --warmup 3 > $out/prof_pose3.txt 2>&1 && echo prof pose3 ok
 bash tools_pmc.sh r03final/pmc_fetch_bal FETCH_SIZE --steps 5 --warmup 1 --no-secondary > /dev/null 2>&1 && echo pmc fetch bal ok
