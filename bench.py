@@ -204,13 +204,20 @@ def pmc_traffic(kernel, workload):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_pmc_traffic.json")), reverse=True):
         try:
             doc = json.load(open(path))
-            k = doc["kernels"][kernel.split("(")[0]]
+            # a pooled roofline entry ("front_small_kernel (+front_tree, front_medium)"): bytes per launch over all its kernels
+            names = [kernel.split("(")[0].strip()]
+            if "(+" in kernel:
+                names += [n.strip() + "_kernel" for n in kernel.split("(+")[1].rstrip(")").split(",")]
+            ks = [doc["kernels"][n] for n in names if n in doc["kernels"]]
+            if not ks:
+                raise KeyError(kernel)
         except (OSError, KeyError, ValueError):
             continue
         rel = os.path.relpath(path, ROOT)
         if now is None or doc.get("csrc_sha1") != now:
             return None, rel + " (stale: captured from other kernel sources)"
-        return k["fetch_bytes"] + k["write_bytes"], rel
+        launches = sum(k.get("launches", 1) for k in ks)
+        return sum((k["fetch_bytes"] + k["write_bytes"]) * k.get("launches", 1) for k in ks) / max(launches, 1), rel
     return None, None
 
 
