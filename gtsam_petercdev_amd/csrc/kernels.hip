@@ -2592,17 +2592,38 @@ void launch_front_small(const DevProblem& P, const DevSymbolic& S, const int* id
 // matrix in LDS, no zeroing of it, no trailing-update sweeps (the reference allocates and sweeps the full
 // (F+S+1)^2 augmented Hessian per landmark: HessianFactor.cpp:240-253, cholesky.cpp:108-143).
 // ---------------------------------------------------------------------------------------------
-__global__ void front_leaf_kernel(DevProblem P, DevSymbolic S, const LeafRec* recs, const double* H, const double* damp,
-                                  const double* scalars, double* arena, DevStatus* status) {
-  extern __shared__ double Pn[];  // n x F, column-major, ld = n
-  const LeafRec rec = recs[blockIdx.x];
+// PACK: four cliques a workgroup, a WAVE each (the launch groups whose cliques run with 64 threads: every BAL landmark) —
+// an experiment (see launch_front_leaf): 78 000 one-wave workgroups in 150 us keep a tenth of the chip's wave slots
+// occupied (SQ counters: 3 600 cycles a wave), but starting fewer, larger workgroups does not change that.  The
+// arithmetic of a clique is the same instruction sequence either way.
+template <bool PACK>
+__device__ __forceinline__ void leaf_sync() {
+  if (PACK) {  // one wave: LDS traffic of its lanes is ordered once the counter has drained
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
+}
+template <bool PACK>
+__global__ void front_leaf_kernel(DevProblem P, DevSymbolic S, const LeafRec* recs, int count, int panel_stride,
+                                  const double* H, const double* damp, const double* scalars, double* arena,
+                                  DevStatus* status) {
+  extern __shared__ double leaf_lds[];  // n x F, column-major, ld = n (PACK: four of them, panel_stride apart)
+  const int sub = PACK ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;   // (wave-uniform: the record stays scalar)
+  const int slot = PACK ? (int)blockIdx.x * 4 + sub : (int)blockIdx.x;
+  if (slot >= count) return;   // (PACK: a whole wave; no workgroup barrier below)
+  double* Pn = leaf_lds + (size_t)sub * panel_stride;
+  const LeafRec rec = recs[slot];
   const int f = rec.front;
   const int n = rec.n, F = rec.F;
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = PACK ? (int)(threadIdx.x & 63) : (int)threadIdx.x, nt = PACK ? 64 : (int)blockDim.x;
   const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
   const double lambda = scalars[SC_LAMBDA];
   for (int e = tid; e < n * F; e += nt) Pn[e] = 0;
-  __syncthreads();
+  leaf_sync<PACK>();
   for (int k = 0; k < rec.nfv; ++k) {
     // the first frontal variable's panel is described by the record itself; further ones (merged leaf cliques of
     // pose graphs) by their VarRec
@@ -2639,21 +2660,21 @@ __global__ void front_leaf_kernel(DevProblem P, DevSymbolic S, const LeafRec* re
         if (dst[u] >= 0) Pn[dst[u]] = x[u];
     }
   }
-  __syncthreads();
+  leaf_sync<PACK>();
   int fail = 0;
   for (int j = 0; j < F; ++j) {
     const double p = Pn[j + j * n];
     if (!(p > 0)) fail = 1;
     const double s = (p > 0) ? sqrt(p) : 1.0;
     const double inv = 1.0 / s;
-    __syncthreads();
+    leaf_sync<PACK>();
     for (int r = j + tid; r < n; r += nt) Pn[r + j * n] = (r == j) ? s : Pn[r + j * n] * inv;
-    __syncthreads();
+    leaf_sync<PACK>();
     for (int c = j + 1 + wave; c < F; c += nw) {
       const double lc = Pn[c + j * n];
       for (int r = c + lane; r < n; r += 64) Pn[r + c * n] -= Pn[r + j * n] * lc;
     }
-    __syncthreads();
+    leaf_sync<PACK>();
   }
   // (choleskyPartial's conditioning test runs per reference clique after the factorization: cond_check_kernel)
   if (fail && tid == 0) report_failure(status, f);
@@ -2724,9 +2745,18 @@ void launch_cond_check(int n, const i64* last, const i64* prev, const int* front
 void launch_front_leaf(const DevProblem& P, const DevSymbolic& S, const LeafRec* recs, int count, int max_panel, int threads,
                        const double* H, const double* damp, const double* scalars, double* arena, DevStatus* status,
                        hipStream_t st) {
-  if (count)
-    front_leaf_kernel<<<count, threads, (size_t)max_panel * sizeof(double), st>>>(P, S, recs, H, damp, scalars, arena,
-                                                                                   status);
+  if (!count) return;
+  // one-wave cliques four to a workgroup while four panels stay a small share of a CU's LDS
+  // MEASURED AND SWITCHED OFF (GSX_LEAF_PACK=1 with GSX_LEAF_SPLIT=1024 turns it on): on BAL-1723 the main-queue launch
+  // goes 148 -> 138 us, the low-priority one 178 -> 346 us, the LM iteration 1.797 -> 1.793 ms (noise) — the leaf launches
+  // are not bound by how fast workgroups start (a thousand waves in flight either way; tools/r03_leaf.sh)
+  static const bool pack_on = std::getenv("GSX_LEAF_PACK") != nullptr;
+  if (pack_on && threads == 64 && (size_t)max_panel * sizeof(double) * 4 <= 32 * 1024)
+    front_leaf_kernel<true><<<(count + 3) / 4, 256, (size_t)max_panel * sizeof(double) * 4, st>>>(
+        P, S, recs, count, max_panel, H, damp, scalars, arena, status);
+  else
+    front_leaf_kernel<false><<<count, threads, (size_t)max_panel * sizeof(double), st>>>(P, S, recs, count, 0, H, damp,
+                                                                                          scalars, arena, status);
 }
 
 // ---------------------------------------------------------------------------------------------

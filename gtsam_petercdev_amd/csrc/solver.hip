@@ -751,7 +751,12 @@ gsx_status upload_symbolic(gsx_context* c) {
       //  the tallest; the launches by (F, height) were each bound by the latency of one leaf: pose2_100k 11 x 18 us ->
       //  38 us, pose3_100k 4 x 21 -> 30)
       const bool all = !narrow && (le - S.lvl_ptr[l]) <= 16384;
-      while (j < le && (all || (S.F[S.sched[j]] == F0 && (narrow || S.N[S.sched[j]] * 2 <= n0 * 3)))) {
+      // (experiment, off: GSX_LEAF_SPLIT=<doubles> puts the narrow cliques with a panel above the limit in a launch of their
+      //  own, so that launch_front_leaf can pack the others four to a workgroup — GSX_LEAF_PACK, measured: no gain)
+      static const int pack_limit = std::getenv("GSX_LEAF_SPLIT") ? std::atoi(std::getenv("GSX_LEAF_SPLIT")) : (1 << 30);
+      auto packable = [&](int k) { return S.N[S.sched[k]] * S.F[S.sched[k]] <= pack_limit; };
+      while (j < le && (all || (S.F[S.sched[j]] == F0 &&
+                                ((narrow && packable(j) == packable(i)) || (!narrow && S.N[S.sched[j]] * 2 <= n0 * 3))))) {
         maxp = std::max(maxp, S.N[S.sched[j]] * S.F[S.sched[j]]);
         maxn = std::max(maxn, S.N[S.sched[j]]);
         ++j;
