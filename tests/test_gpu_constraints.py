@@ -390,3 +390,49 @@ def test_constraint_fuzz(gpu, oracle, seed):
         dg, do = gb.solve(lam, diag), ob.solve(lam, diag)
         assert np.linalg.norm(dg - do) <= 1e-7 * np.linalg.norm(do), (seed, lam, diag, np.linalg.norm(dg - do) / np.linalg.norm(do))
         assert np.allclose(gb.linear_error(), ob.linear_error(), rtol=1e-6), (seed, lam)
+
+
+@pytest.mark.parametrize("order", [A.ORDER_SCHUR, A.ORDER_SCHUR_ND, A.ORDER_MINDEGREE])
+@pytest.mark.parametrize("relax", [0.0, 0.25])
+def test_bundle_adjustment_with_a_hard_gauge(gpu, oracle, order, relax):
+    """BAL-shaped problem whose gauge is fixed by HARD priors (Constrained::All) on the first camera and the first point
+    instead of soft ones (SFMExample_bal.cpp:61-67 adds soft ones): the constrained cliques are a camera front with lean
+    landmark children and a landmark clique that would otherwise be a lean leaf."""
+    arr = datasets.synth_bal_arrays(12, 150, 700, seed=3, long_range=0.3, priors=True)
+    pri = np.flatnonzero(arr.f_type == A.F_PRIOR)
+    assert len(pri) == 2
+    arr = with_constraints(arr, {int(pri[0]): np.zeros(9), int(pri[1]): (np.zeros(3), 10.0)})
+    rows = constraint_rows(arr)
+    assert len(rows) == 12
+    gb, ob = gpu.product_backend(arr), oracle.oracle_backend(arr)
+    ordering = gb.compute_ordering(order)
+    gb.set_amalgamation(relax, 128)
+    gb.set_ordering(ordering)
+    ob.set_ordering(ordering)
+    assert gb.stats()["n_constrained_fronts"] == 2
+    assert abs(gb.error() - ob.error()) <= 1e-11 * abs(ob.error())
+    gb.linearize()
+    ob.linearize()
+    for lam, diag in [(1e-4, False), (1.0, False), (1e-3, True)]:
+        dg, do = gb.solve(lam, diag), ob.solve(lam, diag)
+        # (a bundle adjustment damped by 1e-4 has a condition number near 1e9: both eliminations are compared with the
+        #  dense KKT solution, each within what that conditioning allows, and with each other)
+        tol = 1e-8 if lam >= 1.0 else 2e-6
+        if not diag:
+            dk = dense_kkt_step(arr, ob.jacobians(), rows, lam, np.ones(int(arr.var_dims.sum())))
+            assert np.linalg.norm(dg - dk) <= tol * np.linalg.norm(dk), (lam, np.linalg.norm(dg - dk) / np.linalg.norm(dk))
+            assert np.linalg.norm(do - dk) <= tol * np.linalg.norm(dk), (lam, np.linalg.norm(do - dk) / np.linalg.norm(dk))
+        assert np.linalg.norm(dg - do) <= tol * np.linalg.norm(do), (lam, diag, np.linalg.norm(dg - do) / np.linalg.norm(do))
+        toff = arr.tangent_offsets()
+        for f, r, mu in rows:   # the hard-prior variables do not move
+            v = int(arr.f_vars[arr.f_key_ptr[f]])
+            assert abs(dg[toff[v] + r] - do[toff[v] + r]) <= 1e-10
+    p = A.lm_params_legacy()
+    p.max_iterations = 8
+    gb2, ob2 = gpu.product_backend(arr), oracle.oracle_backend(arr)
+    gb2.set_amalgamation(relax, 128)
+    gb2.set_ordering(ordering)
+    ob2.set_ordering(ordering)
+    rg, ro = gb2.lm_optimize(p), ob2.lm_optimize(p)
+    assert rg["iterations"] == ro["iterations"] and np.array_equal(rg["trace_accepted"], ro["trace_accepted"])
+    assert abs(rg["final_error"] - ro["final_error"]) <= 1e-6 * max(ro["final_error"], 1e-12)
