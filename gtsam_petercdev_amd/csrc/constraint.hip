@@ -6,8 +6,8 @@
 // sigma 0 — and is substituted into every other row; the other columns are weighted Gram-Schmidt steps.
 //
 // Here the fronts are Hessians (J'J) and the elimination is a blocked Cholesky, so the constraint rows of a front are
-// turned into an UNCONSTRAINED front with the same conditionals and the same Schur complement, which the blocked kernels
-// then factor as they factor every other front.  With y = (x, -1) (the rhs row of a front is its last row), M the front's
+// turned into an UNCONSTRAINED front with equivalent conditionals (the same solution for the frontal variables given the
+// separator) and the same Schur complement, which the blocked kernels then factor as they factor every other front.  With y = (x, -1) (the rhs row of a front is its last row), M the front's
 // augmented Hessian and C y = 0 the rows:
 //   1. constraint_reduce_kernel: Gauss-Jordan on C with pivots in FRONTAL columns only (complete pivoting among them; an
 //      entry counts if it exceeds 1e-9 — check_if_constraint, NoiseModel.cpp:483-501).  Pivot columns P, the others

@@ -135,7 +135,7 @@ struct Symbolic {
   // its factor is frontal; there it is used as a PIVOT (one frontal scalar expressed by the others — no Cholesky step for
   // it), or, when the front has fewer frontal scalars than rows, handed to the parent.  A front that takes rows in is
   // always BLOCKED (cls 2): its assembled panel is in the arena, where the constraint kernels rewrite it into an
-  // unconstrained front with the same conditionals and the same Schur complement (solver.hip: constraint_*).
+  // unconstrained front with equivalent conditionals and the same Schur complement (constraint.hip).
   std::vector<char> con;               // front -> takes constraint rows in
   std::vector<int> con_fronts;         // those fronts, children before parents
   std::vector<int> con_index;          // front -> index in con_fronts, -1
