@@ -20,6 +20,8 @@ from gtsam_petercdev_amd.graph import (X, L, Pose2, Pose3, Rot3, Point2, Point3,
                                        GaussNewtonOptimizer)
 
 pytestmark = pytest.mark.gpu
+# GSX_FUZZ_OFFSET=<n> moves every structure fuzz below to other seeds (an occasional wider sweep; the default is what CI runs)
+FUZZ_OFFSET = int(__import__("os").environ.get("GSX_FUZZ_OFFSET", "0"))
 
 
 @pytest.fixture(scope="module")
@@ -1045,7 +1047,7 @@ def test_random_linear_graphs(gpu, oracle, seed):
     """Structure fuzz: random linear-Gaussian graphs — chains with random chords, hubs with many neighbours (leaf cliques
     with tall separators), dense clusters (blocked fronts), variables of 1-9 dimensions — under every ordering and three
     amalgamation settings, against the oracle.  Aimed at the boundaries between the kernels' size classes."""
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(1000 + seed + FUZZ_OFFSET)
     nv = int(rng.choice([4, 9, 30, 70, 140, 260]))
     dim_sets = ([3], [6], [1, 2, 3], [2, 6, 9], [9, 3])
     ds = dim_sets[seed % len(dim_sets)]
@@ -1183,11 +1185,11 @@ def test_random_bal_structures(gpu, oracle, seed):
     product-form complements), one landmark seen by every camera, one camera that sees a landmark it also sees through a
     second (duplicate) observation, under the Schur orderings, plain and relaxed trees: H diagonal, damped steps, three LM
     iterations against the oracle."""
-    rng = np.random.default_rng(300 + seed)
+    rng = np.random.default_rng(300 + seed + FUZZ_OFFSET)
     nc = int(rng.choice([3, 7, 12, 17, 30, 55]))
     npts = int(rng.choice([40, 150, 600]))
     nobs = int(npts * min(rng.choice([2.5, 4.0, 7.0]), 0.8 * nc))
-    arr = datasets.synth_bal_arrays(nc, npts, max(nobs, 2 * npts), seed=300 + seed, long_range=float(rng.choice([0.0, 0.3, 1.0])),
+    arr = datasets.synth_bal_arrays(nc, npts, max(nobs, 2 * npts), seed=300 + seed + FUZZ_OFFSET, long_range=float(rng.choice([0.0, 0.3, 1.0])),
                                     priors=True)
     n_sfm = int((arr.f_type == A.F_SFM).sum())
     cams = arr.f_vars[0:2 * n_sfm:2]
@@ -1253,7 +1255,7 @@ def _random_pose2_graph(rng, nv, cluster):
 def test_optimizers_on_random_structures(gpu, oracle, seed):
     """LM (legacy and Ceres policies), Gauss-Newton and Dogleg on random Pose2 structures: the oracle's accept/reject
     trace, lambda / trust-region schedule and errors."""
-    rng = np.random.default_rng(900 + seed)
+    rng = np.random.default_rng(900 + seed + FUZZ_OFFSET)
     nv = int(rng.choice([15, 80, 200]))
     g, v = _random_pose2_graph(rng, nv, seed % 2 == 0)
     arr = g.to_arrays(v)
@@ -1285,7 +1287,7 @@ def test_partial_reelimination_on_random_structures(gpu, seed):
     """Structure fuzz of the filtered launch plans: random Pose2 graphs with chords, hubs and a dense cluster; random sets
     of moved variables; gsx_relinearize_partial + back-substitution must stay bit for bit the full path, and the
     wildfire pass at threshold 0 likewise."""
-    rng = np.random.default_rng(500 + seed)
+    rng = np.random.default_rng(500 + seed + FUZZ_OFFSET)
     nv = int(rng.choice([12, 60, 150, 400]))
     g, v = _random_pose2_graph(rng, nv, seed % 2 == 0)
     arr = g.to_arrays(v)
