@@ -20,7 +20,10 @@ from gtsam_petercdev_amd.graph import (X, L, Pose2, Pose3, Rot3, Point2, Point3,
                                        GaussNewtonOptimizer)
 
 pytestmark = pytest.mark.gpu
-# GSX_FUZZ_OFFSET=<n> moves every structure fuzz below to other seeds (an occasional wider sweep; the default is what CI runs)
+# GSX_FUZZ_OFFSET=<n> moves every structure fuzz below to other seeds (an occasional wider sweep; the default is what CI runs).
+# End of round 3: twelve offsets x 155 cases, one miss — test_random_bal_structures[2] at offset 77000, a bundle whose
+# rejected trials reach errors of 1e11: after three LM iterations the final error differs by 9e-6 from the oracle's, while
+# the oracle's own two orderings differ by 1e-6 there (conditioning, not a kernel).
 FUZZ_OFFSET = int(__import__("os").environ.get("GSX_FUZZ_OFFSET", "0"))
 
 
